@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Every array below is produced by calling the reference's own Python functions /
+modules (imported where they lie, see ``ref_import.py``); the only stand-in is
+``torch_scatter`` (``oracle/scatter_ref.py``, parity unpinned for the
+scatter_max tie-break).  Fixtures are data only: inputs, weights and expected
+outputs.  SURVEY.md section 8c lists what each fixture pins.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from ref_import import import_reference, make_cfg  # noqa: E402
+from detinit import det_init_, synth_cloud  # noqa: E402
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def edge_xy(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.rand(1, m, 2, generator=g)
+    edge = torch.tensor([2.0 ** -20, 1 - 2.0 ** -24, 0.5, 0.25, 0.75, 1 / 256, 255 / 256, 1 / 16, 15 / 16,
+                         0.49999997, 0.99999, 3 / 128, 1e-6])
+    k = edge.numel()
+    xy[0, :k, 0] = edge
+    xy[0, :k, 1] = edge.flip(0)
+    xy[0, k:2 * k, 0] = edge
+    xy[0, k:2 * k, 1] = 0.3
+    return xy.float()
+
+
+def main():
+    ref = import_reference()
+    from utils.coordinate import coordinate2index
+    from tomosar2height.encoder.pointnet import LocalPoolPointnet
+    from tomosar2height.encoder.alto import DownConv
+    from tomosar2height.block import ResnetBlockFC
+    from tomosar2height.decoder.pixel import PixelwiseDecoder
+    import trainer as ref_trainer
+
+    torch.manual_seed(0)
+
+    # (1) coordinate2index -- utils/coordinate.py:12-28
+    xy = edge_xy(200, 1)
+    arrs = {"xy": xy}
+    for reso in (2, 16, 32, 64, 128, 256):
+        arrs[f"index_r{reso}"] = coordinate2index(xy, reso)
+    save("coordinate2index", **arrs)
+
+    # (3b) the reference's own known-answer vector -- pointnet.py:114-123
+    from torch_scatter import scatter_mean
+    pxy = torch.tensor([[[0., 0.], [0.3, 0.9], [0.9, 0.3], [0.9, 0.9], [0.1, 0.2]]])
+    idx = coordinate2index(pxy, 2)
+    plane = scatter_mean(pxy.permute(0, 2, 1), idx, out=pxy.new_zeros(1, 2, 4)).reshape(1, 2, 2, 2)
+    save("pointnet_main_vector", xy=pxy, index=idx, plane=plane)
+
+    # (2) pool_local fwd + grad -- pointnet.py:92-99, with ties and an all-equal cell
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                            unet_kwargs=dict(depth=2, merge_mode="concat", start_filts=8), plane_resolution=16)
+    arrs = {}
+    for reso in (4, 16):
+        enc.reso_plane = reso
+        cloud = synth_cloud(300, seed=10 + reso)
+        g = torch.Generator().manual_seed(reso)
+        feat = torch.randn(1, 300, 8, generator=g)
+        feat = (feat * 4).round() / 4          # quantised -> many exact ties
+        idx = coordinate2index(cloud[:, :, :2], reso)
+        cell0 = idx[0, 0] == idx[0, 0, 0]
+        feat[0, cell0] = 1.25                  # one all-equal cell: argmax = first point
+        feat.requires_grad_(True)
+        out = enc.pool_local(idx, feat)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        arrs.update({f"xy_r{reso}": cloud[:, :, :2], f"feat_r{reso}": feat, f"index_r{reso}": idx,
+                     f"out_r{reso}": out, f"gout_r{reso}": gout, f"gfeat_r{reso}": feat.grad})
+    save("pool_local", **arrs)
+
+    # (3) generate_plane_features fwd + grad -- pointnet.py:101-111, incl. empty cells
+    arrs = {}
+    for reso, c in ((4, 8), (16, 8), (32, 12)):
+        enc.reso_plane, enc.c_dim = reso, c
+        cloud = synth_cloud(257, seed=20 + reso)
+        g = torch.Generator().manual_seed(100 + reso)
+        feat = torch.randn(1, 257, c, generator=g, requires_grad=True)
+        idx = coordinate2index(cloud[:, :, :2], reso)
+        plane = enc.generate_plane_features({"xy": idx}, feat, "xy")
+        gout = torch.randn(plane.shape, generator=g)
+        plane.backward(gout)
+        arrs.update({f"xy_r{reso}": cloud[:, :, :2], f"feat_r{reso}": feat, f"plane_r{reso}": plane,
+                     f"gout_r{reso}": gout, f"gfeat_r{reso}": feat.grad})
+    save("scatter_mean_plane", **arrs)
+
+    # (4) sample_plane_feature fwd + plane grad -- alto.py:90-95
+    down = DownConv(4, 4, 0, False, depth=2)
+    arrs = {}
+    for r, c in ((8, 4), (16, 8), (5, 3)):
+        g = torch.Generator().manual_seed(200 + r)
+        plane = torch.randn(1, c, r, r, generator=g, requires_grad=True)
+        p = synth_cloud(150, seed=30 + r)
+        corners = torch.tensor([[0., 0.], [1., 0.], [0., 1.], [1., 1.], [.5, .5], [1 - 2.0 ** -24, 2.0 ** -20],
+                                [1 / (r - 1), 2 / (r - 1)], [0.999999, 0.5]])
+        p[0, :corners.shape[0], :2] = corners
+        out = down.sample_plane_feature(p, plane)           # [1, C, N]
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        arrs.update({f"p_r{r}": p, f"plane_r{r}": plane, f"out_r{r}": out, f"gout_r{r}": gout,
+                     f"gplane_r{r}": plane.grad})
+    save("grid_sample_points", **arrs)
+
+    # (5) ResnetBlockFC 64->32 and 32->32 -- block/resnet.py
+    arrs = {}
+    for cin, cout in ((64, 32), (32, 32)):
+        blk = det_init_(ResnetBlockFC(cin, cout), seed=5)
+        g = torch.Generator().manual_seed(cin)
+        x = torch.randn(50, cin, generator=g, requires_grad=True)
+        y = blk(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        tag = f"{cin}_{cout}"
+        arrs.update({f"x_{tag}": x, f"y_{tag}": y, f"gy_{tag}": gy, f"gx_{tag}": x.grad})
+        for k, v in blk.state_dict().items():
+            arrs[f"w_{tag}.{k}"] = v
+        for k, v in blk.named_parameters():
+            arrs[f"g_{tag}.{k}"] = v.grad
+    save("resnet_block_fc", **arrs)
+
+    # (6) LocalPoolPointnet reduced -- pointnet.py:60-90 + alto.py
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16)
+    det_init_(enc, seed=6)
+    cloud = synth_cloud(256, seed=40)
+    out = enc(cloud)["xy"]
+    g = torch.Generator().manual_seed(6)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    arrs = {"cloud": cloud, "out": out, "gout": gout}
+    none_grad = []
+    for k, v in enc.state_dict().items():
+        arrs["w." + k] = v
+    for k, v in enc.named_parameters():
+        if v.grad is None:
+            none_grad.append(k)
+        else:
+            arrs["g." + k] = v.grad
+    arrs["none_grad"] = np.array(none_grad)
+    save("local_pool_pointnet_reduced", **arrs)
+
+    # (7) PixelwiseDecoder small -- pixel.py:94-125
+    arrs = {}
+    for mode in ("conv", "fc"):
+        for foot in (False, True):
+            for img in (False, True):
+                dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode=mode,
+                                                 use_footprint=foot), seed=7)
+                g = torch.Generator().manual_seed(7)
+                planes = {"xy": torch.randn(1, 32, 16, 16, generator=g, requires_grad=True)}
+                if img:
+                    planes["image"] = torch.randn(1, 32, 32, 32, generator=g)
+                xy_plane = planes["xy"]
+                # the reference's `c += planes['xy']` aliases nothing: c starts as int 0
+                x, xf = dec(dict(planes))
+                loss = x.sum() + (xf.sum() * 0.5 if xf is not None else 0)
+                loss.backward()
+                tag = f"{mode}_f{int(foot)}_i{int(img)}"
+                arrs[f"xy_{tag}"] = xy_plane
+                if img:
+                    arrs[f"image_{tag}"] = planes["image"]
+                arrs[f"x_{tag}"] = x
+                if xf is not None:
+                    arrs[f"xf_{tag}"] = xf
+                arrs[f"gxy_{tag}"] = xy_plane.grad
+                arrs[f"keys_{tag}"] = np.array(list(dec.state_dict().keys()))
+    save("pixelwise_decoder", **arrs)
+
+    # (8) full-size models, N = 4096, name-keyed deterministic weights (tests/detinit.py)
+    for tag, kw in (("berlin", dict(depth=5)),
+                    ("munich", dict(depth=6, use_image=True, use_footprint=True, z_bound=(465.5, 599.5)))):
+        cfg = make_cfg(**kw)
+        model = det_init_(ref.TomoSAR2Height(cfg), seed=8)
+        cloud = synth_cloud(4096, seed=50)
+        g = torch.Generator().manual_seed(8)
+        image = torch.randn(1, 3, 512, 512, generator=g) if kw.get("use_image") else None
+        dsm_lo = torch.rand(1, 64, 64, generator=g) * 30       # stored; dsm = 8x8 block replicate
+        dsm = dsm_lo.repeat_interleave(8, 1).repeat_interleave(8, 2)
+        pa, pb = model(input_cloud=cloud, input_image=image)
+        loss = torch.nn.functional.l1_loss(pa.squeeze(), dsm.squeeze())
+        if pb is not None:
+            loss = loss + 10.0 * torch.nn.functional.binary_cross_entropy_with_logits(
+                pb.squeeze(), (dsm.squeeze() > 0.0001).float())
+        loss.backward()
+        names, gnorm, gsum, none_grad = [], [], [], []
+        for k, v in model.named_parameters():
+            if v.grad is None:
+                none_grad.append(k)
+                continue
+            names.append(k)
+            gnorm.append(v.grad.double().norm().item())
+            gsum.append(v.grad.double().sum().item())
+        arrs = dict(cloud=cloud, dsm_lo=dsm_lo, height=pa[0, :, :, 0], loss=loss.detach(),
+                    grad_names=np.array(names), grad_norm=np.array(gnorm), grad_sum=np.array(gsum),
+                    none_grad=np.array(none_grad), n_params=sum(p.numel() for p in model.parameters()),
+                    state_keys=np.array(list(model.state_dict().keys())))
+        if image is not None:
+            arrs["image_seed"] = 8          # regenerate: randn(1,3,512,512) from Generator(8), first draw
+        if pb is not None:
+            arrs["footprint_logits"] = pb[0, :, :, 0]
+        save(f"full_model_{tag}_n4096", **arrs)
+
+    # (9) Trainer.train_step accumulation semantics -- trainer.py:47-89
+    cfg = make_cfg(depth=3, reso=16, hidden=32, start_filts=8)
+    model = det_init_(ref.TomoSAR2Height(cfg), seed=9)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)       # train.py:97
+    tr = ref_trainer.Trainer(model, opt, device=torch.device("cpu"), optimize_every=3, use_cloud=True)
+    arrs = {}
+    track = ["point_encoder.fc_pos.weight", "point_encoder.unet.down_convs.1.fc_comm.0.weight",
+             "decoder.conv_decoder.conv4.weight", "point_encoder.unet.up_convs.0.upconv.bias"]
+    before = {k: v.detach().clone() for k, v in model.named_parameters() if k in track}
+    for t in range(3):
+        cloud = synth_cloud(200, seed=60 + t)
+        g = torch.Generator().manual_seed(60 + t)
+        dsm_lo = torch.rand(64, 64, generator=g) * 30          # stored; dsm = 8x8 block replicate
+        dsm = dsm_lo.repeat_interleave(8, 0).repeat_interleave(8, 1)
+        # DataLoader collate adds the batch dim: inputs [1,N,3], dsm [1,512,512]
+        tr.train_step({"inputs": cloud, "dsm": dsm[None]})
+        arrs[f"cloud_{t}"] = cloud
+        arrs[f"dsm_lo_{t}"] = dsm_lo
+    for k, v in model.named_parameters():
+        if k in track:
+            arrs["before." + k] = before[k]
+            arrs["after." + k] = v
+    arrs["last_avg_loss"] = tr.last_avg_loss
+    save("trainer_accumulation", **arrs)
+
+
+if __name__ == "__main__":
+    main()

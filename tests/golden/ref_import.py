@@ -37,7 +37,13 @@ def import_reference():
     def stub(name, **attrs):
         mod = types.ModuleType(name)
         mod.__dict__.update(attrs)
-        mod.__getattr__ = lambda item: _AnyMeta(item, (), {})  # PEP 562
+
+        def _module_getattr(item):  # PEP 562; dunders must stay missing (inspect.getmodule probes them)
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return _AnyMeta(item, (), {})
+
+        mod.__getattr__ = _module_getattr
         sys.modules.setdefault(name, mod)
         return sys.modules[name]
 
