@@ -1,0 +1,136 @@
+/* t2h.h -- C ABI of libt2h_hip.so: the MI355X (gfx950) implementation of the dual-topology
+ * point-cloud hot path of zhu-xlab/tomosar2height.
+ *
+ * The reference has no FFI of its own: the seam is a handful of Python operator calls
+ * (SURVEY.md section 8b).  Each entry point below names the reference call(s) it replaces
+ * (paths relative to the reference root).  Conventions:
+ *
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in
+ *     the shipped binding); the library allocates nothing and keeps no state, so every call
+ *     is stream-ordered, re-entrant and hipGraph-capturable;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value: 0 on success, a negative T2H_ERR_* code otherwise (never throws, never
+ *     exits); t2h_last_error_string() describes the last failure on the calling thread;
+ *   - all feature arrays are fp32; point features are POINT-MAJOR [B*N, C] rows in the
+ *     CELL-SORTED point order produced by t2h_tile_build; planes exchanged with the point side
+ *     are PIXEL-MAJOR [B, r, r, C] (NHWC), the layout in which a cell / pixel is one contiguous
+ *     row -- t2h_nchw_to_nhwc / t2h_nhwc_to_nchw convert from/to the conv side's NCHW.
+ *
+ * Cell-sorted order.  t2h_tile_build bins the points at the finest plane resolution
+ * R = 2^nbits exactly as coordinate2index does (utils/coordinate.py:12-28: trunc(x*R),
+ * ix + R*iy), then stably sorts them by the Morton code of (ix, iy).  A cell of ANY coarser
+ * level k (resolution R >> k, the resolutions the ALTO U-Net visits) is then one contiguous
+ * run of points: points of level-k cell (cx, cy) are [off0[M << 2k], off0[(M+1) << 2k]) with
+ * M = morton(cx, cy) and off0 the CSR offsets of the finest level.  One sort per tile serves
+ * the 9 coordinate2index calls, 4 scatter_max, 9 scatter_mean and 8 grid_sample backward
+ * passes of one forward/backward.
+ */
+#ifndef T2H_H_
+#define T2H_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2H_OK 0
+#define T2H_ERR_ARG (-1)      /* bad argument (null pointer, unsupported size) */
+#define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
+#define T2H_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define T2H_ABI_VERSION 1
+#define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
+
+typedef void *t2h_stream_t;
+
+int t2h_abi_version(void);
+const char *t2h_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * coordinate2index(x, reso)                                     utils/coordinate.py:12-28
+ * pts: [total, stride] floats (x, y first); index: [total] int64 = trunc(x*reso) + reso*trunc(y*reso).
+ * Any reso >= 1 (the operator-level drop-in; the fused path uses t2h_tile_build instead). */
+int t2h_coordinate2index(const float *pts, int stride, int64_t total, int reso, int64_t *index,
+                         t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tile index: replaces the 9 coordinate2index calls + clone()[..., [0, 1]] copies per forward
+ * (pointnet.py:69-70; alto.py:79-80, 189-190) and provides the segment structure used instead
+ * of torch_scatter's atomics.
+ *
+ *   cloud       [B, N, dim] input points, x/y in [0,1) (dataset.py:278 guarantees (0,1))
+ *   pts_sorted  [B*N, dim]  the same points in cell-sorted order
+ *   perm        [B*N]       index (within its tile, 0..N-1) of the original point at each sorted slot
+ *   cell        [B*N]       b * 4^nbits + morton(ix, iy) of each sorted point (finest level)
+ *   off0        [B * 4^nbits + 1]  CSR offsets into the sorted order (global, i.e. including b*N)
+ *   status      [1]         number of points with x or y outside [0,1) (clamped into the border
+ *                           cell; the reference would index out of range) -- caller checks it
+ * The sort is stable (original order inside a cell), so results are run-to-run deterministic. */
+size_t t2h_tile_workspace_bytes(int B, int N, int nbits);
+int t2h_tile_build(const float *cloud, int dim, int B, int N, int nbits, float *pts_sorted, int32_t *perm,
+                   int32_t *cell, int32_t *off0, int32_t *status, void *workspace, size_t workspace_bytes,
+                   t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pool_local (scatter_max + gather)                              pointnet.py:92-99
+ * feat/pooled [B*N, C] sorted rows; every point receives the per-channel max over the points of
+ * its finest-level cell.  Ties: the first point in ORIGINAL order wins (pytorch-scatter CPU rule;
+ * the stable sort keeps original order inside a cell).
+ * winner: [B*N, t2h_pool_winner_stride(C)] bytes; bit j of byte (n, g) is set iff point n is the
+ * arg-max of its cell for channel g*vec + j (vec = 4 if C % 4 == 0 else 1).
+ * Backward (gather-backward = per-cell sum of gpooled, routed to the arg-max point):
+ * gfeat = (accumulate ? gfeat : 0) + routed gradient. */
+int t2h_pool_winner_stride(int C);
+int t2h_pool_max_fwd(const float *feat, const int32_t *off0, int B, int nbits, int C, float *pooled,
+                     uint8_t *winner, t2h_stream_t stream);
+int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const int32_t *off0, int B, int nbits,
+                     int C, int accumulate, float *gfeat, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * generate_plane_features (scatter_mean into a zero plane)       pointnet.py:101-111; alto.py:76-88,187-197
+ * level k: resolution r = 2^(nbits-k).  plane [B, r, r, C] (NHWC); empty cells are written 0
+ * (no separate memset).  Sum order inside a cell = sorted order (deterministic).
+ * Backward: gfeat[n] = gplane[cell_k(n)] / count(cell_k(n)). */
+int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int nbits, int level, int C,
+                    float *plane_nhwc, t2h_stream_t stream);
+int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N,
+                    int nbits, int level, int C, float *gfeat, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * sample_plane_feature: F.grid_sample(c, 2*xy-1, bilinear, border, align_corners=True)
+ *                                                                alto.py:90-95, 199-205
+ * plane [B, r, r, C] NHWC, pts [B*N, dim] -> out [B*N, C]  (== the reference's [B,C,N] result
+ * after its transpose at alto.py:122).  Any r >= 1.
+ * Backward w.r.t. the plane (points carry no gradient):
+ *   t2h_sample_bwd        deterministic gather over the 3x3 neighbouring cells of each pixel using
+ *                         the tile CSR; requires pts in cell-sorted order and r == 2^(nbits-level);
+ *   t2h_sample_bwd_atomic any r / any point order, float atomics (order-dependent rounding);
+ *                         gplane must be zeroed by the caller. */
+int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
+                   t2h_stream_t stream);
+int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                   int level, int C, float *gplane_nhwc, t2h_stream_t stream);
+int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
+                          float *gplane_nhwc, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F.interpolate(size=(H, W), mode='bilinear', align_corners=True) pixel.py:107,110
+ * NCHW in / NCHW out (the decoder convs consume it).  `addend` (may be NULL) is added to the
+ * result: the image-plane sum of pixel.py:110 when the image plane is already H x W.
+ * Backward: deterministic gather (no atomics). */
+int t2h_upsample_bilinear_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W,
+                              float *out, t2h_stream_t stream);
+int t2h_upsample_bilinear_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
+                              t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout glue between the conv side (NCHW) and the point side (NHWC): [B, C, P] <-> [B, P, C]. */
+int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
+int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2H_H_ */

@@ -1,0 +1,250 @@
+"""GPU parity: every HIP operator (through the C ABI) against the C oracle on the same seeded inputs and
+against the fixtures captured from the reference.  Integer/index results bit exact; fp32 within the
+tolerance written at each assert (north_star: 1e-4 relative; most ops are far tighter)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from detinit import synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _morton(ix, iy):
+    def part(v):
+        v = v.astype(np.uint32) & 0xFFFF
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+    return part(ix) | (part(iy) << 1)
+
+
+def _tile(cloud, reso):
+    from tomosar2height_amd.tile import TileIndex
+    return TileIndex(cloud.to(_dev()), reso)
+
+
+@pytest.mark.parametrize("n,reso,batch", [(1, 2, 1), (5, 2, 1), (300, 16, 1), (2049, 64, 2), (70000, 256, 1),
+                                          (131072, 256, 1)])
+def test_tile_index_bit_exact(n, reso, batch):
+    from oracle import c_oracle
+    cloud = synth_cloud(n, seed=n + reso, batch=batch)
+    t = _tile(cloud, reso)
+    assert t.out_of_domain() == 0
+    idx = c_oracle.coordinate2index(cloud.numpy(), reso)[:, 0]                     # [B,N] reference cell ids
+    m0 = reso * reso
+    want_code = _morton(idx % reso, idx // reso).astype(np.int64) + np.arange(batch)[:, None] * m0
+    perm = t.perm.cpu().numpy().reshape(batch, n).astype(np.int64)
+    cell = t.cell.cpu().numpy().reshape(batch, n).astype(np.int64)
+    off0 = t.off0.cpu().numpy().astype(np.int64)
+    for b in range(batch):
+        assert np.array_equal(np.sort(perm[b]), np.arange(n))                      # a permutation
+        assert np.array_equal(cell[b], want_code[b][perm[b]])                      # cell of each sorted point
+        assert np.all(np.diff(cell[b]) >= 0)                                       # sorted
+        same = np.diff(cell[b]) == 0
+        assert np.all(np.diff(perm[b])[same] > 0)                                  # stable inside a cell
+    counts = np.bincount(want_code.reshape(-1), minlength=batch * m0)
+    assert np.array_equal(off0, np.concatenate([[0], np.cumsum(counts)]))          # CSR
+    pts = t.pts.cpu().numpy().reshape(batch, n, 3)
+    for b in range(batch):
+        assert np.array_equal(pts[b], cloud.numpy()[b][perm[b]])
+
+
+def test_tile_index_out_of_domain_is_counted():
+    cloud = synth_cloud(100, seed=1)
+    cloud[0, 3, 0] = 1.0
+    cloud[0, 7, 1] = -0.25
+    cloud[0, 9, 0] = float("nan")
+    t = _tile(cloud, 16)
+    assert t.out_of_domain() == 3
+    with pytest.raises(ValueError):
+        t.check_domain()
+
+
+def test_coordinate2index_golden():
+    from tomosar2height_amd import ops
+    g = load_golden("coordinate2index")
+    xy = torch.from_numpy(g["xy"]).to(_dev())
+    for reso in (2, 16, 32, 64, 128, 256):
+        assert np.array_equal(ops.coordinate2index(xy, reso).cpu().numpy(), g[f"index_r{reso}"])
+
+
+def _pool_case(cloud, feat, reso, gout):
+    from tomosar2height_amd import ops
+    from oracle import c_oracle
+    t = _tile(cloud, reso)
+    f = t.sort_rows(feat.to(_dev())).requires_grad_(True)
+    pooled = ops.pool_max(t, f)
+    pooled.backward(t.sort_rows(gout.to(_dev())))
+    idx = c_oracle.coordinate2index(cloud.numpy(), reso)
+    want, arg = c_oracle.pool_local_fwd(feat.numpy(), idx, reso * reso)
+    want_g = c_oracle.pool_local_bwd(gout.numpy(), idx, arg, reso * reso)
+    return t.unsort_rows(pooled.detach()).cpu().numpy(), t.unsort_rows(f.grad).cpu().numpy(), want, want_g
+
+
+@pytest.mark.parametrize("n,reso,c,batch", [(300, 4, 8, 1), (300, 16, 32, 2), (5000, 64, 32, 1), (777, 16, 12, 1),
+                                            (40000, 256, 32, 1), (3000, 32, 6, 1), (1000, 8, 512, 1)])
+def test_pool_max_vs_oracle(n, reso, c, batch):
+    g = torch.Generator().manual_seed(n + c)
+    cloud = synth_cloud(n, seed=n, batch=batch)
+    feat = (torch.randn(batch, n, c, generator=g) * 4).round() / 4         # quantised: plenty of exact ties
+    gout = torch.randn(batch, n, c, generator=g)
+    got, got_g, want, want_g = _pool_case(cloud, feat, reso, gout)
+    assert np.array_equal(got, want)                                        # max is exact
+    np.testing.assert_allclose(got_g, want_g, rtol=1e-5, atol=1e-5)        # sums over a cell: order-free to 1e-5
+    assert np.array_equal(got_g != 0, want_g != 0)                          # same arg-max routing (tie-break)
+
+
+def test_pool_max_golden_and_single_cell():
+    g = load_golden("pool_local")
+    for reso in (4, 16):
+        cloud = torch.cat([torch.from_numpy(g[f"xy_r{reso}"]), torch.zeros(1, 300, 1)], 2)
+        got, got_g, _, _ = _pool_case(cloud, torch.from_numpy(g[f"feat_r{reso}"]), reso,
+                                      torch.from_numpy(g[f"gout_r{reso}"]))
+        assert np.array_equal(got, g[f"out_r{reso}"])
+        np.testing.assert_allclose(got_g, g[f"gfeat_r{reso}"], rtol=1e-5, atol=1e-5)
+    # all points in ONE cell, all values equal: first point takes the whole gradient
+    n = 1000
+    cloud = torch.full((1, n, 3), 0.5)
+    feat = torch.ones(1, n, 32)
+    gout = torch.ones(1, n, 32)
+    got, got_g, want, want_g = _pool_case(cloud, feat, 256, gout)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got_g, want_g) and got_g[0, 0, 0] == n and got_g[0, 1:].sum() == 0
+
+
+@pytest.mark.parametrize("n,reso,c,level,batch", [(257, 4, 8, 0, 1), (257, 16, 8, 0, 1), (257, 32, 12, 0, 1),
+                                                  (5000, 64, 32, 0, 2), (5000, 64, 64, 1, 1), (5000, 64, 128, 3, 1),
+                                                  (40000, 256, 32, 0, 1), (20000, 256, 512, 3, 1), (3000, 256, 256, 8, 1)])
+def test_rasterise_mean_vs_oracle(n, reso, c, level, batch):
+    from tomosar2height_amd import ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(n + c + level)
+    cloud = synth_cloud(n, seed=n + 1, batch=batch)
+    feat = torch.randn(batch, n, c, generator=g)
+    r = reso >> level
+    t = _tile(cloud, reso)
+    f = t.sort_rows(feat.to(_dev())).requires_grad_(True)
+    plane = ops.rasterise_mean(t, f, r)
+    assert plane.shape == (batch, c, r, r) and plane.is_contiguous()
+    gout = torch.randn(batch, c, r, r, generator=g)
+    plane.backward(gout.to(_dev()))
+    idx = c_oracle.coordinate2index(cloud.numpy(), r)
+    want = c_oracle.scatter_mean_fwd(feat.numpy(), idx, r)
+    np.testing.assert_allclose(plane.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(plane.detach().cpu().numpy() == 0, want == 0)      # empty cells are exactly 0
+    want_g = c_oracle.scatter_mean_bwd(gout.numpy(), idx, n)
+    np.testing.assert_allclose(t.unsort_rows(f.grad).cpu().numpy(), want_g, rtol=1e-6, atol=1e-7)
+    # channels_last output is the same numbers in NHWC memory
+    plane_cl = ops.rasterise_mean(t, f.detach(), r, channels_last=True)
+    assert torch.equal(plane_cl, plane.detach()) and plane_cl.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_rasterise_mean_golden():
+    from tomosar2height_amd import ops
+    g = load_golden("scatter_mean_plane")
+    for reso in (4, 16, 32):
+        xy = torch.from_numpy(g[f"xy_r{reso}"])
+        cloud = torch.cat([xy, torch.zeros(1, xy.shape[1], 1)], 2)
+        t = _tile(cloud, reso)
+        f = t.sort_rows(torch.from_numpy(g[f"feat_r{reso}"]).to(_dev())).requires_grad_(True)
+        plane = ops.rasterise_mean(t, f, reso)
+        np.testing.assert_allclose(plane.detach().cpu().numpy(), g[f"plane_r{reso}"], rtol=1e-5, atol=1e-6)
+        plane.backward(torch.from_numpy(g[f"gout_r{reso}"]).to(_dev()))
+        np.testing.assert_allclose(t.unsort_rows(f.grad).cpu().numpy(), g[f"gfeat_r{reso}"], rtol=1e-6, atol=1e-7)
+    # the reference's own known-answer vector (pointnet.py:114-123)
+    g = load_golden("pointnet_main_vector")
+    xy = torch.from_numpy(g["xy"])
+    t = _tile(torch.cat([xy, torch.zeros(1, 5, 1)], 2), 2)
+    plane = ops.rasterise_mean(t, t.sort_rows(xy.to(_dev())), 2)
+    np.testing.assert_allclose(plane.cpu().numpy(), g["plane"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,reso,c,level,batch,cl", [(150, 8, 4, 0, 1, False), (150, 16, 8, 0, 2, True),
+                                                     (5000, 64, 32, 0, 1, False), (5000, 64, 64, 1, 1, True),
+                                                     (40000, 256, 32, 0, 1, False), (20000, 256, 512, 3, 1, False),
+                                                     (3000, 64, 12, 2, 1, False), (2000, 256, 16, 8, 1, False)])
+def test_sample_plane_vs_oracle(n, reso, c, level, batch, cl):
+    from tomosar2height_amd import ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(n + c)
+    cloud = synth_cloud(n, seed=n + 2, batch=batch)
+    r = reso >> level
+    plane = torch.randn(batch, c, r, r, generator=g)
+    gout = torch.randn(batch, n, c, generator=g)
+    t = _tile(cloud, reso)
+    p = plane.to(_dev())
+    if cl:
+        p = p.contiguous(memory_format=torch.channels_last)
+    p.requires_grad_(True)
+    out = ops.sample_plane(t, p)
+    out.backward(t.sort_rows(gout.to(_dev())))
+    want = c_oracle.grid_sample_fwd(plane.numpy(), cloud.numpy())
+    np.testing.assert_allclose(t.unsort_rows(out.detach()).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    want_g = c_oracle.grid_sample_bwd(gout.numpy(), cloud.numpy(), r, r)
+    scale = np.abs(want_g).max() + 1e-6
+    np.testing.assert_allclose(p.grad.cpu().numpy(), want_g, rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_sample_plane_golden():
+    from tomosar2height_amd import ops
+    g = load_golden("grid_sample_points")
+    for r in (8, 16):
+        cloud = torch.from_numpy(g[f"p_r{r}"]).clone()
+        # the fixture probes x == 1.0 / y == 1.0 (grid_sample's border clip); cell binning needs [0,1), so
+        # keep the sample coordinates but build the tile on coordinates nudged inside the border cell
+        t_cloud = cloud.clone()
+        t_cloud[..., :2] = t_cloud[..., :2].clamp(max=1 - 2.0 ** -24)
+        same_cell = torch.equal((t_cloud[..., :2] * r).long().clamp(max=r - 1), (cloud[..., :2] * r).long().clamp(max=r - 1))
+        assert same_cell
+        t = _tile(t_cloud, r)
+        t.pts.copy_(t.sort_rows(cloud.to(_dev())))                       # sample at the fixture's exact coordinates
+        p = torch.from_numpy(g[f"plane_r{r}"]).to(_dev()).requires_grad_(True)
+        out = ops.sample_plane(t, p)
+        want = np.transpose(g[f"out_r{r}"], (0, 2, 1))
+        np.testing.assert_allclose(t.unsort_rows(out.detach()).cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+        out.backward(t.sort_rows(torch.from_numpy(np.transpose(g[f"gout_r{r}"], (0, 2, 1)).copy()).to(_dev())))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"gplane_r{r}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,c,h,size", [(1, 32, 256, 512), (2, 3, 16, 32), (1, 5, 7, 19), (1, 4, 32, 32), (1, 2, 1, 8)])
+def test_upsample_bilinear_vs_oracle(b, c, h, size):
+    from tomosar2height_amd import ops
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(h + size)
+    x = torch.randn(b, c, h, h, generator=g)
+    add = torch.randn(b, c, size, size, generator=g)
+    gout = torch.randn(b, c, size, size, generator=g)
+    xd = x.to(_dev()).requires_grad_(True)
+    y = ops.upsample_bilinear(xd, size)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), c_oracle.upsample_bilinear_fwd(x.numpy(), size),
+                               rtol=1e-6, atol=1e-6)
+    y.backward(gout.to(_dev()))
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), c_oracle.upsample_bilinear_bwd(gout.numpy(), h, h),
+                               rtol=1e-5, atol=1e-5)
+    ad = add.to(_dev()).requires_grad_(True)
+    y2 = ops.upsample_bilinear(xd.detach(), size, ad)
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), y.detach().cpu().numpy() + add.numpy(), rtol=1e-6, atol=1e-6)
+    y2.backward(gout.to(_dev()))
+    assert torch.equal(ad.grad.cpu(), gout)
+
+
+def test_layout_roundtrip():
+    from tomosar2height_amd import ops
+    x = torch.randn(2, 37, 19, 19, device=_dev())
+    nhwc = ops.to_nhwc(x)
+    assert torch.equal(nhwc, x.permute(0, 2, 3, 1))
+    assert torch.equal(ops.from_nhwc(nhwc.contiguous(), channels_last=False), x)
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from tomosar2height_amd.tile import TileIndex
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        TileIndex(synth_cloud(10), 16)

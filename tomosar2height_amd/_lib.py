@@ -1,0 +1,93 @@
+"""ctypes binding of libt2h_hip.so (include/t2h.h).  This is the ONLY way the package reaches the
+device: there is no torch/CPU fallback -- a missing library or a non-GPU tensor raises.
+
+torch is imported first on purpose: it loads its bundled libamdhip64.so.7, and the dynamic linker then
+resolves our DT_NEEDED entry of the same SONAME to that already-loaded runtime, so device pointers,
+streams and the caching allocator are shared with PyTorch.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2h_hip.so")
+ABI_VERSION = 1
+
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/t2h.h one to one
+SIGNATURES = {
+    "t2h_abi_version": (_i, []),
+    "t2h_last_error_string": (ctypes.c_char_p, []),
+    "t2h_coordinate2index": (_i, [_vp, _i, _i64, _i, _vp, _vp]),
+    "t2h_tile_workspace_bytes": (_sz, [_i, _i, _i]),
+    "t2h_tile_build": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_pool_winner_stride": (_i, [_i]),
+    "t2h_pool_max_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "t2h_pool_max_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_segmean_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_segmean_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_upsample_bilinear_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class T2HLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises T2HLibraryError if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T2HLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m tomosar2height_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise T2HLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.t2h_abi_version() != ABI_VERSION:
+        raise T2HLibraryError(f"ABI version mismatch: library {lib.t2h_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().t2h_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors, what="t2h op"):
+    """Argument validation that the C side cannot do: device, dtype, contiguity."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"{what}: expected a tensor on the MI355X (cuda device), got {t.device}. "
+                "tomosar2height_amd has no CPU path; the CPU restatement lives in oracle/ for tests only.")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{what}: tensor must be contiguous")

@@ -1,0 +1,433 @@
+// Point <-> grid kernels on the cell-sorted point order (see include/t2h.h).
+//
+//   pool_max        scatter_max + gather          pointnet.py:92-99
+//   segmean         scatter_mean into a plane     pointnet.py:101-111; alto.py:76-88,187-197
+//   sample          grid_sample bilinear/border   alto.py:90-95,199-205
+//
+// All of them are HBM-bound row streaming: a "group" of G = 2^lg lanes owns one cell / point / pixel and
+// each lane owns VEC consecutive channels of the row, so a row is one coalesced G*VEC*4-byte access and no
+// cross-lane traffic is needed.  Segments are contiguous runs of rows thanks to the Morton sort, so the
+// reductions are plain sequential loops over neighbouring rows: no atomics, deterministic sums.
+#include <float.h>
+
+#include "t2h_common.h"
+
+namespace t2h {
+
+constexpr int kThreads = 256;
+
+struct GroupCfg {
+    int lg;        // log2 lanes per group
+    int span;      // channels covered per pass = (1 << lg) * VEC
+};
+
+template <int VEC>
+static GroupCfg group_cfg(int C) {
+    GroupCfg g;
+    g.lg = group_log2(C, VEC);
+    g.span = (1 << g.lg) * VEC;
+    return g;
+}
+
+static inline unsigned grid_for(int64_t groups, int lg) {
+    int64_t threads = groups << lg;
+    return (unsigned)((threads + kThreads - 1) / kThreads);
+}
+
+// ------------------------------------------------------------------------------------------------ pool_max
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__restrict__ feat,
+                                                                const int32_t *__restrict__ off0, int64_t ncells, int C,
+                                                                int lg, int wstride, float *__restrict__ pooled,
+                                                                uint8_t *__restrict__ winner) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t cellid = t >> lg;
+    if (cellid >= ncells) return;
+    int s = off0[cellid], e = off0[cellid + 1];
+    if (s == e) return;
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        float best[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { best[j] = -FLT_MAX; arg[j] = -1; }
+        for (int n = s; n < e; ++n) {
+            Vec<VEC> v = Vec<VEC>::load(feat + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (v.v[j] > best[j]) { best[j] = v.v[j]; arg[j] = n; }   // strict >: first point wins ties
+        }
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = arg[j] < 0 ? 0.0f : best[j];
+        for (int n = s; n < e; ++n) {
+            o.store(pooled + (size_t)n * C + c);
+            uint8_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) bits |= (uint8_t)((arg[j] == n) << j);
+            winner[(size_t)n * wstride + c / VEC] = bits;
+        }
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void pool_max_bwd_kernel(const float *__restrict__ gpooled,
+                                                                const uint8_t *__restrict__ winner,
+                                                                const int32_t *__restrict__ off0, int64_t ncells, int C,
+                                                                int lg, int wstride, int accumulate,
+                                                                float *__restrict__ gfeat) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t cellid = t >> lg;
+    if (cellid >= ncells) return;
+    int s = off0[cellid], e = off0[cellid + 1];
+    if (s == e) return;
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        float sum[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+        for (int n = s; n < e; ++n) {
+            Vec<VEC> g = Vec<VEC>::load(gpooled + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sum[j] += g.v[j];
+        }
+        for (int n = s; n < e; ++n) {
+            uint8_t bits = winner[(size_t)n * wstride + c / VEC];
+            Vec<VEC> o;
+            if (accumulate) o = Vec<VEC>::load(gfeat + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float r = ((bits >> j) & 1) ? sum[j] : 0.0f;
+                o.v[j] = accumulate ? o.v[j] + r : r;
+            }
+            o.store(gfeat + (size_t)n * C + c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- segmean
+// One group per level-k cell, cells enumerated in Morton order (neighbouring groups read neighbouring rows).
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__restrict__ feat,
+                                                               const int32_t *__restrict__ off0, int B, int nbits,
+                                                               int level, int C, int lg, float *__restrict__ plane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t gid = t >> lg;
+    const int rbits = nbits - level;
+    const int64_t cells_per_tile = (int64_t)1 << (2 * rbits);
+    if (gid >= (int64_t)B * cells_per_tile) return;
+    int b = (int)(gid >> (2 * rbits));
+    uint32_t mk = (uint32_t)(gid & (cells_per_tile - 1));
+    size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+    int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    int r = 1 << rbits;
+    float *orow = plane + (((size_t)b * r + cy) * r + cx) * C;
+    float inv_den = (float)(e - s > 0 ? e - s : 1);
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        float sum[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+        int n = s;
+        for (; n + 4 <= e; n += 4) {   // 4 independent row loads in flight
+            Vec<VEC> a0 = Vec<VEC>::load(feat + (size_t)(n + 0) * C + c);
+            Vec<VEC> a1 = Vec<VEC>::load(feat + (size_t)(n + 1) * C + c);
+            Vec<VEC> a2 = Vec<VEC>::load(feat + (size_t)(n + 2) * C + c);
+            Vec<VEC> a3 = Vec<VEC>::load(feat + (size_t)(n + 3) * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sum[j] = (((sum[j] + a0.v[j]) + a1.v[j]) + a2.v[j]) + a3.v[j];
+        }
+        for (; n < e; ++n) {
+            Vec<VEC> a = Vec<VEC>::load(feat + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sum[j] += a.v[j];
+        }
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = __fdiv_rn(sum[j], inv_den);
+        o.store(orow + c);
+    }
+}
+
+// One group per point: gfeat[n] = gplane[cell_k(n)] / count.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void segmean_bwd_kernel(const float *__restrict__ gplane,
+                                                               const int32_t *__restrict__ cell,
+                                                               const int32_t *__restrict__ off0, int64_t npts, int nbits,
+                                                               int level, int C, int lg, float *__restrict__ gfeat) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t n = t >> lg;
+    if (n >= npts) return;
+    uint32_t code = (uint32_t)cell[n];
+    uint32_t b = code >> (2 * nbits);
+    uint32_t m = code & ((1u << (2 * nbits)) - 1u);
+    uint32_t mk = m >> (2 * level);
+    size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    int cnt = off0[obase + ((size_t)1 << (2 * level))] - off0[obase];
+    int rbits = nbits - level, r = 1 << rbits;
+    int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    const float *grow = gplane + (((size_t)b * r + cy) * r + cx) * C;
+    float den = (float)(cnt > 0 ? cnt : 1);
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        Vec<VEC> g = Vec<VEC>::load(grow + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g.v[j] = __fdiv_rn(g.v[j], den);
+        g.store(gfeat + (size_t)n * C + c);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- sample
+struct Taps {
+    int x0, y0;
+    float wx0, wx1, wy0, wy1;   // west/east, north/south factors
+};
+__device__ inline Taps make_taps(float x01, float y01, int r) {
+    float ix = unnormalize_clip(x01, r), iy = unnormalize_clip(y01, r);
+    float fx = floorf(ix), fy = floorf(iy);
+    Taps t;
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    t.wx0 = __fsub_rn(fx + 1.0f, ix); t.wx1 = __fsub_rn(ix, fx);
+    t.wy0 = __fsub_rn(fy + 1.0f, iy); t.wy1 = __fsub_rn(iy, fy);
+    return t;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__restrict__ plane,
+                                                              const float *__restrict__ pts, int dim, int64_t npts,
+                                                              int N, int r, int C, int lg, float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t n = t >> lg;
+    if (n >= npts) return;
+    int b = (int)(n / N);
+    Taps tp = make_taps(pts[n * dim + 0], pts[n * dim + 1], r);
+    // ATen: nw = (x1-ix)*(y1-iy), ne = (ix-x0)*(y1-iy), sw = (x1-ix)*(iy-y0), se = (ix-x0)*(iy-y0)
+    float nw = __fmul_rn(tp.wx0, tp.wy0), ne = __fmul_rn(tp.wx1, tp.wy0);
+    float sw = __fmul_rn(tp.wx0, tp.wy1), se = __fmul_rn(tp.wx1, tp.wy1);
+    bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;   // x0,y0 are in range after the border clip
+    const float *base = plane + (size_t)b * r * r * C;
+    const float *p00 = base + ((size_t)tp.y0 * r + tp.x0) * C;
+    const float *p01 = p00 + C;
+    const float *p10 = p00 + (size_t)r * C;
+    const float *p11 = p10 + C;
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        Vec<VEC> acc;
+        Vec<VEC> v = Vec<VEC>::load(p00 + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc.v[j] = __fmul_rn(v.v[j], nw);
+        if (x1ok) {
+            v = Vec<VEC>::load(p01 + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(acc.v[j], __fmul_rn(v.v[j], ne));
+        }
+        if (y1ok) {
+            v = Vec<VEC>::load(p10 + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(acc.v[j], __fmul_rn(v.v[j], sw));
+        }
+        if (x1ok && y1ok) {
+            v = Vec<VEC>::load(p11 + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(acc.v[j], __fmul_rn(v.v[j], se));
+        }
+        acc.store(out + (size_t)n * C + c);
+    }
+}
+
+// Deterministic backward: one group per pixel; a point of cell (cx,cy) only touches pixels
+// {cx-1..cx+1} x {cy-1..cy+1} (px = x*(r-1) lies in (cx-1, cx+1)), so pixel (px,py) gathers from the
+// 3x3 cells around it.  Cells are visited row-major, points in sorted order: a fixed summation order.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__restrict__ gout,
+                                                              const float *__restrict__ pts, int dim,
+                                                              const int32_t *__restrict__ off0, int B, int nbits,
+                                                              int level, int C, int lg, float *__restrict__ gplane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t gid = t >> lg;
+    const int rbits = nbits - level, r = 1 << rbits;
+    if (gid >= (int64_t)B * r * r) return;
+    int b = (int)(gid >> (2 * rbits));
+    int py = (int)((gid >> rbits) & (r - 1)), px = (int)(gid & (r - 1));
+    int span = VEC << lg;
+    int c0 = ((int)t & ((1 << lg) - 1)) * VEC;
+    for (int c = c0; c < C; c += span) {
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+        for (int cy = max(py - 1, 0); cy <= min(py + 1, r - 1); ++cy)
+            for (int cx = max(px - 1, 0); cx <= min(px + 1, r - 1); ++cx) {
+                size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
+                int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+                for (int n = s; n < e; ++n) {
+                    Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+                    float wx = (tp.x0 == px) ? tp.wx0 : ((tp.x0 + 1 == px) ? tp.wx1 : 0.0f);
+                    float wy = (tp.y0 == py) ? tp.wy0 : ((tp.y0 + 1 == py) ? tp.wy1 : 0.0f);
+                    bool hit = (tp.x0 == px || tp.x0 + 1 == px) && (tp.y0 == py || tp.y0 + 1 == py);
+                    if (!hit) continue;
+                    float w = __fmul_rn(wx, wy);
+                    Vec<VEC> g = Vec<VEC>::load(gout + (size_t)n * C + c);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(w, g.v[j]));
+                }
+            }
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
+        o.store(gplane + (((size_t)b * r + py) * r + px) * C + c);
+    }
+}
+
+// Generic backward (any r, any point order): float atomics, caller zeroes gplane.
+__global__ __launch_bounds__(kThreads) void sample_bwd_atomic_kernel(const float *__restrict__ gout,
+                                                                     const float *__restrict__ pts, int dim,
+                                                                     int64_t npts, int N, int r, int C, int lg,
+                                                                     float *__restrict__ gplane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t n = t >> lg;
+    if (n >= npts) return;
+    int b = (int)(n / N);
+    Taps tp = make_taps(pts[n * dim + 0], pts[n * dim + 1], r);
+    float nw = tp.wx0 * tp.wy0, ne = tp.wx1 * tp.wy0, sw = tp.wx0 * tp.wy1, se = tp.wx1 * tp.wy1;
+    bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+    float *base = gplane + (size_t)b * r * r * C;
+    float *p00 = base + ((size_t)tp.y0 * r + tp.x0) * C;
+    for (int c = (int)t & ((1 << lg) - 1); c < C; c += 1 << lg) {
+        float g = gout[(size_t)n * C + c];
+        atomicAdd(p00 + c, nw * g);
+        if (x1ok) atomicAdd(p00 + C + c, ne * g);
+        if (y1ok) atomicAdd(p00 + (size_t)r * C + c, sw * g);
+        if (x1ok && y1ok) atomicAdd(p00 + (size_t)r * C + C + c, se * g);
+    }
+}
+
+}  // namespace t2h
+
+using namespace t2h;
+
+#define T2H_DISPATCH_VEC(C, CALL4, CALL1) \
+    do {                                  \
+        if ((C) % 4 == 0) { CALL4; } else { CALL1; } \
+    } while (0)
+
+static int check_level(const char *what, int B, int nbits, int level, int C) {
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1)
+        return fail(T2H_ERR_ARG, "%s: unsupported shape (B=%d nbits=%d level=%d C=%d)", what, B, nbits, level, C);
+    return T2H_OK;
+}
+
+T2H_API int t2h_pool_winner_stride(int C) { return C % 4 == 0 ? C / 4 : C; }
+
+T2H_API int t2h_pool_max_fwd(const float *feat, const int32_t *off0, int B, int nbits, int C, float *pooled,
+                             uint8_t *winner, t2h_stream_t stream) {
+    if (!feat || !off0 || !pooled || !winner) return fail(T2H_ERR_ARG, "pool_max_fwd: null pointer");
+    int rc = check_level("pool_max_fwd", B, nbits, 0, C);
+    if (rc) return rc;
+    int64_t ncells = (int64_t)B << (2 * nbits);
+    int ws = t2h_pool_winner_stride(C);
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(pool_max_fwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             feat, off0, ncells, C, g.lg, ws, pooled, winner); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(pool_max_fwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             feat, off0, ncells, C, g.lg, ws, pooled, winner); });
+    return check_launch("pool_max_fwd");
+}
+
+T2H_API int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const int32_t *off0, int B, int nbits, int C,
+                             int accumulate, float *gfeat, t2h_stream_t stream) {
+    if (!gpooled || !winner || !off0 || !gfeat) return fail(T2H_ERR_ARG, "pool_max_bwd: null pointer");
+    int rc = check_level("pool_max_bwd", B, nbits, 0, C);
+    if (rc) return rc;
+    int64_t ncells = (int64_t)B << (2 * nbits);
+    int ws = t2h_pool_winner_stride(C);
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(pool_max_bwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gpooled, winner, off0, ncells, C, g.lg, ws, accumulate, gfeat); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(pool_max_bwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gpooled, winner, off0, ncells, C, g.lg, ws, accumulate, gfeat); });
+    return check_launch("pool_max_bwd");
+}
+
+T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int nbits, int level, int C,
+                            float *plane_nhwc, t2h_stream_t stream) {
+    if (!feat || !off0 || !plane_nhwc) return fail(T2H_ERR_ARG, "segmean_fwd: null pointer");
+    int rc = check_level("segmean_fwd", B, nbits, level, C);
+    if (rc) return rc;
+    int64_t groups = (int64_t)B << (2 * (nbits - level));
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(segmean_fwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(segmean_fwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
+    return check_launch("segmean_fwd");
+}
+
+T2H_API int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N, int nbits,
+                            int level, int C, float *gfeat, t2h_stream_t stream) {
+    if (!gplane_nhwc || !cell || !off0 || !gfeat) return fail(T2H_ERR_ARG, "segmean_bwd: null pointer");
+    int rc = check_level("segmean_bwd", B, nbits, level, C);
+    if (rc) return rc;
+    if (N < 0) return fail(T2H_ERR_ARG, "segmean_bwd: N < 0");
+    int64_t npts = (int64_t)B * N;
+    if (npts == 0) return T2H_OK;
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(segmean_bwd_kernel<4>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, gfeat); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(segmean_bwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, gfeat); });
+    return check_launch("segmean_bwd");
+}
+
+T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
+                           t2h_stream_t stream) {
+    if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd: null pointer");
+    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_fwd: unsupported shape");
+    int64_t npts = (int64_t)B * N;
+    if (npts == 0) return T2H_OK;
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(sample_fwd_kernel<4>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(sample_fwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });
+    return check_launch("sample_fwd");
+}
+
+T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                           int level, int C, float *gplane_nhwc, t2h_stream_t stream) {
+    if (!gout || !pts || !off0 || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd: null pointer");
+    int rc = check_level("sample_bwd", B, nbits, level, C);
+    if (rc) return rc;
+    if (dim < 2 || N < 0) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
+    int64_t groups = (int64_t)B << (2 * (nbits - level));
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(sample_bwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(sample_bwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); });
+    return check_launch("sample_bwd");
+}
+
+T2H_API int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
+                                  float *gplane_nhwc, t2h_stream_t stream) {
+    if (!gout || !pts || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd_atomic: null pointer");
+    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_bwd_atomic: unsupported shape");
+    int64_t npts = (int64_t)B * N;
+    if (npts == 0) return T2H_OK;
+    int lg = group_log2(C, 1);
+    hipLaunchKernelGGL(sample_bwd_atomic_kernel, dim3(grid_for(npts, lg)), dim3(kThreads), 0, as_stream(stream), gout, pts,
+                       dim, npts, N, r, C, lg, gplane_nhwc);
+    return check_launch("sample_bwd_atomic");
+}

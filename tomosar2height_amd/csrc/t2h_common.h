@@ -1,0 +1,75 @@
+// Shared host/device helpers of libt2h_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/t2h.h"
+
+#define T2H_API extern "C" __attribute__((visibility("default")))
+
+namespace t2h {
+
+constexpr int kWave = 64;
+
+// ---- error reporting (thread local, never throws) -------------------------------------------
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+inline hipStream_t as_stream(t2h_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- Morton helpers: x in even bits, y in odd bits (up to 16 bits per coordinate) --------------
+__host__ __device__ inline uint32_t part1by1(uint32_t v) {
+    v &= 0x0000ffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__host__ __device__ inline uint32_t compact1by1(uint32_t v) {
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0f0f0f0fu;
+    v = (v | (v >> 4)) & 0x00ff00ffu;
+    v = (v | (v >> 8)) & 0x0000ffffu;
+    return v;
+}
+__host__ __device__ inline uint32_t morton2(uint32_t x, uint32_t y) { return part1by1(x) | (part1by1(y) << 1); }
+
+// ---- channel vector access: VEC = 4 (16-byte rows, C % 4 == 0) or 1 (any C) -----------------------
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+    float v[4];
+    __device__ static Vec load(const float *p) {
+        float4 t = *reinterpret_cast<const float4 *>(p);
+        Vec r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+    }
+    __device__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<1> {
+    float v[1];
+    __device__ static Vec load(const float *p) { Vec r; r.v[0] = *p; return r; }
+    __device__ void store(float *p) const { *p = v[0]; }
+};
+
+// lanes per row group for C channels at VEC channels per lane: smallest power of two >= C/VEC, capped at 64
+inline int group_log2(int C, int vec) {
+    int lanes = (C + vec - 1) / vec;
+    int lg = 0;
+    while ((1 << lg) < lanes && lg < 6) ++lg;
+    return lg;
+}
+
+// grid_sample's unnormalise + border clip, align_corners=True (ATen grid_sampler_2d), on the
+// reference's vgrid = 2*xy - 1 (alto.py:94).  Kept as separate roundings (no contraction).
+__device__ inline float unnormalize_clip(float x01, int size) {
+    float g = __fsub_rn(__fmul_rn(2.0f, x01), 1.0f);
+    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(g, 1.0f), 2.0f), (float)(size - 1));
+    ix = fminf(fmaxf(ix, 0.0f), (float)(size - 1));
+    return ix;
+}
+
+}  // namespace t2h

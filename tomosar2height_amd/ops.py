@@ -1,0 +1,195 @@
+"""Autograd operators over the C ABI (include/t2h.h).  Point features are ``[B*N, C]`` rows in the tile's
+cell-sorted order; planes cross this boundary as ``[B, C, r, r]`` tensors (NCHW or channels_last).
+
+Reference seam: ``pool_local`` (pointnet.py:92-99), ``generate_plane_features``
+(pointnet.py:101-111, alto.py:76-88), ``sample_plane_feature`` (alto.py:90-95), ``F.interpolate``
+(pixel.py:107).  No op here has a torch/CPU fallback.
+"""
+import torch
+
+from . import _lib
+from .tile import TileIndex
+
+
+def _f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 expected, got {t.dtype}")
+    return t
+
+
+# --------------------------------------------------------------------------------------- layout glue
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] (any strides) -> contiguous [B,H,W,C]; free when x is already channels_last."""
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    x = x.contiguous()
+    _lib.require_device(x, what="to_nhwc")
+    b, c, h, w = x.shape
+    out = torch.empty(b, h, w, c, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().t2h_nchw_to_nhwc(_lib.ptr(x), b, c, h * w, _lib.ptr(out), _lib.stream()), "t2h_nchw_to_nhwc")
+    return out
+
+
+def from_nhwc(x_nhwc: torch.Tensor, channels_last: bool) -> torch.Tensor:
+    """contiguous [B,H,W,C] -> [B,C,H,W]; a view if channels_last, else an NCHW-contiguous copy."""
+    if channels_last:
+        return x_nhwc.permute(0, 3, 1, 2)
+    _lib.require_device(x_nhwc, what="from_nhwc")
+    b, h, w, c = x_nhwc.shape
+    out = torch.empty(b, c, h, w, dtype=x_nhwc.dtype, device=x_nhwc.device)
+    _lib.check(_lib.load().t2h_nhwc_to_nchw(_lib.ptr(x_nhwc), b, c, h * w, _lib.ptr(out), _lib.stream()),
+               "t2h_nhwc_to_nchw")
+    return out
+
+
+def _is_channels_last(x: torch.Tensor) -> bool:
+    return x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous()
+
+
+# --------------------------------------------------------------------------------------- pool_local
+class _PoolMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, tile: TileIndex):
+        feat = _f32(feat, "pool_max").contiguous()
+        _lib.require_device(feat, what="pool_max")
+        lib = _lib.load()
+        n, c = feat.shape
+        if n != tile.n_points:
+            raise ValueError(f"pool_max: {n} feature rows for a tile of {tile.n_points} points")
+        pooled = torch.empty_like(feat)
+        winner = torch.empty(n, lib.t2h_pool_winner_stride(c), dtype=torch.uint8, device=feat.device)
+        _lib.check(lib.t2h_pool_max_fwd(_lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled),
+                                        _lib.ptr(winner), _lib.stream()), "t2h_pool_max_fwd")
+        ctx.tile, ctx.c = tile, c
+        ctx.save_for_backward(winner)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpooled):
+        (winner,) = ctx.saved_tensors
+        tile = ctx.tile
+        gpooled = gpooled.contiguous()
+        gfeat = torch.empty_like(gpooled)
+        _lib.check(_lib.load().t2h_pool_max_bwd(_lib.ptr(gpooled), _lib.ptr(winner), _lib.ptr(tile.off0), tile.B,
+                                                tile.nbits, ctx.c, 0, _lib.ptr(gfeat), _lib.stream()),
+                   "t2h_pool_max_bwd")
+        return gfeat, None
+
+
+def pool_max(tile: TileIndex, feat: torch.Tensor) -> torch.Tensor:
+    """Per-cell max at the finest level, broadcast back to every point (pointnet.py:92-99)."""
+    return _PoolMax.apply(feat, tile)
+
+
+# --------------------------------------------------------------------------------------- scatter_mean -> plane
+class _RasteriseMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, tile: TileIndex, level: int, channels_last: bool):
+        feat = _f32(feat, "rasterise_mean").contiguous()
+        _lib.require_device(feat, what="rasterise_mean")
+        n, c = feat.shape
+        if n != tile.n_points:
+            raise ValueError(f"rasterise_mean: {n} feature rows for a tile of {tile.n_points} points")
+        r = tile.R >> level
+        plane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.load().t2h_segmean_fwd(_lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, level, c,
+                                               _lib.ptr(plane), _lib.stream()), "t2h_segmean_fwd")
+        ctx.tile, ctx.level, ctx.c = tile, level, c
+        return from_nhwc(plane, channels_last)
+
+    @staticmethod
+    def backward(ctx, gplane):
+        tile = ctx.tile
+        g = to_nhwc(gplane)
+        gfeat = torch.empty(tile.n_points, ctx.c, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().t2h_segmean_bwd(_lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N,
+                                               tile.nbits, ctx.level, ctx.c, _lib.ptr(gfeat), _lib.stream()),
+                   "t2h_segmean_bwd")
+        return gfeat, None, None, None
+
+
+def rasterise_mean(tile: TileIndex, feat: torch.Tensor, reso: int, channels_last: bool = False) -> torch.Tensor:
+    """Per-cell mean of point features -> ``[B, C, reso, reso]``; empty cells are 0
+    (generate_plane_features: pointnet.py:101-111; alto.py:76-88,187-197)."""
+    return _RasteriseMean.apply(feat, tile, tile.level(reso), channels_last)
+
+
+# --------------------------------------------------------------------------------------- grid_sample at points
+class _SamplePlane(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plane, tile: TileIndex):
+        _f32(plane, "sample_plane")
+        if plane.dim() != 4 or plane.shape[2] != plane.shape[3] or plane.shape[0] != tile.B:
+            raise ValueError(f"sample_plane: expected [B={tile.B}, C, r, r], got {tuple(plane.shape)}")
+        ctx.was_cl = _is_channels_last(plane)
+        p = to_nhwc(plane)
+        _lib.require_device(p, what="sample_plane")
+        b, r, _, c = p.shape
+        out = torch.empty(tile.n_points, c, dtype=torch.float32, device=p.device)
+        _lib.check(_lib.load().t2h_sample_fwd(_lib.ptr(p), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c,
+                                              _lib.ptr(out), _lib.stream()), "t2h_sample_fwd")
+        ctx.tile, ctx.r, ctx.c = tile, r, c
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        tile, r, c = ctx.tile, ctx.r, ctx.c
+        gout = gout.contiguous()
+        gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
+        _lib.check(_lib.load().t2h_sample_bwd(_lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+                                              tile.N, tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.stream()),
+                   "t2h_sample_bwd")
+        return from_nhwc(gplane, ctx.was_cl), None
+
+
+def sample_plane(tile: TileIndex, plane: torch.Tensor) -> torch.Tensor:
+    """Bilinear/border/align_corners sample of ``plane [B,C,r,r]`` at every point -> ``[B*N, C]``
+    (sample_plane_feature + transpose: alto.py:90-95,122)."""
+    return _SamplePlane.apply(plane, tile)
+
+
+# --------------------------------------------------------------------------------------- F.interpolate
+class _UpsampleBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size: int, addend):
+        x = _f32(x, "upsample_bilinear").contiguous()
+        _lib.require_device(x, addend, what="upsample_bilinear")
+        b, c, h, w = x.shape
+        out = torch.empty(b, c, size, size, dtype=torch.float32, device=x.device)
+        if addend is not None:
+            addend = addend.contiguous()
+            if addend.shape != out.shape:
+                raise ValueError("upsample_bilinear: addend must already have the output size")
+        _lib.check(_lib.load().t2h_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend) if addend is not None else None,
+                                                         b, c, h, w, size, size, _lib.ptr(out), _lib.stream()),
+                   "t2h_upsample_bilinear_fwd")
+        ctx.shape = (b, c, h, w, size)
+        ctx.has_addend = addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        b, c, h, w, size = ctx.shape
+        gout = gout.contiguous()
+        gin = torch.empty(b, c, h, w, dtype=torch.float32, device=gout.device)
+        _lib.check(_lib.load().t2h_upsample_bilinear_bwd(_lib.ptr(gout), b, c, h, w, size, size, _lib.ptr(gin),
+                                                         _lib.stream()), "t2h_upsample_bilinear_bwd")
+        return gin, None, (gout if ctx.has_addend else None)
+
+
+def upsample_bilinear(x: torch.Tensor, size: int, addend: torch.Tensor = None) -> torch.Tensor:
+    """``F.interpolate(x, size, mode='bilinear', align_corners=True)`` (+ ``addend``) -- pixel.py:107,110."""
+    return _UpsampleBilinear.apply(x, int(size), addend)
+
+
+# --------------------------------------------------------------------------------------- operator-level drop-ins
+def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
+    """utils/coordinate.py:12-28: ``x [B,N,2+] -> int64 [B,1,N]``, bit exact."""
+    x = _f32(x, "coordinate2index").contiguous()
+    _lib.require_device(x, what="coordinate2index")
+    b, n, d = x.shape
+    out = torch.empty(b, n, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.load().t2h_coordinate2index(_lib.ptr(x), d, b * n, int(reso), _lib.ptr(out), _lib.stream()),
+               "t2h_coordinate2index")
+    return out[:, None, :]

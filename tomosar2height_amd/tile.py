@@ -1,0 +1,85 @@
+"""Per-tile cell index: the once-per-forward replacement of the reference's repeated
+``coordinate2index`` calls (utils/coordinate.py:12-28; called at pointnet.py:70 and alto.py:80,190)."""
+import torch
+
+from . import _lib
+
+
+def _log2_exact(v: int) -> int:
+    if v < 1 or v & (v - 1):
+        raise ValueError(f"plane resolution must be a power of two, got {v}")
+    return v.bit_length() - 1
+
+
+class TileIndex:
+    """Points of a batch of tiles in cell-sorted (Morton) order + CSR offsets of the finest level.
+
+    ``cloud`` is ``[B, N, dim]`` fp32 on the GPU with x, y in [0, 1) (the reference's tiles are strictly
+    inside (0, 1): dataset.py:278).  Everything downstream (per-point features, their gradients) lives in
+    this sorted order; the network is permutation-equivariant over points, so only the summation order
+    inside a cell differs from the reference (stable sort: original order is kept inside a finest cell).
+    """
+
+    def __init__(self, cloud: torch.Tensor, plane_resolution: int):
+        if cloud.dim() != 3 or cloud.shape[-1] < 2:
+            raise ValueError(f"expected a [B, N, dim>=2] point tensor, got {tuple(cloud.shape)}")
+        if cloud.dtype != torch.float32:
+            raise TypeError("points must be float32")
+        self.R = int(plane_resolution)
+        self.nbits = _log2_exact(self.R)
+        if not 1 <= self.nbits <= 10:
+            raise ValueError("plane resolution must be in [2, 1024]")
+        cloud = cloud.contiguous()
+        _lib.require_device(cloud, what="TileIndex")
+        self.B, self.N, self.dim = cloud.shape
+        lib = _lib.load()
+        dev = cloud.device
+        bn = self.B * self.N
+        cells = self.B * (1 << (2 * self.nbits))
+        self.pts = torch.empty(bn, self.dim, dtype=torch.float32, device=dev)
+        self.perm = torch.empty(bn, dtype=torch.int32, device=dev)
+        self.cell = torch.empty(bn, dtype=torch.int32, device=dev)
+        self.off0 = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+        self.status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = lib.t2h_tile_workspace_bytes(self.B, self.N, self.nbits)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.t2h_tile_build(_lib.ptr(cloud), self.dim, self.B, self.N, self.nbits, _lib.ptr(self.pts),
+                                      _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0),
+                                      _lib.ptr(self.status), _lib.ptr(ws), ws_bytes, _lib.stream()),
+                   "t2h_tile_build")
+        self.device = dev
+
+    @property
+    def n_points(self) -> int:
+        return self.B * self.N
+
+    def level(self, reso: int) -> int:
+        """ALTO level k whose plane resolution is ``reso`` (= R >> k)."""
+        k = self.nbits - _log2_exact(int(reso))
+        if k < 0:
+            raise ValueError(f"plane resolution {reso} is finer than the tile's {self.R}")
+        return k
+
+    def out_of_domain(self) -> int:
+        """Number of points with x or y outside [0,1) (synchronises).  The reference would raise an index
+        error inside torch_scatter for these; here they were clamped into the border cells."""
+        return int(self.status.item())
+
+    def check_domain(self):
+        bad = self.out_of_domain()
+        if bad:
+            raise ValueError(f"{bad} point(s) have x or y outside [0, 1): normalise the tile first")
+
+    def sort_rows(self, feat: torch.Tensor) -> torch.Tensor:
+        """[B, N, C] original order -> [B*N, C] sorted order (test/interop helper, not on the hot path)."""
+        b, n, c = feat.shape
+        idx = (self.perm.long() + torch.arange(b, device=feat.device).repeat_interleave(n) * n)
+        return feat.reshape(b * n, c)[idx].contiguous()
+
+    def unsort_rows(self, feat_sorted: torch.Tensor) -> torch.Tensor:
+        """[B*N, C] sorted order -> [B, N, C] original order (test/interop helper)."""
+        c = feat_sorted.shape[1]
+        idx = (self.perm.long() + torch.arange(self.B, device=feat_sorted.device).repeat_interleave(self.N) * self.N)
+        out = torch.empty_like(feat_sorted)
+        out[idx] = feat_sorted
+        return out.reshape(self.B, self.N, c)
