@@ -1,0 +1,192 @@
+"""GPU parity at the module seam: the HIP-backed modules (same constructor / forward / state_dict as the
+reference) against fixtures captured from the reference itself and against the torch oracle on the CPU.
+Tolerance (north_star): fp32 heights within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from detinit import det_init_, synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, want, rel=REL, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = np.abs(want).max() + 1e-30
+    err = np.abs(got - want).max() / scale
+    assert err <= rel, f"{what}: max rel err {err:.3e} > {rel:g}"
+
+
+def _dsm(lo):
+    return torch.from_numpy(lo).repeat_interleave(8, -2).repeat_interleave(8, -1)
+
+
+def test_local_pool_pointnet_reduced_golden():
+    from tomosar2height_amd.encoder.pointnet import LocalPoolPointnet
+    g = load_golden("local_pool_pointnet_reduced")
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert list(sd) == list(enc.state_dict())
+    enc.load_state_dict(sd, strict=True)
+    enc.to(_dev())
+    out = enc(torch.from_numpy(g["cloud"]).to(_dev()))["xy"]
+    _close(out.detach().cpu().numpy(), g["out"], what="plane")
+    out.backward(torch.from_numpy(g["gout"]).to(_dev()))
+    none_grad = [k for k, v in enc.named_parameters() if v.grad is None]
+    assert none_grad == g["none_grad"].tolist()
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            _close(v.grad.cpu().numpy(), g["g." + k], rel=2e-4, what=k)
+
+
+@pytest.mark.parametrize("mode", ["conv", "fc"])
+@pytest.mark.parametrize("foot", [False, True])
+@pytest.mark.parametrize("img", [False, True])
+def test_pixelwise_decoder_golden(mode, foot, img):
+    from tomosar2height_amd.decoder.pixel import PixelwiseDecoder
+    g = load_golden("pixelwise_decoder")
+    tag = f"{mode}_f{int(foot)}_i{int(img)}"
+    dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode=mode, use_footprint=foot), seed=7)
+    assert list(dec.state_dict()) == g[f"keys_{tag}"].tolist()
+    dec.to(_dev())
+    planes = {"xy": torch.from_numpy(g[f"xy_{tag}"]).to(_dev()).requires_grad_(True)}
+    if img:
+        planes["image"] = torch.from_numpy(g[f"image_{tag}"]).to(_dev())
+    x, xf = dec(planes)
+    _close(x.detach().cpu().numpy(), g[f"x_{tag}"], what="x")
+    loss = x.sum()
+    if foot:
+        _close(xf.detach().cpu().numpy(), g[f"xf_{tag}"], what="xf")
+        loss = loss + 0.5 * xf.sum()
+    else:
+        assert xf is None
+    loss.backward()
+    _close(planes["xy"].grad.cpu().numpy(), g[f"gxy_{tag}"], rel=2e-4, what="gxy")
+
+
+def _full_model(tag):
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config, munich_config
+    cfg = berlin_config() if tag == "berlin" else munich_config(use_image=True)
+    return det_init_(TomoSAR2Height(cfg), seed=8).to(_dev()), cfg
+
+
+@pytest.mark.parametrize("tag", ["berlin", "munich"])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_full_model_golden(tag, channels_last):
+    """Full-size networks at N=4096 against the reference's own output (fixture 8 of SURVEY 8c)."""
+    from tomosar2height_amd.trainer import Trainer
+    g = load_golden(f"full_model_{tag}_n4096")
+    model, cfg = _full_model(tag)
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    assert list(model.state_dict()) == g["state_keys"].tolist()
+    if channels_last:
+        model.set_channels_last(True)
+    cloud = torch.from_numpy(g["cloud"]).to(_dev())
+    image = None
+    if tag == "munich":
+        image = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(8)).to(_dev())
+    with torch.no_grad():
+        pa, pb = model(input_cloud=cloud, input_image=image)
+    assert pa.shape == (1, 512, 512, 1)
+    _close(pa[0, :, :, 0].cpu().numpy(), g["height"], what="height")
+    if tag == "munich":
+        _close(pb[0, :, :, 0].cpu().numpy(), g["footprint_logits"], what="footprint logits")
+    else:
+        assert pb is None
+    # loss + gradients through Trainer.train_step semantics
+    dsm = _dsm(g["dsm_lo"])
+    tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=2,
+                 use_cloud=True, use_image=tag == "munich", use_footprint=tag == "munich")
+    data = {"inputs": cloud, "dsm": dsm.to(_dev())}
+    if image is not None:
+        data["image"] = image
+    assert tr.train_step(data) is False
+    np.testing.assert_allclose(float(tr.accumulated_loss), float(g["loss"]), rtol=1e-4)
+    grads = dict(model.named_parameters())
+    assert [k for k, v in grads.items() if v.grad is None] == g["none_grad"].tolist()
+    for k, n in zip(g["grad_names"].tolist(), g["grad_norm"]):
+        got = grads[k].grad.double().norm().item()
+        assert abs(got - n) <= 1e-3 * n + 1e-9, f"{k}: grad norm {got} vs {n}"
+
+
+def test_model_vs_torch_oracle_all_grads():
+    """Same weights, same skewed tile (N=20000): every output pixel and every parameter gradient against the
+    CPU torch oracle."""
+    from oracle import torch_ref
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    cfg = berlin_config()
+    ref = det_init_(torch_ref.TomoSAR2Height(cfg), seed=21)
+    model = TomoSAR2Height(cfg)
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model.to(_dev())
+    cloud = synth_cloud(20000, seed=77)
+    cloud[0, :3000, :2] = cloud[0, 0, :2]                    # 3000 points in ONE finest cell (facade-like skew)
+    dsm = torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(1)) * 30
+    loss_ref = torch_ref.train_loss(ref, cloud, None, dsm)
+    loss_ref.backward()
+    pa, _ = model(input_cloud=cloud.to(_dev()))
+    loss = torch.nn.functional.l1_loss(pa.squeeze(), dsm.squeeze().to(_dev()))
+    loss.backward()
+    with torch.no_grad():
+        pa_ref, _ = ref(input_cloud=cloud)
+    _close(pa.detach().cpu().numpy(), pa_ref.numpy(), what="height")
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is not None:
+            _close(p.grad.cpu().numpy(), q.grad.numpy(), rel=1e-3, what=k)
+
+
+def test_trainer_accumulation_golden():
+    """trainer.py:47-89: 3 tiles summed, one AdamW step -- post-step weights of the reference's own Trainer."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    g = load_golden("trainer_accumulation")
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.plane_resolution = 16
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 3
+    cfg.model.encoder_kwargs.unet_kwargs.start_filts = 8
+    model = det_init_(TomoSAR2Height(cfg), seed=9).to(_dev())
+    tr = Trainer(model, torch.optim.AdamW(model.parameters(), lr=1e-4), device=_dev(), optimize_every=3, use_cloud=True)
+    stepped = [tr.train_step({"inputs": torch.from_numpy(g[f"cloud_{t}"]), "dsm": _dsm(g[f"dsm_lo_{t}"])[None]})
+               for t in range(3)]
+    assert stepped == [False, False, True]
+    np.testing.assert_allclose(float(tr.last_avg_loss), float(g["last_avg_loss"]), rtol=1e-5)
+    params = dict(model.named_parameters())
+    for k in g.files:
+        if k.startswith("after."):
+            name = k[len("after."):]
+            np.testing.assert_allclose(params[name].detach().cpu().numpy(), g[k], rtol=1e-4, atol=2e-6)
+    # grads were zeroed for the next accumulation window; never-used parameters still have no grad
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in model.parameters())
+    assert sum(p.grad is None for p in model.parameters()) == 8
+
+
+def test_full_size_properties():
+    """BASELINE.json config 2 (N = 131072): size-independent properties -- run-to-run determinism (no atomics
+    on the path) and invariance to the order of the input points (the network is a set function of the cloud)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    model = det_init_(TomoSAR2Height(berlin_config()), seed=3).to(_dev())
+    tile = berlin_tile(5)
+    cloud = tile["inputs"].to(_dev())
+    with torch.no_grad():
+        h1, _ = model(input_cloud=cloud)
+        h2, _ = model(input_cloud=cloud)
+        perm = torch.randperm(cloud.shape[1], generator=torch.Generator().manual_seed(0)).to(_dev())
+        h3, _ = model(input_cloud=cloud[:, perm].contiguous())
+    assert torch.isfinite(h1).all()
+    assert torch.equal(h1, h2), "two runs on the same tile differ: a nondeterministic reduction crept in"
+    _close(h3.cpu().numpy(), h1.cpu().numpy(), what="point-order invariance")

@@ -1,0 +1,174 @@
+"""ALTO U-Net (reference: tomosar2height/encoder/alto.py) on the MI355X path.
+
+Every level alternates topology: grid convs (MIOpen through PyTorch-ROCm, out of hand-written scope:
+SURVEY.md 8a-9) -> bilinear sample to the points -> per-point MLP -> mean-rasterise back to the grid.
+The three point<->grid steps run as HIP kernels on the tile's cell-sorted order
+(``ops.sample_plane`` / ``mlp.comm_mlp`` / ``ops.rasterise_mean``); the reference recomputes cell indices
+and clones the coordinates at every level (alto.py:79-80, 92-94, 189-190), here the ``TileIndex`` built
+once per forward is shared by all of them.
+
+Constructor arguments, sub-module names and therefore ``state_dict`` keys are the reference's
+(``down_convs.{i}.{conv1,conv2,fc_comm.0,fc_comm.2,fc_c,conv1x1}``, ``up_convs.{i}.{upconv,upconv_noup,
+fc_comm.0,fc_comm.2,fc_c,conv1x1,conv1,conv2}``, ``conv_final``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import init
+
+from .. import mlp, ops
+from ..tile import TileIndex
+
+
+def conv3x3(in_channels, out_channels):
+    return nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+
+
+def conv1x1(in_channels, out_channels):
+    return nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+def upconv2x2(in_channels, out_channels, mode="transpose"):
+    if mode != "transpose":
+        raise NotImplementedError("only up_mode='transpose' is built (the only mode any reference config selects)")
+    return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+
+
+def _comm_layers(channels):
+    return nn.Sequential(nn.Linear(channels, 2 * channels), nn.ReLU(), nn.Linear(2 * channels, channels))
+
+
+class _PointGridLevel(nn.Module):
+    """Shared point<->grid step of DownConv / UpConv: sample -> fc_comm (+ fc_c) -> rasterise."""
+
+    channels_last = False
+
+    def _exchange(self, tile: TileIndex, grid: torch.Tensor, c_last):
+        sampled = ops.sample_plane(tile, grid)                                   # alto.py:121-122 / 245-246
+        fa, fb = self.fc_comm[0], self.fc_comm[2]
+        c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
+                         self.fc_c.weight, self.fc_c.bias)                       # alto.py:123-128 / 248-253
+        raster = ops.rasterise_mean(tile, c, grid.shape[2], self.channels_last)  # alto.py:130 / 255
+        return raster, c
+
+
+class DownConv(_PointGridLevel):
+    """alto.py:47-138."""
+
+    def __init__(self, in_channels, out_channels, i, pooling, depth, sample_mode="bilinear"):
+        super().__init__()
+        if sample_mode != "bilinear":
+            raise NotImplementedError("only sample_mode='bilinear' is built")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.pooling, self.downsample, self.depth = pooling, i, depth
+        self.conv1 = conv3x3(in_channels, out_channels)
+        self.conv2 = conv3x3(out_channels, out_channels)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.fc_comm = _comm_layers(out_channels)
+        self.fc_c = nn.Linear(in_channels, out_channels)
+        if i > 0:
+            self.conv1x1 = conv1x1(in_channels, out_channels)
+
+    def forward(self, tile: TileIndex, grid, prev_conv=None, c_last=None):
+        g = F.relu(self.conv2(F.relu(self.conv1(grid))))
+        if prev_conv is not None:
+            # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
+            res_in = self.pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
+            g = g + self.conv1x1(res_in)
+        raster, c = self._exchange(tile, g, c_last)
+        pooled = self.pool(raster) if self.pooling else raster
+        return pooled, raster, g, c
+
+
+class UpConv(_PointGridLevel):
+    """alto.py:141-257."""
+
+    def __init__(self, in_channels, out_channels, i, depth, merge_mode="concat", up_mode="transpose",
+                 sample_mode="bilinear"):
+        super().__init__()
+        if sample_mode != "bilinear":
+            raise NotImplementedError("only sample_mode='bilinear' is built")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.merge_mode, self.up_mode, self.depth = merge_mode, up_mode, depth
+        self.is_last = i == depth - 2
+        self.upconv = upconv2x2(in_channels, out_channels, up_mode)
+        if self.is_last:
+            self.upconv_noup = conv1x1(in_channels, out_channels)
+        self.fc_comm = _comm_layers(out_channels)
+        self.fc_c = nn.Linear(in_channels, out_channels)
+        self.conv1x1 = conv1x1(in_channels, out_channels) if self.is_last else upconv2x2(in_channels, out_channels, up_mode)
+        self.conv1 = conv3x3(2 * out_channels if merge_mode == "concat" else out_channels, out_channels)
+        self.conv2 = conv3x3(out_channels, out_channels)
+
+    def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last):
+        up = self.upconv_noup(from_up) if self.is_last else self.upconv(from_up)    # alto.py:215-218
+        g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
+        g = F.relu(self.conv2(F.relu(self.conv1(g))))
+        if prev_conv is not None:
+            g = g + self.conv1x1(prev_conv)                                         # alto.py:233-236
+        if self.is_last:                                                            # alto.py:241-242
+            return g, g, c_last
+        raster, c = self._exchange(tile, g, c_last)
+        return raster, g, c
+
+
+class UNet(nn.Module):
+    """alto.py:260-382.  ``forward(p, x, c)`` keeps the reference signature: ``p [B,N,3]`` points,
+    ``x = {'xy': plane}``, ``c [B,N,C]`` point features.  The encoder calls ``forward_sorted`` with the
+    tile it already built; the public signature builds one on the fly."""
+
+    def __init__(self, num_classes, in_channels=3, depth=0, start_filts=64, up_mode="transpose",
+                 merge_mode="concat", **kwargs):
+        super().__init__()
+        if up_mode not in ("transpose", "upsample"):
+            raise ValueError(f'"{up_mode}" is not a valid mode for upsampling. Only "transpose" and "upsample" are allowed.')
+        if merge_mode not in ("concat", "add"):
+            raise ValueError(f'"{merge_mode}" is not a valid mode for merging up and down paths. '
+                             'Only "concat" and "add" are allowed.')
+        if up_mode == "upsample" and merge_mode == "add":
+            raise ValueError('up_mode "upsample" is incompatible with merge_mode "add"')
+        self.num_classes, self.in_channels = num_classes, in_channels
+        self.start_filts, self.depth = start_filts, depth
+        self.up_mode, self.merge_mode = up_mode, merge_mode
+
+        downs, ups = [], []
+        outs = in_channels
+        for i in range(depth):
+            ins = in_channels if i == 0 else outs
+            outs = start_filts * (2 ** i)
+            downs.append(DownConv(ins, outs, i, pooling=0 < i < depth - 1, depth=depth))
+        for i in range(depth - 1):
+            ins, outs = outs, outs // 2
+            ups.append(UpConv(ins, outs, i, depth=depth, up_mode=up_mode, merge_mode=merge_mode))
+        self.down_convs = nn.ModuleList(downs)
+        self.up_convs = nn.ModuleList(ups)
+        self.conv_final = conv1x1(outs, num_classes)
+        self.reset_params()
+
+    @staticmethod
+    def weight_init(m):
+        if isinstance(m, nn.Conv2d):
+            init.xavier_normal_(m.weight)
+            init.constant_(m.bias, 0)
+
+    def reset_params(self):
+        for m in self.modules():
+            self.weight_init(m)
+
+    def set_channels_last(self, flag: bool):
+        for m in self.modules():
+            if isinstance(m, _PointGridLevel):
+                m.channels_last = bool(flag)
+
+    def forward_sorted(self, tile: TileIndex, plane: torch.Tensor, c_sorted: torch.Tensor) -> torch.Tensor:
+        skips, prev_conv, c = [], None, c_sorted
+        for down in self.down_convs:
+            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c)
+            skips.append(raster)
+        for i, up in enumerate(self.up_convs):
+            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c)
+        return self.conv_final(plane)
+
+    def forward(self, p, x, c):
+        tile = TileIndex(p, x["xy"].shape[2])
+        return self.forward_sorted(tile, x["xy"], tile.sort_rows(c))

@@ -1,0 +1,71 @@
+"""LocalPoolPointnet (reference: tomosar2height/encoder/pointnet.py:12-111) on the MI355X path.
+
+One ``TileIndex`` (bin + stable Morton sort + CSR) is built per forward; all per-point tensors then live
+in cell-sorted order, where the reference's ``scatter_max``/``gather`` neighbourhood pooling and its
+``scatter_mean`` rasterisation are contiguous-segment HIP kernels (``ops.pool_max``,
+``ops.rasterise_mean``).  Parameters and ``state_dict`` keys are the reference's: ``fc_pos``,
+``blocks.{k}.{fc_0,fc_1,shortcut}``, ``fc_c``, ``unet.*``.
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .. import mlp, ops
+from ..block import ResnetBlockFC
+from ..tile import TileIndex
+from .alto import UNet as Alto
+from .unet import UNet
+
+
+class LocalPoolPointnet(nn.Module):
+    def __init__(self, feature_dim=128, dim=3, hidden_dim=128, scatter_type="max", unet_type="alto",
+                 unet_kwargs=None, plane_resolution=None, n_blocks=5):
+        super().__init__()
+        self.c_dim = feature_dim
+        self.fc_pos = nn.Linear(dim, 2 * hidden_dim)
+        self.blocks = nn.ModuleList([ResnetBlockFC(2 * hidden_dim, hidden_dim) for _ in range(n_blocks)])
+        self.fc_c = nn.Linear(hidden_dim, feature_dim)
+        self.actvn = nn.ReLU()
+        self.unet_type = unet_type
+        if unet_type == "unet":
+            self.unet = UNet(feature_dim, in_channels=feature_dim, **(unet_kwargs or {}))
+        elif unet_type == "alto":
+            self.unet = Alto(feature_dim, in_channels=feature_dim, **(unet_kwargs or {}))
+        else:
+            raise ValueError(f"Unknown unet_type: {unet_type}")
+        self.reso_plane = plane_resolution
+        if scatter_type == "max":
+            self.scatter_type = "max"
+        elif scatter_type == "mean":
+            raise NotImplementedError("scatter_type='mean' pooling is not built (no reference config selects it)")
+        else:
+            raise ValueError("Invalid scatter type")
+        self.channels_last = False
+        self.check_domain = False
+
+    def set_channels_last(self, flag: bool):
+        """Keep the grid side in channels_last memory so planes need no NCHW<->NHWC copies."""
+        self.channels_last = bool(flag)
+        if hasattr(self.unet, "set_channels_last"):
+            self.unet.set_channels_last(flag)
+
+    def point_features(self, tile: TileIndex) -> torch.Tensor:
+        """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max-pools, fc_c."""
+        net = mlp.linear(tile.pts, self.fc_pos.weight, self.fc_pos.bias)
+        net = self.blocks[0](net)
+        for block in self.blocks[1:]:
+            pooled = ops.pool_max(tile, net)
+            net = block.forward_split(net, pooled)
+        return mlp.linear(net, self.fc_c.weight, self.fc_c.bias, relu_in=True)
+
+    def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``."""
+        tile = TileIndex(inputs, self.reso_plane)
+        if self.check_domain:
+            tile.check_domain()
+        net = self.point_features(tile)
+        plane = ops.rasterise_mean(tile, net, self.reso_plane, self.channels_last)      # pointnet.py:83
+        if self.unet_type == "unet":
+            return {"xy": self.unet(plane)}
+        return {"xy": self.unet.forward_sorted(tile, plane, net)}                       # pointnet.py:88

@@ -1,0 +1,63 @@
+"""TomoSAR2Height network wiring (reference: tomosar2height/model.py:9-86): point-cloud encoder (+ optional
+image encoder) -> pixelwise decoder -> heights in metres.  Same constructor, forward signature and
+``state_dict`` keys (``point_encoder.*``, ``image_encoder.*``, ``decoder.*``) as the reference, so
+``trainer.py`` / ``generator.py``-style callers and reference checkpoints work unchanged."""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .decoder import decoder_dict
+from .encoder import encoder_dict
+
+
+class TomoSAR2Height(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        cfg_model = cfg["model"]
+        self.dim = cfg_model["data_dim"]
+        self.use_cloud = cfg.use_cloud
+        self.use_image = cfg.use_image
+        if self.use_cloud:
+            self.point_encoder = encoder_dict[cfg_model["encoder"]](dim=self.dim, **cfg_model["encoder_kwargs"])
+        if self.use_image:
+            self.image_encoder = encoder_dict[cfg_model.get("encoder2")](**cfg_model.get("encoder2_kwargs", {}))
+        self.decoder = decoder_dict["pixel"](**cfg_model["decoder_pixel_kwargs"])
+        self.threshold = cfg["test"]["threshold"]
+        z_bound = cfg["dataset"]["normalize"]["z_bound"]
+        self.z_scale = z_bound[1] - z_bound[0]
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        """model.py:46-52: Xavier-uniform weights / zero biases on every Conv2d and Linear (ConvTranspose2d is
+        not a Conv2d subclass and keeps torch's default init)."""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def set_channels_last(self, flag: bool = True):
+        """Run the grid side (planes + convs) in channels_last memory: the point<->grid HIP kernels read and
+        write pixel-major rows natively, so no layout copies remain.  Numerics are unchanged."""
+        if self.use_cloud and hasattr(self.point_encoder, "set_channels_last"):
+            self.point_encoder.set_channels_last(flag)
+        fmt = torch.channels_last if flag else torch.contiguous_format
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.weight.data = m.weight.data.contiguous(memory_format=fmt)
+        return self
+
+    def forward(self, input_cloud=None, input_image=None):
+        assert self.use_image or self.use_cloud, "At least one input modality must be used."
+        feature_planes = self.encode_inputs(input_cloud, input_image)
+        pa, pb = self.decoder(feature_planes)
+        return pa * self.z_scale, pb
+
+    def encode_inputs(self, input_cloud=None, input_image=None) -> Dict[str, torch.Tensor]:
+        feature_planes = {}
+        if self.use_cloud:
+            feature_planes.update(self.point_encoder(input_cloud))
+        if self.use_image:
+            feature_planes["image"] = self.image_encoder(input_image)
+        return feature_planes

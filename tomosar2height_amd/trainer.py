@@ -1,0 +1,146 @@
+"""Training / evaluation step (reference: trainer.py:8-146) plus tile-level data parallelism.
+
+``Trainer.train_step(data)`` keeps the reference contract: L1(mean) on heights (+ ``weight_ce`` x
+BCE-with-logits on ``dsm > 1e-4`` with a footprint head), ``loss.backward()``, gradients SUMMED over
+``optimize_every`` tiles (no 1/k scaling, trainer.py:69-89), then one optimizer step.
+
+Data parallel (an addition: the reference is single-device): with ``process_group`` set, each of
+the W ranks runs ``optimize_every / W`` of the tiles of one optimizer step, and one RCCL all-reduce(SUM) of a
+single flat fp32 gradient bucket precedes ``optimizer.step()``.  SUM, not mean: it reproduces the
+single-device accumulated gradient.  Parameters that never receive a gradient
+(``up_convs[depth-2].{upconv,fc_comm,fc_c}``, alto.py:241-242) are a static set and stay out of the bucket, so
+AdamW skips them exactly as it does in the reference.
+"""
+from collections import defaultdict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class GradBucket:
+    """One contiguous fp32 buffer holding every live gradient; ``p.grad`` are views into it."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.grad is not None]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.grad.dtype, device=ref.grad.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.flat[off:off + n].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+            off += n
+
+    def all_reduce(self, group):
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+    def zero_(self):
+        self.flat.zero_()
+
+
+class Trainer:
+    def __init__(self, model: nn.Module, optimizer, device=None, optimize_every=1, use_cloud=False, use_image=False,
+                 use_footprint=False, weight_ce=10., process_group=None):
+        self.model = model
+        self.optimizer = optimizer
+        self.device = device
+        self.loss_ce = nn.BCEWithLogitsLoss(reduction="mean")
+        self.loss_l1 = nn.L1Loss(reduction="mean")
+        self.weight_ce = weight_ce
+        self.optimizer.zero_grad()
+
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if process_group is not None else 1
+        if optimize_every % self.world:
+            raise ValueError(f"optimize_every={optimize_every} must be a multiple of the world size {self.world}")
+        self.optimize_every = optimize_every
+        self.local_every = optimize_every // self.world      # tiles per rank per optimizer step
+        self.bucket = None
+
+        self.accumulated_steps = 0
+        self.accumulated_loss = 0.0
+        self.accumulated_loss_dict = {"loss_ce": 0.0, "loss_l1": 0.0}
+        self.last_avg_loss = 0.0
+        self.last_avg_loss_dict = {"loss_ce": 0.0, "loss_l1": 0.0}
+        self.use_cloud, self.use_image, self.use_footprint = use_cloud, use_image, use_footprint
+
+    # ------------------------------------------------------------------------------------------ loss
+    def _losses(self, data, mask_threshold):
+        device = self.device
+        input_cloud = data.get("inputs").to(device) if self.use_cloud else None
+        input_image = data.get("image").to(device) if self.use_image else None
+        dsm_gt = data.get("dsm").to(device)[None, ...]
+        pa, pb = self.model(input_cloud=input_cloud, input_image=input_image)
+        loss_l1 = self.loss_l1(pa.squeeze(), dsm_gt.squeeze().float())
+        if self.use_footprint:
+            loss_ce = self.weight_ce * self.loss_ce(pb.squeeze(), (dsm_gt.squeeze() > mask_threshold).float())
+        else:
+            loss_ce = torch.tensor(0.0, device=device)
+        return loss_l1, loss_ce
+
+    # ------------------------------------------------------------------------------------------ train
+    def train_step(self, data) -> bool:
+        """One tile: forward, loss, backward.  Returns True when this call ended with an optimizer step."""
+        self.model.train()
+        loss_l1, loss_ce = self._losses(data, 0.0001)                     # trainer.py:63-69
+        loss = loss_l1 + loss_ce
+        loss.backward()
+
+        self.accumulated_steps += 1
+        self.accumulated_loss += loss.detach()
+        self.accumulated_loss_dict["loss_ce"] += loss_ce.detach()
+        self.accumulated_loss_dict["loss_l1"] += loss_l1.detach()
+        if self.accumulated_steps < self.local_every:
+            return False
+
+        if self.bucket is None:
+            self.bucket = GradBucket(list(self.model.parameters()))
+        if self.world > 1:
+            self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
+        self.optimizer.step()
+        with torch.no_grad():
+            denom = self.optimize_every
+            acc = self.accumulated_loss
+            acc_d = dict(self.accumulated_loss_dict)
+            if self.world > 1:
+                packed = torch.stack([torch.as_tensor(acc, device=self.device, dtype=torch.float32),
+                                      torch.as_tensor(acc_d["loss_ce"], device=self.device, dtype=torch.float32),
+                                      torch.as_tensor(acc_d["loss_l1"], device=self.device, dtype=torch.float32)])
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                acc, acc_d = packed[0], {"loss_ce": packed[1], "loss_l1": packed[2]}
+            self.last_avg_loss = acc / denom
+            self.last_avg_loss_dict = {k: v / denom for k, v in acc_d.items()}
+        self.accumulated_loss = 0.0
+        self.accumulated_steps = 0
+        self.accumulated_loss_dict = {k: 0.0 for k in self.accumulated_loss_dict}
+        self.bucket.zero_()     # == optimizer.zero_grad() for every parameter that has a gradient
+        return True
+
+    # ------------------------------------------------------------------------------------------ eval
+    def eval_step(self, data):
+        self.model.eval()
+        with torch.no_grad():
+            loss_l1, loss_ce = self._losses(data, 0.00001)                # trainer.py:136
+            loss = loss_l1 + loss_ce
+        return {"loss": loss.item(), "loss_l1": loss_l1.item(), "loss_ce": loss_ce.item()}
+
+    def evaluate(self, val_loader):
+        metrics = defaultdict(list)
+        for data in val_loader:
+            for k, v in self.eval_step(data).items():
+                metrics[k].append(v)
+        return {k: torch.tensor(v).mean().item() for k, v in metrics.items()}
+
+
+def broadcast_parameters(model: nn.Module, group=None, src: int = 0):
+    """Identical replicas before the first step (rank `src`'s init wins)."""
+    flat = torch.cat([p.data.reshape(-1) for p in model.parameters()])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for p in model.parameters():
+        n = p.numel()
+        p.data.copy_(flat[off:off + n].view_as(p))
+        off += n
