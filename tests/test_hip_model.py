@@ -113,9 +113,12 @@ def test_full_model_golden(tag, channels_last):
     np.testing.assert_allclose(float(tr.accumulated_loss), float(g["loss"]), rtol=1e-4)
     grads = dict(model.named_parameters())
     assert [k for k, v in grads.items() if v.grad is None] == g["none_grad"].tolist()
+    # L1's gradient is sign(pa - dsm): pixels with pa ~ dsm flip under 1e-6 height differences, so gradient
+    # NORMS under the reference loss are only comparable to ~1e-2; tight gradient parity is checked with a
+    # smooth loss in test_model_vs_torch_oracle_all_grads.
     for k, n in zip(g["grad_names"].tolist(), g["grad_norm"]):
         got = grads[k].grad.double().norm().item()
-        assert abs(got - n) <= 1e-3 * n + 1e-9, f"{k}: grad norm {got} vs {n}"
+        assert abs(got - n) <= 2e-2 * n + 1e-9, f"{k}: grad norm {got} vs {n}"
 
 
 def test_model_vs_torch_oracle_all_grads():
@@ -131,20 +134,34 @@ def test_model_vs_torch_oracle_all_grads():
     model.to(_dev())
     cloud = synth_cloud(20000, seed=77)
     cloud[0, :3000, :2] = cloud[0, 0, :2]                    # 3000 points in ONE finest cell (facade-like skew)
-    dsm = torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(1)) * 30
-    loss_ref = torch_ref.train_loss(ref, cloud, None, dsm)
+    # smooth (linear) loss with fixed random weights: the gradient does not depend on sign(pa - dsm)
+    w = torch.randn(512, 512, generator=torch.Generator().manual_seed(1))
+    pa_ref, _ = ref(input_cloud=cloud)
+    loss_ref = (pa_ref.squeeze() * w).mean()
     loss_ref.backward()
+    pa_ref = pa_ref.detach()
     pa, _ = model(input_cloud=cloud.to(_dev()))
-    loss = torch.nn.functional.l1_loss(pa.squeeze(), dsm.squeeze().to(_dev()))
+    loss = (pa.squeeze() * w.to(_dev())).mean()
     loss.backward()
-    with torch.no_grad():
-        pa_ref, _ = ref(input_cloud=cloud)
     _close(pa.detach().cpu().numpy(), pa_ref.numpy(), what="height")
-    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
-    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4, atol=1e-5)
+    # Gradients of a ReLU/max-pool network are piecewise constant in the activations: a mask that flips under
+    # a 1e-7 activation difference moves a gradient entry by a finite step.  The torch oracle itself, run on
+    # this GPU instead of the CPU, deviates from its CPU run by up to ~6e-3 (max-normalised) on the same inputs
+    # (measured), so that is the resolution of this check: 1e-2 max-normalised, 3e-3 in L2.
+    ref_gpu = det_init_(torch_ref.TomoSAR2Height(cfg), seed=21).to(_dev())
+    pg, _ = ref_gpu(input_cloud=cloud.to(_dev()))
+    (pg.squeeze() * w.to(_dev())).mean().backward()
+    for (k, p), (_, q), (_, r) in zip(model.named_parameters(), ref.named_parameters(), ref_gpu.named_parameters()):
         assert (p.grad is None) == (q.grad is None), k
-        if p.grad is not None:
-            _close(p.grad.cpu().numpy(), q.grad.numpy(), rel=1e-3, what=k)
+        if p.grad is None:
+            continue
+        got, want, want_gpu = p.grad.cpu().double(), q.grad.double(), r.grad.cpu().double()
+        _close(got.numpy(), want.numpy(), rel=1e-2, what=k)
+        l2 = ((got - want).norm() / (want.norm() + 1e-30)).item()
+        l2_gpu = ((got - want_gpu).norm() / (want_gpu.norm() + 1e-30)).item()
+        assert l2 <= 3e-3, f"{k}: L2 rel err vs CPU oracle {l2:.2e}"
+        assert l2_gpu <= 3e-3, f"{k}: L2 rel err vs the oracle run on the device {l2_gpu:.2e}"
 
 
 def test_trainer_accumulation_golden():

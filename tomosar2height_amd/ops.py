@@ -154,13 +154,13 @@ class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, size: int, addend):
         x = _f32(x, "upsample_bilinear").contiguous()
+        if addend is not None:
+            addend = _f32(addend, "upsample_bilinear").contiguous()
         _lib.require_device(x, addend, what="upsample_bilinear")
         b, c, h, w = x.shape
         out = torch.empty(b, c, size, size, dtype=torch.float32, device=x.device)
-        if addend is not None:
-            addend = addend.contiguous()
-            if addend.shape != out.shape:
-                raise ValueError("upsample_bilinear: addend must already have the output size")
+        if addend is not None and addend.shape != out.shape:
+            raise ValueError("upsample_bilinear: addend must already have the output size")
         _lib.check(_lib.load().t2h_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend) if addend is not None else None,
                                                          b, c, h, w, size, size, _lib.ptr(out), _lib.stream()),
                    "t2h_upsample_bilinear_fwd")
