@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training tile-steps/s on Berlin-shaped synthetic tiles, cloud-only, fp32
+(BASELINE.json configs[1]: N = 131072 points / tile, R = 256, ALTO depth 5, 512^2 target).
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one tile through ``Trainer.train_step``: forward, L1 loss, backward, and -- every
+``optimize_every``/world tiles per rank -- one RCCL all-reduce(SUM) of the flat gradient bucket + AdamW step
+(reference: trainer.py:47-89, optimize_every = 64).  Tiles are resident in HBM before the timed region.
+Weak scaling: every rank runs K tiles; value = world * K / max-over-ranks(time).
+
+Rank 0 prints ONE JSON line (contract fields + `roofline` + `cpu_baseline` + a per-kernel table).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--points", type=int, default=131072, help="points per tile (SURVEY.md 8d default)")
+    ap.add_argument("--optimize-every", type=int, default=64, help="tiles per optimizer step (reference: 64)")
+    ap.add_argument("--tile-pool", type=int, default=4, help="distinct resident tiles cycled per rank")
+    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    return ap.parse_args()
+
+
+def cpu_baseline(points: int, threads: int):
+    """The oracle's torch restatement of the reference model ("port"), one tile-step (fwd + bwd) of the SAME
+    workload on the host cores.  This is the only place bench.py touches oracle/."""
+    from oracle import torch_ref
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    if threads > 0:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = torch_ref.TomoSAR2Height(berlin_config())
+    warm = berlin_tile(1, n_points=2048)
+    torch_ref.train_loss(model, warm["inputs"], None, warm["dsm"]).backward()
+    tile = berlin_tile(0, n_points=points)
+    t0 = time.perf_counter()
+    torch_ref.train_loss(model, tile["inputs"], None, tile["dsm"]).backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"1 tile-step (fwd+bwd, N={points}, fp32) of the oracle torch restatement, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU path to benchmark)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        group = dist.group.WORLD
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    from tomosar2height_amd import TomoSAR2Height, _lib
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.trainer import Trainer, broadcast_parameters
+
+    cfg = berlin_config()
+    torch.manual_seed(0)
+    model = TomoSAR2Height(cfg).to(dev)
+    if args.channels_last:
+        model.set_channels_last(True)
+    if world > 1:
+        broadcast_parameters(model, group)
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate)     # train.py:97
+    trainer = Trainer(model, opt, device=dev, optimize_every=args.optimize_every, use_cloud=True,
+                      process_group=group)
+    n_params = sum(p.numel() for p in model.parameters())
+
+    tiles = []
+    for i in range(args.tile_pool):
+        t = berlin_tile(seed=1000 * rank + i, n_points=args.points)
+        tiles.append({"inputs": t["inputs"].to(dev), "dsm": t["dsm"].to(dev)})
+
+    def run(n_steps, offset=0):
+        for s in range(n_steps):
+            trainer.train_step(tiles[(offset + s) % len(tiles)])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    timeline = None if args.no_kernel_timing else _lib.KernelTimeline()
+    t0 = time.perf_counter()
+    if timeline is not None:
+        with timeline:
+            run(args.steps, args.warmup)
+    else:
+        run(args.steps, args.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "training tiles/sec (Berlin crop, cloud-only)", "value": round(value, 4), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Berlin cloud-only, fp32, B=1 tile, "
+                                   f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
+                                   f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
+                       "points_per_tile": args.points, "optimize_every": args.optimize_every,
+                       "parallelism": f"dp{world}", "params": n_params, "channels_last": bool(args.channels_last),
+                       "miopen_find": bool(args.miopen_find)},
+        }
+        if timeline is not None:
+            kernels = []
+            for name, d in sorted(timeline.summary().items(), key=lambda kv: -kv[1]["ms"]):
+                avg_us = 1e3 * d["ms"] / d["calls"]
+                per_launch = d["bytes"] / d["calls"]
+                gbs = per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+                kernels.append({"kernel": name, "launches_per_step": round(d["calls"] / args.steps, 2),
+                                "avg_us": round(avg_us, 2), "bytes_per_launch": int(per_launch),
+                                "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                                "ms_per_step": round(d["ms"] / args.steps, 4)})
+            if kernels:
+                top = kernels[0]
+                out["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["GBps"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": None}
+                out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
+                out["kernels"] = kernels
+        if world == 1 and not args.skip_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

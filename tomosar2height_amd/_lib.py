@@ -72,6 +72,53 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
+class KernelTimeline:
+    """Opt-in per-call HIP-event timing of the C-ABI launches (used by bench.py for the roofline figures).
+
+    Events are recorded on torch's current stream -- the stream every t2h launch goes to -- right before and
+    after the call.  ``summary()`` must be called after a device synchronise."""
+
+    def __init__(self):
+        self.records = []          # (name, algorithmic_bytes, start_event, end_event)
+
+    def __enter__(self):
+        global _timeline
+        self._prev, _timeline = _timeline, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timeline
+        _timeline = self._prev
+
+    def summary(self):
+        out = {}
+        for name, nbytes, s, e in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += nbytes
+        return out
+
+
+_timeline = None
+
+
+def call(name: str, *args, nbytes: int = 0, tag: str = None):
+    """Invoke ``name`` from the library, raising on a non-zero return code.  ``nbytes`` = the ALGORITHMIC HBM
+    bytes of this launch, only used when a KernelTimeline is active."""
+    fn = getattr(load(), name)
+    tl = _timeline
+    if tl is None:
+        rc = fn(*args)
+    else:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        tl.records.append((tag or name, nbytes, s, e))
+    check(rc, name)
+
+
 def ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
 

@@ -27,7 +27,7 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     _lib.require_device(x, what="to_nhwc")
     b, c, h, w = x.shape
     out = torch.empty(b, h, w, c, dtype=x.dtype, device=x.device)
-    _lib.check(_lib.load().t2h_nchw_to_nhwc(_lib.ptr(x), b, c, h * w, _lib.ptr(out), _lib.stream()), "t2h_nchw_to_nhwc")
+    _lib.call("t2h_nchw_to_nhwc", _lib.ptr(x), b, c, h * w, _lib.ptr(out), _lib.stream(), nbytes=8 * x.numel())
     return out
 
 
@@ -38,8 +38,8 @@ def from_nhwc(x_nhwc: torch.Tensor, channels_last: bool) -> torch.Tensor:
     _lib.require_device(x_nhwc, what="from_nhwc")
     b, h, w, c = x_nhwc.shape
     out = torch.empty(b, c, h, w, dtype=x_nhwc.dtype, device=x_nhwc.device)
-    _lib.check(_lib.load().t2h_nhwc_to_nchw(_lib.ptr(x_nhwc), b, c, h * w, _lib.ptr(out), _lib.stream()),
-               "t2h_nhwc_to_nchw")
+    _lib.call("t2h_nhwc_to_nchw", _lib.ptr(x_nhwc), b, c, h * w, _lib.ptr(out), _lib.stream(),
+              nbytes=8 * x_nhwc.numel())
     return out
 
 
@@ -53,14 +53,13 @@ class _PoolMax(torch.autograd.Function):
     def forward(ctx, feat, tile: TileIndex):
         feat = _f32(feat, "pool_max").contiguous()
         _lib.require_device(feat, what="pool_max")
-        lib = _lib.load()
         n, c = feat.shape
         if n != tile.n_points:
             raise ValueError(f"pool_max: {n} feature rows for a tile of {tile.n_points} points")
         pooled = torch.empty_like(feat)
-        winner = torch.empty(n, lib.t2h_pool_winner_stride(c), dtype=torch.uint8, device=feat.device)
-        _lib.check(lib.t2h_pool_max_fwd(_lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled),
-                                        _lib.ptr(winner), _lib.stream()), "t2h_pool_max_fwd")
+        winner = torch.empty(n, _lib.load().t2h_pool_winner_stride(c), dtype=torch.uint8, device=feat.device)
+        _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled),
+                  _lib.ptr(winner), _lib.stream(), nbytes=8 * c * n + 4 * n)
         ctx.tile, ctx.c = tile, c
         ctx.save_for_backward(winner)
         return pooled
@@ -71,9 +70,8 @@ class _PoolMax(torch.autograd.Function):
         tile = ctx.tile
         gpooled = gpooled.contiguous()
         gfeat = torch.empty_like(gpooled)
-        _lib.check(_lib.load().t2h_pool_max_bwd(_lib.ptr(gpooled), _lib.ptr(winner), _lib.ptr(tile.off0), tile.B,
-                                                tile.nbits, ctx.c, 0, _lib.ptr(gfeat), _lib.stream()),
-                   "t2h_pool_max_bwd")
+        _lib.call("t2h_pool_max_bwd", _lib.ptr(gpooled), _lib.ptr(winner), _lib.ptr(tile.off0), tile.B, tile.nbits,
+                  ctx.c, 0, _lib.ptr(gfeat), _lib.stream(), nbytes=8 * ctx.c * tile.n_points + 4 * tile.n_points)
         return gfeat, None
 
 
@@ -93,8 +91,8 @@ class _RasteriseMean(torch.autograd.Function):
             raise ValueError(f"rasterise_mean: {n} feature rows for a tile of {tile.n_points} points")
         r = tile.R >> level
         plane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=feat.device)
-        _lib.check(_lib.load().t2h_segmean_fwd(_lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, level, c,
-                                               _lib.ptr(plane), _lib.stream()), "t2h_segmean_fwd")
+        _lib.call("t2h_segmean_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, level, c, _lib.ptr(plane),
+                  _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(), tag=f"t2h_segmean_fwd[C={c},r={r}]")
         ctx.tile, ctx.level, ctx.c = tile, level, c
         return from_nhwc(plane, channels_last)
 
@@ -103,9 +101,10 @@ class _RasteriseMean(torch.autograd.Function):
         tile = ctx.tile
         g = to_nhwc(gplane)
         gfeat = torch.empty(tile.n_points, ctx.c, dtype=torch.float32, device=g.device)
-        _lib.check(_lib.load().t2h_segmean_bwd(_lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N,
-                                               tile.nbits, ctx.level, ctx.c, _lib.ptr(gfeat), _lib.stream()),
-                   "t2h_segmean_bwd")
+        _lib.call("t2h_segmean_bwd", _lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
+                  ctx.level, ctx.c, _lib.ptr(gfeat), _lib.stream(),
+                  nbytes=4 * g.numel() + 4 * tile.n_points + 4 * g.numel() // ctx.c + 4 * ctx.c * tile.n_points,
+                  tag=f"t2h_segmean_bwd[C={ctx.c},r={g.shape[1]}]")
         return gfeat, None, None, None
 
 
@@ -127,8 +126,9 @@ class _SamplePlane(torch.autograd.Function):
         _lib.require_device(p, what="sample_plane")
         b, r, _, c = p.shape
         out = torch.empty(tile.n_points, c, dtype=torch.float32, device=p.device)
-        _lib.check(_lib.load().t2h_sample_fwd(_lib.ptr(p), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c,
-                                              _lib.ptr(out), _lib.stream()), "t2h_sample_fwd")
+        _lib.call("t2h_sample_fwd", _lib.ptr(p), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c, _lib.ptr(out),
+                  _lib.stream(), nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * p.numel(),
+                  tag=f"t2h_sample_fwd[C={c},r={r}]")
         ctx.tile, ctx.r, ctx.c = tile, r, c
         return out
 
@@ -137,9 +137,10 @@ class _SamplePlane(torch.autograd.Function):
         tile, r, c = ctx.tile, ctx.r, ctx.c
         gout = gout.contiguous()
         gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
-        _lib.check(_lib.load().t2h_sample_bwd(_lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
-                                              tile.N, tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.stream()),
-                   "t2h_sample_bwd")
+        _lib.call("t2h_sample_bwd", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+                  tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.stream(),
+                  nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel(),
+                  tag=f"t2h_sample_bwd[C={c},r={r}]")
         return from_nhwc(gplane, ctx.was_cl), None
 
 
@@ -161,9 +162,9 @@ class _UpsampleBilinear(torch.autograd.Function):
         out = torch.empty(b, c, size, size, dtype=torch.float32, device=x.device)
         if addend is not None and addend.shape != out.shape:
             raise ValueError("upsample_bilinear: addend must already have the output size")
-        _lib.check(_lib.load().t2h_upsample_bilinear_fwd(_lib.ptr(x), _lib.ptr(addend) if addend is not None else None,
-                                                         b, c, h, w, size, size, _lib.ptr(out), _lib.stream()),
-                   "t2h_upsample_bilinear_fwd")
+        _lib.call("t2h_upsample_bilinear_fwd", _lib.ptr(x), _lib.ptr(addend) if addend is not None else None, b, c, h, w,
+                  size, size, _lib.ptr(out), _lib.stream(),
+                  nbytes=4 * (x.numel() + out.numel() * (2 if addend is not None else 1)))
         ctx.shape = (b, c, h, w, size)
         ctx.has_addend = addend is not None
         return out
@@ -173,8 +174,8 @@ class _UpsampleBilinear(torch.autograd.Function):
         b, c, h, w, size = ctx.shape
         gout = gout.contiguous()
         gin = torch.empty(b, c, h, w, dtype=torch.float32, device=gout.device)
-        _lib.check(_lib.load().t2h_upsample_bilinear_bwd(_lib.ptr(gout), b, c, h, w, size, size, _lib.ptr(gin),
-                                                         _lib.stream()), "t2h_upsample_bilinear_bwd")
+        _lib.call("t2h_upsample_bilinear_bwd", _lib.ptr(gout), b, c, h, w, size, size, _lib.ptr(gin), _lib.stream(),
+                  nbytes=4 * (gout.numel() + gin.numel()))
         return gin, None, (gout if ctx.has_addend else None)
 
 
@@ -190,6 +191,6 @@ def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
     _lib.require_device(x, what="coordinate2index")
     b, n, d = x.shape
     out = torch.empty(b, n, dtype=torch.int64, device=x.device)
-    _lib.check(_lib.load().t2h_coordinate2index(_lib.ptr(x), d, b * n, int(reso), _lib.ptr(out), _lib.stream()),
-               "t2h_coordinate2index")
+    _lib.call("t2h_coordinate2index", _lib.ptr(x), d, b * n, int(reso), _lib.ptr(out), _lib.stream(),
+              nbytes=16 * b * n)
     return out[:, None, :]

@@ -43,10 +43,9 @@ class TileIndex:
         self.status = torch.empty(1, dtype=torch.int32, device=dev)
         ws_bytes = lib.t2h_tile_workspace_bytes(self.B, self.N, self.nbits)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        _lib.check(lib.t2h_tile_build(_lib.ptr(cloud), self.dim, self.B, self.N, self.nbits, _lib.ptr(self.pts),
-                                      _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0),
-                                      _lib.ptr(self.status), _lib.ptr(ws), ws_bytes, _lib.stream()),
-                   "t2h_tile_build")
+        _lib.call("t2h_tile_build", _lib.ptr(cloud), self.dim, self.B, self.N, self.nbits, _lib.ptr(self.pts),
+                  _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0), _lib.ptr(self.status), _lib.ptr(ws),
+                  ws_bytes, _lib.stream(), nbytes=16 * bn + 4 * cells)
         self.device = dev
 
     @property
