@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Steady-state per-step kernel summary from a rocprofv3 --kernel-trace CSV of bench.py.
+
+rocprofv3's own --stats aggregates the whole process, which for this workload is dominated by MIOpen's
+one-time naive_conv warm-up; steps are delimited here by t2h::tile_keys_kernel (one launch per tile) and only
+the last `--steps` tiles are summarised.
+
+    python profiles/summarize_trace.py <kernel_trace.csv> [--steps 6] [--top 45]
+"""
+import argparse
+import collections
+import csv
+
+
+def category(k):
+    if "t2h::" in k:
+        return "t2h hand-written HIP"
+    if k.startswith("Cijk"):
+        return "rocBLAS/hipBLASLt GEMM"
+    if any(s in k for s in ("conv", "igemm", "Sp3Asm", "batched_transpose", "gemm_xdlops_bwd_weight", "Conv")):
+        return "MIOpen conv"
+    if "at::native" in k or "elementwise" in k:
+        return "torch elementwise/reduce/cat"
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--top", type=int, default=45)
+    a = ap.parse_args()
+    rows = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "tile_keys_kernel" in r["Kernel_Name"]]
+    lo, hi = starts[-(a.steps + 1)], starts[-1]
+    sel = rows[lo:hi]
+    wall = (int(rows[hi]["Start_Timestamp"]) - int(rows[lo]["Start_Timestamp"])) / 1e6 / a.steps
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in sel:
+        agg[r["Kernel_Name"]][0] += 1
+        agg[r["Kernel_Name"]][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    busy = sum(v[1] for v in agg.values()) / 1e3 / a.steps
+    print(f"steady state over the last {a.steps} tile-steps: wall {wall:.2f} ms/step, kernel-busy {busy:.2f} ms/step, "
+          f"{len(sel) / a.steps:.0f} launches/step")
+    cat = collections.defaultdict(float)
+    for k, (c, t) in agg.items():
+        cat[category(k)] += t
+    for k, v in sorted(cat.items(), key=lambda kv: -kv[1]):
+        print(f"  {k:<34s} {v / 1e3 / a.steps:9.3f} ms/step")
+    print()
+    print(f"{'kernel':<100s} {'launches/step':>13s} {'avg us':>10s} {'ms/step':>9s}")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
+        print(f"{k[:100]:<100s} {c / a.steps:13.1f} {t / c:10.1f} {t / 1e3 / a.steps:9.3f}")
+
+
+if __name__ == "__main__":
+    main()
