@@ -92,9 +92,12 @@ int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const int32_t 
  * generate_plane_features (scatter_mean into a zero plane)       pointnet.py:101-111; alto.py:76-88,187-197
  * level k: resolution r = 2^(nbits-k).  plane [B, r, r, C] (NHWC); empty cells are written 0
  * (no separate memset).  Sum order inside a cell = sorted order (deterministic).
- * Backward: gfeat[n] = gplane[cell_k(n)] / count(cell_k(n)). */
-int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int nbits, int level, int C,
-                    float *plane_nhwc, t2h_stream_t stream);
+ * Backward: gfeat[n] = gplane[cell_k(n)] / count(cell_k(n)).
+ * Coarse levels (>= 16 points per cell on average) run as per-(cell, split) partial sums in `workspace`
+ * (t2h_segmean_workspace_bytes; 0 = not needed, NULL accepted) + a finalise pass. */
+size_t t2h_segmean_workspace_bytes(int B, int N, int nbits, int level, int C);
+int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                    float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N,
                     int nbits, int level, int C, float *gfeat, t2h_stream_t stream);
 
@@ -106,12 +109,16 @@ int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t
  * Backward w.r.t. the plane (points carry no gradient):
  *   t2h_sample_bwd        deterministic gather over the 3x3 neighbouring cells of each pixel using
  *                         the tile CSR; requires pts in cell-sorted order and r == 2^(nbits-level);
+ *                         at coarse levels each row is instead read once into per-cell 3x3 pixel partials
+ *                         (`workspace`, t2h_sample_bwd_workspace_bytes) that a second pass gathers;
  *   t2h_sample_bwd_atomic any r / any point order, float atomics (order-dependent rounding);
  *                         gplane must be zeroed by the caller. */
 int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                    t2h_stream_t stream);
+size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C);
 int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
-                   int level, int C, float *gplane_nhwc, t2h_stream_t stream);
+                   int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
+                   t2h_stream_t stream);
 int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
                           float *gplane_nhwc, t2h_stream_t stream);
 

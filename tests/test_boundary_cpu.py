@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     build.build()
     lib = _lib.load()
     declared = _declared_symbols()
-    assert len(declared) >= 17
+    assert len(declared) >= 19
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/t2h.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
@@ -36,7 +36,7 @@ def test_host_side_helpers_need_no_gpu():
     assert lib.t2h_tile_workspace_bytes(1, 131072, 8) >= 4 * 131072 * 4
     assert lib.t2h_tile_workspace_bytes(1, 10, 11) == 0            # nbits out of range
     # argument validation happens before any launch: null pointers are an error code, not a crash
-    assert lib.t2h_segmean_fwd(None, None, 1, 8, 0, 32, None, None) == -1
+    assert lib.t2h_segmean_fwd(None, None, 1, 100, 8, 0, 32, None, None, 0, None) == -1
     assert b"null pointer" in lib.t2h_last_error_string()
 
 

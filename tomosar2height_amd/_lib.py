@@ -26,10 +26,12 @@ SIGNATURES = {
     "t2h_pool_winner_stride": (_i, [_i]),
     "t2h_pool_max_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_pool_max_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "t2h_segmean_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_segmean_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "t2h_segmean_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_segmean_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -121,6 +123,11 @@ def call(name: str, *args, nbytes: int = 0, tag: str = None):
 
 def ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch buffer from PyTorch's caching allocator (the library itself never allocates)."""
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
 def stream() -> int:

@@ -279,6 +279,181 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
     }
 }
 
+
+// ------------------------------------------------------------------------------ coarse levels (many points / cell)
+// At coarse ALTO levels a cell holds tens to hundreds of points, so "one lane-group walks one cell" leaves the
+// chip idle and the 3x3 pixel gather re-reads every row ~9x.  Here one workgroup owns (cell, split): its rows
+// are dealt round-robin to P = 256/G parallel row-slots (G lanes x float4 = the channel chunk), each slot keeps
+// its partial sums in registers, and the slots are combined through LDS in slot order (fixed => deterministic).
+constexpr int kCellThreads = 256;
+
+__host__ __device__ inline int cell_chunk_channels(int C) { return C < 256 ? C : 256; }   // channels per workgroup (<= 64 lanes x float4)
+
+// rows [lo, hi) of split `sp` out of S over segment [s, e)
+__device__ inline void split_range(int s, int e, int sp, int S, int &lo, int &hi) {
+    int len = e - s, per = (len + S - 1) / S;
+    lo = min(e, s + sp * per);
+    hi = min(e, lo + per);
+}
+
+// partial[((cellrow * S + sp)] [C]  -- per-(cell, split) sums of the rows; finalised by segmean_finalize_kernel
+__global__ __launch_bounds__(kCellThreads) void segmean_cells_kernel(const float *__restrict__ feat,
+                                                                     const int32_t *__restrict__ off0, int nbits,
+                                                                     int level, int C, int lgG, int S,
+                                                                     float *__restrict__ partial) {
+    extern __shared__ float4 red[];                       // [P][G]
+    const int G = 1 << lgG, P = kCellThreads >> lgG;
+    int lane_c = threadIdx.x & (G - 1), slot = threadIdx.x >> lgG;
+    int64_t cellrow = blockIdx.x;                          // b * cells_per_tile + mk   (Morton order)
+    int sp = blockIdx.y % S, chunk = blockIdx.y / S;
+    const int rbits = nbits - level;
+    int b = (int)(cellrow >> (2 * rbits));
+    uint32_t mk = (uint32_t)(cellrow & (((int64_t)1 << (2 * rbits)) - 1));
+    size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+    int lo, hi;
+    split_range(s, e, sp, S, lo, hi);
+    int c = chunk * cell_chunk_channels(C) + lane_c * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        int n = lo + slot;
+        for (; n + P < hi; n += 2 * P) {                   // two independent rows in flight per slot
+            float4 a0 = *reinterpret_cast<const float4 *>(feat + (size_t)n * C + c);
+            float4 a1 = *reinterpret_cast<const float4 *>(feat + (size_t)(n + P) * C + c);
+            acc.x = (acc.x + a0.x) + a1.x; acc.y = (acc.y + a0.y) + a1.y;
+            acc.z = (acc.z + a0.z) + a1.z; acc.w = (acc.w + a0.w) + a1.w;
+        }
+        for (; n < hi; n += P) {
+            float4 a0 = *reinterpret_cast<const float4 *>(feat + (size_t)n * C + c);
+            acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+        }
+    }
+    red[slot * G + lane_c] = acc;
+    __syncthreads();
+    if (slot == 0 && c < C) {
+        float4 t = red[lane_c];
+        for (int q = 1; q < P; ++q) {
+            float4 u = red[q * G + lane_c];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4 *>(partial + ((size_t)cellrow * S + sp) * C + c) = t;
+    }
+}
+
+// plane[cell] = (sum over splits, in split order) / max(count, 1)
+__global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float *__restrict__ partial,
+                                                                   const int32_t *__restrict__ off0, int B, int nbits,
+                                                                   int level, int C, int lg, int S,
+                                                                   float *__restrict__ plane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t gid = t >> lg;
+    const int rbits = nbits - level;
+    const int64_t cells_per_tile = (int64_t)1 << (2 * rbits);
+    if (gid >= (int64_t)B * cells_per_tile) return;
+    int b = (int)(gid >> (2 * rbits));
+    uint32_t mk = (uint32_t)(gid & (cells_per_tile - 1));
+    size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    int cnt = off0[obase + ((size_t)1 << (2 * level))] - off0[obase];
+    float den = (float)(cnt > 0 ? cnt : 1);
+    int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1), r = 1 << rbits;
+    float *orow = plane + (((size_t)b * r + cy) * r + cx) * C;
+    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < S; ++sp) {
+            float4 u = *reinterpret_cast<const float4 *>(partial + ((size_t)gid * S + sp) * C + c);
+            acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+        }
+        acc.x = __fdiv_rn(acc.x, den); acc.y = __fdiv_rn(acc.y, den);
+        acc.z = __fdiv_rn(acc.z, den); acc.w = __fdiv_rn(acc.w, den);
+        *reinterpret_cast<float4 *>(orow + c) = acc;
+    }
+}
+
+// grid_sample backward, stage 1: per (cell, split) the contributions of its rows to the 3x3 pixels around the
+// cell (slot = (py-cy+1)*3 + (px-cx+1)); every gradient row is read exactly once.
+__global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const float *__restrict__ gout,
+                                                                        const float *__restrict__ pts, int dim,
+                                                                        const int32_t *__restrict__ off0, int nbits,
+                                                                        int level, int C, int lgG, int S,
+                                                                        float *__restrict__ partial) {
+    extern __shared__ float4 red[];                       // [P][G]
+    const int G = 1 << lgG, P = kCellThreads >> lgG;
+    int lane_c = threadIdx.x & (G - 1), slot = threadIdx.x >> lgG;
+    int64_t cellrow = blockIdx.x;
+    int sp = blockIdx.y % S, chunk = blockIdx.y / S;
+    const int rbits = nbits - level, r = 1 << rbits;
+    int b = (int)(cellrow >> (2 * rbits));
+    uint32_t mk = (uint32_t)(cellrow & (((int64_t)1 << (2 * rbits)) - 1));
+    int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+    int lo, hi;
+    split_range(s, e, sp, S, lo, hi);
+    int c = chunk * cell_chunk_channels(C) + lane_c * 4;
+    float4 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        for (int n = lo + slot; n < hi; n += P) {
+            Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+            float4 g = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
+            int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;           // slot column/row of the north-west tap: 0 or 1
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy) {
+                float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
+                    float w = __fmul_rn(wx, wy);
+                    float4 &a = acc[sy * 3 + sx];
+                    a.x = __fadd_rn(a.x, __fmul_rn(w, g.x)); a.y = __fadd_rn(a.y, __fmul_rn(w, g.y));
+                    a.z = __fadd_rn(a.z, __fmul_rn(w, g.z)); a.w = __fadd_rn(a.w, __fmul_rn(w, g.w));
+                }
+            }
+        }
+    }
+    float *pbase = partial + ((size_t)cellrow * S + sp) * 9 * C;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        __syncthreads();
+        red[slot * G + lane_c] = acc[q];
+        __syncthreads();
+        if (slot == 0 && c < C) {
+            float4 t = red[lane_c];
+            for (int k = 1; k < P; ++k) {
+                float4 u = red[k * G + lane_c];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            *reinterpret_cast<float4 *>(pbase + (size_t)q * C + c) = t;
+        }
+    }
+}
+
+// stage 2: pixel (px,py) sums the matching slot of its (up to) 9 neighbouring cells, cells row-major, splits in order.
+__global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const float *__restrict__ partial, int B,
+                                                                     int rbits, int C, int lg, int S,
+                                                                     float *__restrict__ gplane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t gid = t >> lg;
+    const int r = 1 << rbits;
+    if (gid >= (int64_t)B * r * r) return;
+    int b = (int)(gid >> (2 * rbits));
+    int py = (int)((gid >> rbits) & (r - 1)), px = (int)(gid & (r - 1));
+    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cy = max(py - 1, 0); cy <= min(py + 1, r - 1); ++cy)
+            for (int cx = max(px - 1, 0); cx <= min(px + 1, r - 1); ++cx) {
+                size_t cellrow = ((size_t)b << (2 * rbits)) + morton2((uint32_t)cx, (uint32_t)cy);
+                int slot = (py - cy + 1) * 3 + (px - cx + 1);
+                for (int sp = 0; sp < S; ++sp) {
+                    float4 u = *reinterpret_cast<const float4 *>(partial + ((cellrow * S + sp) * 9 + slot) * C + c);
+                    acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+                }
+            }
+        *reinterpret_cast<float4 *>(gplane + (((size_t)b * r + py) * r + px) * C + c) = acc;
+    }
+}
+
 // Generic backward (any r, any point order): float atomics, caller zeroes gplane.
 __global__ __launch_bounds__(kThreads) void sample_bwd_atomic_kernel(const float *__restrict__ gout,
                                                                      const float *__restrict__ pts, int dim,
@@ -317,6 +492,34 @@ static int check_level(const char *what, int B, int nbits, int level, int C) {
     return T2H_OK;
 }
 
+
+// ---- coarse-level strategy: used when a cell holds >= 16 points on average and rows are float4-able ----------
+struct CoarsePlan { bool use; int S; int lgG; int chunks; };
+static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C) {
+    CoarsePlan p{false, 1, 0, 1};
+    if (C % 4 != 0 || N <= 0) return p;
+    int64_t cells = (int64_t)1 << (2 * (nbits - level));
+    if ((int64_t)N < 16 * cells) return p;
+    p.use = true;
+    int64_t want = (4096 + B * cells - 1) / (B * cells);            // aim at >= 4096 workgroups
+    p.S = (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
+    int cc = cell_chunk_channels(C);
+    p.chunks = (C + cc - 1) / cc;
+    p.lgG = group_log2(cc, 4);
+    return p;
+}
+
+T2H_API size_t t2h_segmean_workspace_bytes(int B, int N, int nbits, int level, int C) {
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1) return 0;
+    CoarsePlan p = coarse_plan(B, N, nbits, level, C);
+    if (!p.use) return 0;
+    return ((size_t)B << (2 * (nbits - level))) * p.S * C * sizeof(float);
+}
+
+T2H_API size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C) {
+    return 9 * t2h_segmean_workspace_bytes(B, N, nbits, level, C);
+}
+
 T2H_API int t2h_pool_winner_stride(int C) { return C % 4 == 0 ? C / 4 : C; }
 
 T2H_API int t2h_pool_max_fwd(const float *feat, const int32_t *off0, int B, int nbits, int C, float *pooled,
@@ -353,12 +556,27 @@ T2H_API int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const 
     return check_launch("pool_max_bwd");
 }
 
-T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int nbits, int level, int C,
-                            float *plane_nhwc, t2h_stream_t stream) {
+T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                            float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!feat || !off0 || !plane_nhwc) return fail(T2H_ERR_ARG, "segmean_fwd: null pointer");
     int rc = check_level("segmean_fwd", B, nbits, level, C);
     if (rc) return rc;
     int64_t groups = (int64_t)B << (2 * (nbits - level));
+    CoarsePlan cp = coarse_plan(B, N, nbits, level, C);
+    if (cp.use) {
+        size_t need = t2h_segmean_workspace_bytes(B, N, nbits, level, C);
+        if (!workspace || workspace_bytes < need)
+            return fail(T2H_ERR_WORKSPACE, "segmean_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+        float *partial = static_cast<float *>(workspace);
+        int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
+        hipLaunchKernelGGL(segmean_cells_kernel, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+                           (size_t)P * G * sizeof(float4), as_stream(stream), feat, off0, nbits, level, C, cp.lgG, cp.S,
+                           partial);
+        GroupCfg g = group_cfg<4>(C);
+        hipLaunchKernelGGL(segmean_finalize_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                           partial, off0, B, nbits, level, C, g.lg, cp.S, plane_nhwc);
+        return check_launch("segmean_fwd(coarse)");
+    }
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
           hipLaunchKernelGGL(segmean_fwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
@@ -404,12 +622,28 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
 }
 
 T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
-                           int level, int C, float *gplane_nhwc, t2h_stream_t stream) {
+                           int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
+                           t2h_stream_t stream) {
     if (!gout || !pts || !off0 || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd: null pointer");
     int rc = check_level("sample_bwd", B, nbits, level, C);
     if (rc) return rc;
     if (dim < 2 || N < 0) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
     int64_t groups = (int64_t)B << (2 * (nbits - level));
+    CoarsePlan cp = coarse_plan(B, N, nbits, level, C);
+    if (cp.use) {
+        size_t need = t2h_sample_bwd_workspace_bytes(B, N, nbits, level, C);
+        if (!workspace || workspace_bytes < need)
+            return fail(T2H_ERR_WORKSPACE, "sample_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+        float *partial = static_cast<float *>(workspace);
+        int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
+        hipLaunchKernelGGL(sample_bwd_cells_kernel, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+                           (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
+                           cp.lgG, cp.S, partial);
+        GroupCfg g = group_cfg<4>(C);
+        hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                           partial, B, nbits - level, C, g.lg, cp.S, gplane_nhwc);
+        return check_launch("sample_bwd(coarse)");
+    }
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
           hipLaunchKernelGGL(sample_bwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),

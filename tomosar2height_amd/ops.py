@@ -91,8 +91,10 @@ class _RasteriseMean(torch.autograd.Function):
             raise ValueError(f"rasterise_mean: {n} feature rows for a tile of {tile.n_points} points")
         r = tile.R >> level
         plane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=feat.device)
-        _lib.call("t2h_segmean_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, level, c, _lib.ptr(plane),
-                  _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(), tag=f"t2h_segmean_fwd[C={c},r={r}]")
+        ws_bytes = _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+        ws = _lib.workspace(ws_bytes, feat.device)
+        _lib.call("t2h_segmean_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c,
+                  _lib.ptr(plane), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(), tag=f"t2h_segmean_fwd[C={c},r={r}]")
         ctx.tile, ctx.level, ctx.c = tile, level, c
         return from_nhwc(plane, channels_last)
 
@@ -137,8 +139,10 @@ class _SamplePlane(torch.autograd.Function):
         tile, r, c = ctx.tile, ctx.r, ctx.c
         gout = gout.contiguous()
         gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
+        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c)
+        ws = _lib.workspace(ws_bytes, gout.device)
         _lib.call("t2h_sample_bwd", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
-                  tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.stream(),
+                  tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.ptr(ws), ws_bytes, _lib.stream(),
                   nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel(),
                   tag=f"t2h_sample_bwd[C={c},r={r}]")
         return from_nhwc(gplane, ctx.was_cl), None
