@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 1
+#define T2H_ABI_VERSION 2
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -75,7 +75,9 @@ int t2h_tile_build(const float *cloud, int dim, int B, int N, int nbits, float *
 
 /* ---------------------------------------------------------------------------------------------
  * pool_local (scatter_max + gather)                              pointnet.py:92-99
- * feat/pooled [B*N, C] sorted rows; every point receives the per-channel max over the points of
+ * feat/pooled [B*N, C] sorted rows with row strides ldf/ldp (>= C: the pooled half of the reference's
+ * torch.cat([net, pooled]) at pointnet.py:78 is written straight into its column slice of the next
+ * block's input); every point receives the per-channel max over the points of
  * its finest-level cell.  Ties: the first point in ORIGINAL order wins (pytorch-scatter CPU rule;
  * the stable sort keeps original order inside a cell).
  * winner: [B*N, t2h_pool_winner_stride(C)] bytes; bit j of byte (n, g) is set iff point n is the
@@ -83,10 +85,10 @@ int t2h_tile_build(const float *cloud, int dim, int B, int N, int nbits, float *
  * Backward (gather-backward = per-cell sum of gpooled, routed to the arg-max point):
  * gfeat = (accumulate ? gfeat : 0) + routed gradient. */
 int t2h_pool_winner_stride(int C);
-int t2h_pool_max_fwd(const float *feat, const int32_t *off0, int B, int nbits, int C, float *pooled,
-                     uint8_t *winner, t2h_stream_t stream);
-int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const int32_t *off0, int B, int nbits,
-                     int C, int accumulate, float *gfeat, t2h_stream_t stream);
+int t2h_pool_max_fwd(const float *feat, int ldf, const int32_t *off0, int B, int nbits, int C, float *pooled,
+                     int ldp, uint8_t *winner, t2h_stream_t stream);
+int t2h_pool_max_bwd(const float *gpooled, int ldg, const uint8_t *winner, const int32_t *off0, int B, int nbits,
+                     int C, int accumulate, float *gfeat, int ldo, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * generate_plane_features (scatter_mean into a zero plane)       pointnet.py:101-111; alto.py:76-88,187-197
@@ -121,6 +123,31 @@ int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *
                    t2h_stream_t stream);
 int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
                           float *gplane_nhwc, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-point nn.Linear layers in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32):
+ * pointnet.py:36-40 (fc_pos, fc_c), block/resnet.py:26-31 (fc_0, fc_1, shortcut), alto.py:63-69,164-170
+ * (fc_comm.0, fc_comm.2, fc_c) and their autograd backward.  Rows are points (row stride ld*, so a layer can
+ * read / write a column slice of a wider buffer and the reference's torch.cat at pointnet.py:78 never
+ * materialises); W is torch's [N_out, K_in] row-major weight.  The elementwise neighbours are fused:
+ *
+ *   t2h_linear_fwd    y = [y +] act_out( act_in(x) W^T + bias )        flags: T2H_RELU_IN | T2H_RELU_OUT | T2H_ACCUM
+ *   t2h_linear_dgrad  dx = [dx +] (dy W) * (mask > 0)                   flags: T2H_ACCUM;  mask [M, ldmask] or NULL
+ *                     (mask = the tensor whose ReLU fed this layer / whose ReLU output dy belongs to)
+ *   t2h_linear_wgrad  dw = [dw +] dy^T act_in(x);  db = [db +] colsum(dy)  flags: T2H_RELU_IN | T2H_ACCUM; db may be NULL
+ *                     reduction over the M points is split across workgroups into slabs in `workspace`
+ *                     (t2h_linear_wgrad_workspace_bytes) and summed in split order: deterministic.
+ * K_in that is not a multiple of 4 (fc_pos: K = 3) takes a VALU path (K <= 64 forward, K <= 8 wgrad). */
+#define T2H_RELU_IN 1
+#define T2H_RELU_OUT 2
+#define T2H_ACCUM 4
+int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
+                   int N, int flags, t2h_stream_t stream);
+int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,
+                     const float *mask, int ldmask, int flags, t2h_stream_t stream);
+size_t t2h_linear_wgrad_workspace_bytes(int M, int K, int N);
+int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int K, int N, int flags,
+                     float *dw, float *db, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F.interpolate(size=(H, W), mode='bilinear', align_corners=True) pixel.py:107,110

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -24,8 +24,8 @@ SIGNATURES = {
     "t2h_tile_workspace_bytes": (_sz, [_i, _i, _i]),
     "t2h_tile_build": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "t2h_pool_winner_stride": (_i, [_i]),
-    "t2h_pool_max_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "t2h_pool_max_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_pool_max_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "t2h_pool_max_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "t2h_segmean_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_segmean_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_segmean_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -33,11 +33,17 @@ SIGNATURES = {
     "t2h_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_linear_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "t2h_linear_dgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "t2h_linear_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "t2h_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
+
+RELU_IN, RELU_OUT, ACCUM = 1, 2, 4
 
 _lib = None
 

@@ -1,6 +1,7 @@
 """ResnetBlockFC with the reference's parameters (block/resnet.py:4-54): ``fc_0``, ``fc_1`` and a bias-free
-``shortcut`` when the width changes.  ``forward_split`` takes the two halves of the reference's
-``torch.cat([net, pooled], dim=2)`` input (pointnet.py:78) separately so the concat is never materialised."""
+``shortcut`` when the width changes.  The arithmetic is ``mlp.resblock`` (fp32 MFMA kernels with the ReLUs, biases
+and the residual add fused); inside the PointNet trunk the blocks are driven by ``mlp.point_trunk`` instead, which
+also removes the reference's ``torch.cat([net, pooled], dim=2)`` (pointnet.py:78)."""
 import torch
 import torch.nn as nn
 
@@ -21,9 +22,4 @@ class ResnetBlockFC(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         ws = None if self.shortcut is None else self.shortcut.weight
-        return mlp.resblock(x, None, self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, ws)
-
-    def forward_split(self, xa: torch.Tensor, xb: torch.Tensor) -> torch.Tensor:
-        """Same block applied to ``cat([xa, xb], -1)`` without building the concatenation."""
-        ws = None if self.shortcut is None else self.shortcut.weight
-        return mlp.resblock(xa, xb, self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, ws)
+        return mlp.resblock(x, self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, ws)

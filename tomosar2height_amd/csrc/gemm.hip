@@ -1,0 +1,434 @@
+// Per-point MLP GEMMs in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32): the dense side of the hot
+// path -- nn.Linear forward / input-gradient / weight-gradient for pointnet.py:36-40, resnet.py:26-31 and
+// alto.py:63-69,164-170, with the surrounding elementwise work (bias, ReLU, ReLU masks, residual accumulate,
+// bias gradient) fused into the prologue / epilogue so no separate elementwise launches remain.
+//
+//   linear_fwd    Y[M,N]  = [Y +] act_out( act_in(X)[M,K] . W[N,K]^T + b )                 "NT"
+//   linear_dgrad  dX[M,K] = [dX +] ( dY[M,N] . W[N,K] ) * (mask > 0)                        "NN"
+//   linear_wgrad  dW[N,K] = [dW +] dY[M,N]^T . act_in(X)[M,K];  db[N] = [db +] colsum(dY)   "TN", split over M
+//
+// M = points of the tile batch (1e5..1e6), N/K = feature widths (8..2048).  One workgroup = BM x BN output tile,
+// BK = 16 reduction slab, operands staged global -> registers -> LDS (k-major, rows padded by 4 floats so both the
+// transposing ds_write_b32 and the fragment ds_read_b32 stay (nearly) conflict free), LDS double-buffered with
+// the next slab's global loads in flight during the MFMAs.  MFMA numerics are an fp32 fma chain in k order, so
+// results agree with a scalar fp32 reference to rounding.
+//
+// The weight gradient reduces over M: the grid's z dimension splits M, every split writes its partial tile to a
+// slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
+// deterministic).
+#include "t2h_common.h"
+
+namespace t2h {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 16;
+constexpr int kPad = 4;
+
+enum : int { F_RELU_A = 1, F_RELU_B = 2, F_RELU_OUT = 4, F_ACCUM = 8 };
+
+struct GemmArgs {
+    const float *A, *B;
+    float *C;
+    const float *bias;     // [N] or null
+    const float *mask;     // [M, ldm] or null: result *= (mask > 0)
+    float *colsum;         // TN only: per-split column sums of A (i.e. sum over k of A(m,k)), [splits][M] or null
+    int M, N, K;
+    int lda, ldb, ldc, ldm;
+    int flags;
+    int k_chunk;           // reduction range per blockIdx.z
+    long long slab_stride; // C offset per blockIdx.z (floats)
+};
+
+// A(m,k): A_KC ? A[m*lda + k] : A[k*lda + m];   B(k,n): B_KC ? B[n*ldb + k] : B[k*ldb + n]
+template <int ROWS, int NT, bool KC>
+struct TileLoader {
+    static constexpr int TOTAL = ROWS * BK / 4;             // float4s per tile
+    static constexpr int PER = (TOTAL + NT - 1) / NT;
+    float4 r[PER];
+
+    __device__ inline void load(const float *__restrict__ src, int ld, int row0, int rows, int k0, int kend, int tid,
+                                bool relu) {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            int idx = tid + f * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOTAL % NT == 0 || idx < TOTAL) {
+                if (KC) {
+                    int i = idx / (BK / 4), kc = idx % (BK / 4);
+                    int m = row0 + i, k = k0 + kc * 4;
+                    if (m < rows && k < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)m * ld + k);
+                } else {
+                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
+                    int m = row0 + ic * 4, kk = k0 + k;
+                    if (m < rows && kk < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)kk * ld + m);
+                }
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            r[f] = v;
+        }
+    }
+    __device__ inline void store(float *__restrict__ lds, int tid) const {   // lds: [BK][ROWS + kPad]
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            int idx = tid + f * NT;
+            if (TOTAL % NT == 0 || idx < TOTAL) {
+                if (KC) {
+                    int i = idx / (BK / 4), kc = idx % (BK / 4);
+                    float *p = lds + (kc * 4) * (ROWS + kPad) + i;
+                    p[0] = r[f].x; p[ROWS + kPad] = r[f].y; p[2 * (ROWS + kPad)] = r[f].z; p[3 * (ROWS + kPad)] = r[f].w;
+                } else {
+                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
+                    *reinterpret_cast<float4 *>(lds + k * (ROWS + kPad) + ic * 4) = r[f];
+                }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
+    constexpr int SA = BM + kPad, SB = BN + kPad;
+    static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
+    constexpr int BUF = BK * (SA + SB);            // floats per LDS buffer: A slab then B slab
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+    const bool relu_a = p.flags & F_RELU_A, relu_b = p.flags & F_RELU_B;
+
+    TileLoader<BM, NT, A_KC> la;
+    TileLoader<BN, NT, B_KC> lb;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+
+    // TN bias gradient: every thread's float4 of the (direct-layout) A tile covers fixed columns m0 + ic*4..+3
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_colsum = !A_KC && p.colsum != nullptr && blockIdx.x == 0;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        la.load(p.A, p.lda, m0, p.M, kbeg, kend, tid, relu_a);
+        lb.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid, relu_b);
+        la.store(lds, tid);
+        lb.store(lds + BK * SA, tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (do_colsum) {
+#pragma unroll
+            for (int f = 0; f < TileLoader<BM, NT, A_KC>::PER; ++f) {
+                csum.x += la.r[f].x; csum.y += la.r[f].y; csum.z += la.r[f].z; csum.w += la.r[f].w;
+            }
+        }
+        if (kt + 1 < nk) {
+            la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid, relu_a);
+            lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid, relu_b);
+        }
+        const float *a_base = lds + cur * BUF + (lane >> 5) * SA + wm * (TM * 32) + (lane & 31);
+        const float *b_base = lds + cur * BUF + BK * SA + (lane >> 5) * SB + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_base[kp * 2 * SA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_base[kp * 2 * SB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.store(lds + (cur ^ 1) * BUF, tid);
+            lb.store(lds + (cur ^ 1) * BUF + BK * SA, tid);
+        }
+        __syncthreads();
+    }
+
+    if (do_colsum) {   // fixed-order reduction over the threads that share a column group
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        constexpr int GROUPS = BM / 4;
+        if (tid < GROUPS) {
+            float4 t = red[tid];
+            for (int j = tid + GROUPS; j < NT; j += GROUPS) { t.x += red[j].x; t.y += red[j].y; t.z += red[j].z; t.w += red[j].w; }
+            float *dst = p.colsum + (size_t)blockIdx.z * p.M + m0 + tid * 4;
+            float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (m0 + tid * 4 + q < p.M) dst[q] = tv[q];
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *C = p.C + (size_t)blockIdx.z * p.slab_stride;
+    const bool accum = p.flags & F_ACCUM, relu_out = p.flags & F_RELU_OUT;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int row = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][q] + bv;
+                if (p.mask) v = p.mask[(size_t)row * p.ldm + col] > 0.0f ? v : 0.0f;
+                if (relu_out) v = fmaxf(v, 0.0f);
+                float *dst = C + (size_t)row * p.ldc + col;
+                if (accum) v += *dst;
+                *dst = v;
+            }
+        }
+}
+
+// out[e] = [out[e] +] sum_z slabs[z][e].  16 consecutive elements x 16 split-lanes per workgroup: lane q sums the
+// splits z = q, q+16, ... in order (4 loads in flight), the 16 lane sums are then added in lane order through LDS:
+// a fixed summation tree, so the result is deterministic, and the chain per thread is splits/16 loads deep.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
+                                                          int rows, int cols, int ld_out, int accumulate,
+                                                          float *__restrict__ out) {
+    __shared__ float red[256];
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    long long e = (long long)blockIdx.x * 16 + el;
+    const long long total = (long long)rows * cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < total) {
+        int z = q;
+        for (; z + 48 < splits; z += 64) {
+            s0 += slabs[(size_t)z * stride + e];
+            s1 += slabs[(size_t)(z + 16) * stride + e];
+            s2 += slabs[(size_t)(z + 32) * stride + e];
+            s3 += slabs[(size_t)(z + 48) * stride + e];
+        }
+        for (; z < splits; z += 16) s0 += slabs[(size_t)z * stride + e];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && e < total) {
+        float t = red[el];
+        for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
+        int r = (int)(e / cols), c = (int)(e % cols);
+        float *dst = out + (size_t)r * ld_out + c;
+        *dst = accumulate ? *dst + t : t;
+    }
+}
+
+// ---- small-K fallback (fc_pos: K = 3): plain VALU, memory bound --------------------------------------------
+__global__ __launch_bounds__(256) void linear_smallk_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                               const float *__restrict__ w, const float *__restrict__ bias,
+                                                               int M, int K, int N, int ldy, int flags,
+                                                               float *__restrict__ y) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)M * N) return;
+    int m = (int)(e / N), n = (int)(e % N);
+    float acc = bias ? bias[n] : 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float v = x[(size_t)m * ldx + k];
+        if (flags & F_RELU_A) v = fmaxf(v, 0.0f);
+        acc = fmaf(v, w[(size_t)n * K + k], acc);
+    }
+    if (flags & F_RELU_OUT) acc = fmaxf(acc, 0.0f);
+    float *dst = y + (size_t)m * ldy + n;
+    *dst = (flags & F_ACCUM) ? *dst + acc : acc;
+}
+
+constexpr int kSmallKMax = 8;
+constexpr int kSmallKRows = 512;   // rows per workgroup
+// slab[z][n][k] = sum over the workgroup's rows of dy[m][n] * x[m][k];  colslab[z][n] = sum dy[m][n]
+__global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restrict__ dy, int lddy,
+                                                          const float *__restrict__ x, int ldx, int M, int K, int N,
+                                                          int relu_x, float *__restrict__ slab, float *__restrict__ colslab) {
+    __shared__ float red[256 * (kSmallKMax + 1)];
+    int tid = threadIdx.x;
+    int lanes_n = min(N, 256);                 // threads along n
+    int slots = 256 / lanes_n;                 // parallel row slots
+    int n_local = tid % lanes_n, slot = tid / lanes_n;
+    int m_begin = blockIdx.x * kSmallKRows, m_end = min(M, m_begin + kSmallKRows);
+    for (int nb = 0; nb < N; nb += lanes_n) {
+        int n = nb + n_local;
+        float acc[kSmallKMax + 1];
+#pragma unroll
+        for (int k = 0; k <= kSmallKMax; ++k) acc[k] = 0.0f;
+        if (n < N && slot < slots) {
+            for (int m = m_begin + slot; m < m_end; m += slots) {
+                float g = dy[(size_t)m * lddy + n];
+                acc[kSmallKMax] += g;
+#pragma unroll
+                for (int k = 0; k < kSmallKMax; ++k)
+                    if (k < K) {
+                        float v = x[(size_t)m * ldx + k];
+                        if (relu_x) v = fmaxf(v, 0.0f);
+                        acc[k] = fmaf(g, v, acc[k]);
+                    }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k <= kSmallKMax; ++k) red[k * 256 + tid] = acc[k];
+        __syncthreads();
+        if (slot == 0 && n < N) {
+#pragma unroll
+            for (int k = 0; k <= kSmallKMax; ++k) {
+                if (k < K || k == kSmallKMax) {
+                    float t = 0.0f;
+                    for (int s = 0; s < slots; ++s) t += red[k * 256 + s * lanes_n + n_local];
+                    if (k == kSmallKMax) { if (colslab) colslab[(size_t)blockIdx.x * N + n] = t; }
+                    else slab[((size_t)blockIdx.x * N + n) * K + k] = t;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC>), grid, dim3(64 * WM * WN), 0, s, a);
+    return check_launch(what);
+}
+
+// pick the N tile for row-streaming GEMMs (M huge): 128 when it divides evenly enough, else 64 / 32
+template <bool B_KC>
+static int launch_rows(const GemmArgs &a, hipStream_t s, const char *what) {
+    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC>(a, 1, s, what);
+    if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC>(a, 1, s, what);
+    return launch_gemm<128, 32, 4, 1, true, B_KC>(a, 1, s, what);
+}
+
+static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
+
+}  // namespace t2h
+
+using namespace t2h;
+
+static int map_flags(int f) {
+    int o = 0;
+    if (f & T2H_RELU_IN) o |= F_RELU_A;
+    if (f & T2H_RELU_OUT) o |= F_RELU_OUT;
+    if (f & T2H_ACCUM) o |= F_ACCUM;
+    return o;
+}
+
+T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
+                           int N, int flags, t2h_stream_t stream) {
+    if (!x || !w || !y) return fail(T2H_ERR_ARG, "linear_fwd: null pointer");
+    if (M < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return fail(T2H_ERR_ARG, "linear_fwd: bad shape");
+    if (M == 0) return T2H_OK;
+    hipStream_t s = as_stream(stream);
+    if (K % 4 != 0 || !aligned4(x, ldx) || !aligned4(w, K)) {
+        if (K > 64) return fail(T2H_ERR_ARG, "linear_fwd: K=%d must be a multiple of 4 (16-byte rows)", K);
+        long long total = (long long)M * N;
+        hipLaunchKernelGGL(linear_smallk_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, w, bias,
+                           M, K, N, ldy, map_flags(flags), y);
+        return check_launch("linear_fwd(small K)");
+    }
+    GemmArgs a{};
+    a.A = x; a.lda = ldx; a.B = w; a.ldb = K; a.C = y; a.ldc = ldy; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.flags = map_flags(flags); a.k_chunk = K; a.slab_stride = 0;
+    return launch_rows<true>(a, s, "linear_fwd");
+}
+
+T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,
+                             const float *mask, int ldmask, int flags, t2h_stream_t stream) {
+    if (!dy || !w || !dx) return fail(T2H_ERR_ARG, "linear_dgrad: null pointer");
+    if (M < 0 || K < 1 || N < 1 || lddy < N || lddx < K) return fail(T2H_ERR_ARG, "linear_dgrad: bad shape");
+    if (N % 4 != 0 || K % 4 != 0 || !aligned4(dy, lddy) || !aligned4(w, K))
+        return fail(T2H_ERR_ARG, "linear_dgrad: N=%d, K=%d must be multiples of 4 (16-byte rows)", N, K);
+    if (M == 0) return T2H_OK;
+    GemmArgs a{};
+    // dX[M,K] = dY[M,N] . W[N,K]: reduction over N; B(k=n, j) = W[n*K + j] is j-contiguous (direct layout)
+    a.A = dy; a.lda = lddy; a.B = w; a.ldb = K; a.C = dx; a.ldc = lddx; a.mask = mask; a.ldm = ldmask;
+    a.M = M; a.N = K; a.K = N; a.flags = map_flags(flags & T2H_ACCUM); a.k_chunk = N; a.slab_stride = 0;
+    return launch_rows<false>(a, as_stream(stream), "linear_dgrad");
+}
+
+namespace {
+struct WgradPlan { bool smallk; int bm, bn, tiles, splits, k_chunk; };
+WgradPlan wgrad_plan(int M, int K, int N) {
+    WgradPlan p{};
+    p.smallk = (K % 4 != 0);
+    if (p.smallk) { p.splits = (M + kSmallKRows - 1) / kSmallKRows; return p; }
+    p.bm = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    p.bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
+    p.tiles = ((N + p.bm - 1) / p.bm) * ((K + p.bn - 1) / p.bn);
+    int want = (1024 + p.tiles - 1) / p.tiles;                  // ~1024 workgroups in flight
+    if (want > 512) want = 512;
+    int max_splits = (M + 16 * BK - 1) / (16 * BK);             // at least 16 reduction slabs per workgroup
+    int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits < 1) splits = 1;
+    int chunk = (M + splits - 1) / splits;
+    chunk = (chunk + BK - 1) / BK * BK;
+    p.k_chunk = chunk;
+    p.splits = (M + chunk - 1) / chunk;
+    return p;
+}
+}  // namespace
+
+T2H_API size_t t2h_linear_wgrad_workspace_bytes(int M, int K, int N) {
+    if (M < 1 || K < 1 || N < 1) return 0;
+    WgradPlan p = wgrad_plan(M, K, N);
+    return (size_t)p.splits * ((size_t)N * K + N) * sizeof(float);
+}
+
+T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int K, int N, int flags,
+                             float *dw, float *db, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "linear_wgrad: null pointer");
+    if (M < 1 || K < 1 || N < 1 || lddy < N || ldx < K) return fail(T2H_ERR_ARG, "linear_wgrad: bad shape");
+    size_t need = t2h_linear_wgrad_workspace_bytes(M, K, N);
+    if (!workspace || workspace_bytes < need)
+        return fail(T2H_ERR_WORKSPACE, "linear_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    WgradPlan p = wgrad_plan(M, K, N);
+    float *slab = static_cast<float *>(workspace);
+    float *colslab = slab + (size_t)p.splits * N * K;
+    int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
+    if (p.smallk) {
+        if (K > kSmallKMax) return fail(T2H_ERR_ARG, "linear_wgrad: K=%d must be a multiple of 4 (or <= %d)", K, kSmallKMax);
+        hipLaunchKernelGGL(wgrad_smallk_kernel, dim3(p.splits), dim3(256), 0, s, dy, lddy, x, ldx, M, K, N,
+                           (flags & T2H_RELU_IN) ? 1 : 0, slab, db ? colslab : nullptr);
+    } else {
+        if (N % 4 != 0 || !aligned4(dy, lddy) || !aligned4(x, ldx))
+            return fail(T2H_ERR_ARG, "linear_wgrad: N=%d must be a multiple of 4 (16-byte rows)", N);
+        GemmArgs a{};
+        // dW[N,K] = sum_m dY[m,n] X[m,k]: A(i=n, k=m) = dY[m*lddy + n] (direct), B(k=m, j) = X[m*ldx + j] (direct)
+        a.A = dy; a.lda = lddy; a.B = x; a.ldb = ldx; a.C = slab; a.ldc = K; a.colsum = db ? colslab : nullptr;
+        a.M = N; a.N = K; a.K = M; a.flags = (flags & T2H_RELU_IN) ? F_RELU_B : 0;
+        a.k_chunk = p.k_chunk; a.slab_stride = (long long)N * K;
+        int rc;
+        if (p.bm == 128 && p.bn == 128) rc = launch_gemm<128, 128, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 128 && p.bn == 64) rc = launch_gemm<128, 64, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 128 && p.bn == 32) rc = launch_gemm<128, 32, 4, 1, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 64 && p.bn == 128) rc = launch_gemm<64, 128, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 64 && p.bn == 64) rc = launch_gemm<64, 64, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 64 && p.bn == 32) rc = launch_gemm<64, 32, 2, 1, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 32 && p.bn == 128) rc = launch_gemm<32, 128, 1, 4, false, false>(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 32 && p.bn == 64) rc = launch_gemm<32, 64, 1, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        else rc = launch_gemm<32, 32, 1, 1, false, false>(a, p.splits, s, "linear_wgrad");
+        if (rc) return rc;
+    }
+    long long total = (long long)N * K;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, slab, p.splits,
+                       (long long)N * K, N, K, K, accumulate, dw);
+    if (db)
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, s, colslab, p.splits,
+                           (long long)N, 1, N, N, accumulate, db);
+    return check_launch("linear_wgrad/reduce");
+}

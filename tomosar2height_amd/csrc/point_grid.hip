@@ -38,7 +38,8 @@ static inline unsigned grid_for(int64_t groups, int lg) {
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__restrict__ feat,
                                                                 const int32_t *__restrict__ off0, int64_t ncells, int C,
-                                                                int lg, int wstride, float *__restrict__ pooled,
+                                                                int ldf, int ldp, int lg, int wstride,
+                                                                float *__restrict__ pooled,
                                                                 uint8_t *__restrict__ winner) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t cellid = t >> lg;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__r
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { best[j] = -FLT_MAX; arg[j] = -1; }
         for (int n = s; n < e; ++n) {
-            Vec<VEC> v = Vec<VEC>::load(feat + (size_t)n * C + c);
+            Vec<VEC> v = Vec<VEC>::load(feat + (size_t)n * ldf + c);
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
                 if (v.v[j] > best[j]) { best[j] = v.v[j]; arg[j] = n; }   // strict >: first point wins ties
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__r
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = arg[j] < 0 ? 0.0f : best[j];
         for (int n = s; n < e; ++n) {
-            o.store(pooled + (size_t)n * C + c);
+            o.store(pooled + (size_t)n * ldp + c);
             uint8_t bits = 0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) bits |= (uint8_t)((arg[j] == n) << j);
@@ -74,7 +75,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void pool_max_bwd_kernel(const float *__restrict__ gpooled,
                                                                 const uint8_t *__restrict__ winner,
                                                                 const int32_t *__restrict__ off0, int64_t ncells, int C,
-                                                                int lg, int wstride, int accumulate,
+                                                                int ldg, int ldo, int lg, int wstride, int accumulate,
                                                                 float *__restrict__ gfeat) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t cellid = t >> lg;
@@ -87,20 +88,20 @@ __global__ __launch_bounds__(kThreads) void pool_max_bwd_kernel(const float *__r
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
         for (int n = s; n < e; ++n) {
-            Vec<VEC> g = Vec<VEC>::load(gpooled + (size_t)n * C + c);
+            Vec<VEC> g = Vec<VEC>::load(gpooled + (size_t)n * ldg + c);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) sum[j] += g.v[j];
         }
         for (int n = s; n < e; ++n) {
             uint8_t bits = winner[(size_t)n * wstride + c / VEC];
             Vec<VEC> o;
-            if (accumulate) o = Vec<VEC>::load(gfeat + (size_t)n * C + c);
+            if (accumulate) o = Vec<VEC>::load(gfeat + (size_t)n * ldo + c);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float r = ((bits >> j) & 1) ? sum[j] : 0.0f;
                 o.v[j] = accumulate ? o.v[j] + r : r;
             }
-            o.store(gfeat + (size_t)n * C + c);
+            o.store(gfeat + (size_t)n * ldo + c);
         }
     }
 }
@@ -522,37 +523,47 @@ T2H_API size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level
 
 T2H_API int t2h_pool_winner_stride(int C) { return C % 4 == 0 ? C / 4 : C; }
 
-T2H_API int t2h_pool_max_fwd(const float *feat, const int32_t *off0, int B, int nbits, int C, float *pooled,
-                             uint8_t *winner, t2h_stream_t stream) {
+T2H_API int t2h_pool_max_fwd(const float *feat, int ldf, const int32_t *off0, int B, int nbits, int C, float *pooled,
+                             int ldp, uint8_t *winner, t2h_stream_t stream) {
     if (!feat || !off0 || !pooled || !winner) return fail(T2H_ERR_ARG, "pool_max_fwd: null pointer");
     int rc = check_level("pool_max_fwd", B, nbits, 0, C);
     if (rc) return rc;
+    if (ldf < C || ldp < C) return fail(T2H_ERR_ARG, "pool_max_fwd: row stride smaller than C");
     int64_t ncells = (int64_t)B << (2 * nbits);
     int ws = t2h_pool_winner_stride(C);
-    T2H_DISPATCH_VEC(C,
-        { GroupCfg g = group_cfg<4>(C);
-          hipLaunchKernelGGL(pool_max_fwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             feat, off0, ncells, C, g.lg, ws, pooled, winner); },
-        { GroupCfg g = group_cfg<1>(C);
-          hipLaunchKernelGGL(pool_max_fwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             feat, off0, ncells, C, g.lg, ws, pooled, winner); });
+    bool v4 = C % 4 == 0 && ldf % 4 == 0 && ldp % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)pooled % 16 == 0;
+    if (C % 4 == 0 && !v4) return fail(T2H_ERR_ARG, "pool_max_fwd: rows must be 16-byte aligned when C %% 4 == 0");
+    if (v4) {
+        GroupCfg g = group_cfg<4>(C);
+        hipLaunchKernelGGL(pool_max_fwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream), feat,
+                           off0, ncells, C, ldf, ldp, g.lg, ws, pooled, winner);
+    } else {
+        GroupCfg g = group_cfg<1>(C);
+        hipLaunchKernelGGL(pool_max_fwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream), feat,
+                           off0, ncells, C, ldf, ldp, g.lg, ws, pooled, winner);
+    }
     return check_launch("pool_max_fwd");
 }
 
-T2H_API int t2h_pool_max_bwd(const float *gpooled, const uint8_t *winner, const int32_t *off0, int B, int nbits, int C,
-                             int accumulate, float *gfeat, t2h_stream_t stream) {
+T2H_API int t2h_pool_max_bwd(const float *gpooled, int ldg, const uint8_t *winner, const int32_t *off0, int B, int nbits,
+                             int C, int accumulate, float *gfeat, int ldo, t2h_stream_t stream) {
     if (!gpooled || !winner || !off0 || !gfeat) return fail(T2H_ERR_ARG, "pool_max_bwd: null pointer");
     int rc = check_level("pool_max_bwd", B, nbits, 0, C);
     if (rc) return rc;
+    if (ldg < C || ldo < C) return fail(T2H_ERR_ARG, "pool_max_bwd: row stride smaller than C");
     int64_t ncells = (int64_t)B << (2 * nbits);
     int ws = t2h_pool_winner_stride(C);
-    T2H_DISPATCH_VEC(C,
-        { GroupCfg g = group_cfg<4>(C);
-          hipLaunchKernelGGL(pool_max_bwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gpooled, winner, off0, ncells, C, g.lg, ws, accumulate, gfeat); },
-        { GroupCfg g = group_cfg<1>(C);
-          hipLaunchKernelGGL(pool_max_bwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gpooled, winner, off0, ncells, C, g.lg, ws, accumulate, gfeat); });
+    bool v4 = C % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && (uintptr_t)gpooled % 16 == 0 && (uintptr_t)gfeat % 16 == 0;
+    if (C % 4 == 0 && !v4) return fail(T2H_ERR_ARG, "pool_max_bwd: rows must be 16-byte aligned when C %% 4 == 0");
+    if (v4) {
+        GroupCfg g = group_cfg<4>(C);
+        hipLaunchKernelGGL(pool_max_bwd_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                           gpooled, winner, off0, ncells, C, ldg, ldo, g.lg, ws, accumulate, gfeat);
+    } else {
+        GroupCfg g = group_cfg<1>(C);
+        hipLaunchKernelGGL(pool_max_bwd_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                           gpooled, winner, off0, ncells, C, ldg, ldo, g.lg, ws, accumulate, gfeat);
+    }
     return check_launch("pool_max_bwd");
 }
 

@@ -52,12 +52,7 @@ class LocalPoolPointnet(nn.Module):
 
     def point_features(self, tile: TileIndex) -> torch.Tensor:
         """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max-pools, fc_c."""
-        net = mlp.linear(tile.pts, self.fc_pos.weight, self.fc_pos.bias)
-        net = self.blocks[0](net)
-        for block in self.blocks[1:]:
-            pooled = ops.pool_max(tile, net)
-            net = block.forward_split(net, pooled)
-        return mlp.linear(net, self.fc_c.weight, self.fc_c.bias, relu_in=True)
+        return mlp.point_trunk(tile, tile.pts, self.fc_pos, self.blocks, self.fc_c)
 
     def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
         """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``."""

@@ -1,45 +1,303 @@
-"""Per-point MLP arithmetic (the dense GEMM side of the hot path: pointnet.py:36-40, resnet.py:26-31,
-alto.py:63-69,164-170).  Rows are points in cell-sorted order.
+"""Per-point MLP arithmetic on the MI355X: the dense side of the hot path (reference: pointnet.py:36-40,72-82,
+block/resnet.py:26-54, alto.py:63-69,121-128,164-170,245-253) as explicit forward/backward chains over the
+fp32 MFMA kernels of include/t2h.h (t2h_linear_fwd / dgrad / wgrad) and the strided pool kernels.
 
-Round-1 state: these are plain library GEMMs through PyTorch-ROCm (rocBLAS / hipBLASLt, fp32) on the
-device; the hand-written MFMA kernels of SURVEY.md section 7 step 6 replace them behind this same
-interface.  Nothing here runs on the CPU in the product path: every input comes out of a t2h HIP op.
+Rows are points in the tile's cell-sorted order.  Every elementwise neighbour of a Linear layer is folded into a
+kernel prologue/epilogue (bias, ReLU, ReLU-mask of the backward, residual/shortcut accumulation, bias gradient),
+and the reference's ``torch.cat([net, pooled], dim=2)`` (pointnet.py:78) never materialises: each ResNet block
+writes its output into the left half of the next block's [M, 2h] input buffer and ``pool_max`` writes the right
+half in place.  There is no CPU path here: all tensors must live on the device.
 """
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
+
+from . import _lib
 
 
-def _need_gpu(x: torch.Tensor):
-    if not x.is_cuda:
-        raise RuntimeError("tomosar2height_amd.mlp: expected device tensors; there is no CPU path "
+# ------------------------------------------------------------------------------------------------ kernel calls
+def _rows(t: torch.Tensor, what: str):
+    """A 2-D fp32 device view whose rows are contiguous (row stride >= width): returns (ptr, ld)."""
+    if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{what}: expected a 2-D float32 tensor with unit inner stride, got {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: expected device tensors; tomosar2height_amd has no CPU path "
                            "(the CPU restatement lives in oracle/ for tests only)")
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
+    """y = [y +] act_out(act_in(x) w^T + bias), written in place into ``y`` (may be a column slice)."""
+    (xp, ldx), (yp, ldy) = _rows(x, "linear_fwd x"), _rows(y, "linear_fwd y")
+    m, k = x.shape
+    n = w.shape[0]
+    w = w.contiguous()
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0)
+    _lib.call("t2h_linear_fwd", xp, ldx, w.data_ptr(), bias.data_ptr() if bias is not None else None, yp, ldy, m, k, n,
+              flags, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), tag=f"t2h_linear_fwd[K={k},N={n}]")
+    return y
+
+
+def linear_dgrad_(dy, w, dx, mask=None, accumulate=False):
+    """dx = [dx +] (dy w) * (mask > 0), in place into ``dx``."""
+    (gp, ldg), (dp, ldd) = _rows(dy, "linear_dgrad dy"), _rows(dx, "linear_dgrad dx")
+    m, n = dy.shape
+    k = w.shape[1]
+    w = w.contiguous()
+    mp, ldm = (None, 0) if mask is None else _rows(mask, "linear_dgrad mask")
+    _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm, _lib.ACCUM if accumulate else 0,
+              _lib.stream(), nbytes=4 * (m * k + m * n + n * k), tag=f"t2h_linear_dgrad[N={n},K={k}]")
+    return dx
+
+
+def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
+    """dw = [dw +] dy^T act_in(x); db = [db +] colsum(dy) (db may be None); deterministic split reduction."""
+    (gp, ldg), (xp, ldx) = _rows(dy, "linear_wgrad dy"), _rows(x, "linear_wgrad x")
+    m, n = dy.shape
+    k = x.shape[1]
+    if not dw.is_contiguous() or (db is not None and not db.is_contiguous()):
+        raise ValueError("linear_wgrad: dw / db must be contiguous")
+    if m == 0:
+        if not accumulate:
+            dw.zero_()
+            if db is not None:
+                db.zero_()
+        return
+    ws_bytes = _lib.load().t2h_linear_wgrad_workspace_bytes(m, k, n)
+    ws = _lib.workspace(ws_bytes, dy.device)
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0)
+    _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
+              ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k),
+              tag=f"t2h_linear_wgrad[N={n},K={k}]")
+
+
+def _wgrad(dy, x, w, bias, relu_in=False):
+    if w.shape[0] % 4 != 0:
+        # odd output widths (the 1-channel head of the non-default per-pixel FC decoder, pixel.py:51) are off the
+        # per-point hot path: library GEMM on the device
+        xa = torch.relu(x) if relu_in else x
+        return dy.t() @ xa, (dy.sum(0) if bias is not None else None)
+    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+    db = torch.empty_like(bias) if bias is not None else None
+    linear_wgrad_(dy, x, dw, db, relu_in=relu_in)
+    return dw, db
+
+
+def _pool_fwd_(tile, feat, pooled, winner):
+    (fp, ldf), (pp, ldp) = _rows(feat, "pool feat"), _rows(pooled, "pool out")
+    c = feat.shape[1]
+    _lib.call("t2h_pool_max_fwd", fp, ldf, _lib.ptr(tile.off0), tile.B, tile.nbits, c, pp, ldp, _lib.ptr(winner),
+              _lib.stream(), nbytes=8 * c * tile.n_points + 4 * tile.n_points)
+
+
+def _pool_bwd_(tile, gpooled, winner, gfeat, accumulate):
+    (gp, ldg), (op, ldo) = _rows(gpooled, "pool gpooled"), _rows(gfeat, "pool gfeat")
+    c = gpooled.shape[1]
+    _lib.call("t2h_pool_max_bwd", gp, ldg, _lib.ptr(winner), _lib.ptr(tile.off0), tile.B, tile.nbits, c,
+              1 if accumulate else 0, op, ldo, _lib.stream(), nbytes=8 * c * tile.n_points + 4 * tile.n_points)
+
+
+def _empty(rows, cols, like):
+    return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------ nn.Linear
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu_in: bool):
+        y = _empty(x.shape[0], w.shape[0], x)
+        linear_fwd_(x, w, bias, y, relu_in=relu_in)
+        ctx.save_for_backward(x, w, bias)
+        ctx.relu_in = relu_in
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, bias = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0:
+                dx = linear_dgrad_(gy, w, torch.empty_like(x), mask=x if ctx.relu_in else None)
+            else:   # odd widths never occur on the network's hot path; keep the generic seam correct
+                dx = gy @ w
+                if ctx.relu_in:
+                    dx = dx * (x > 0)
+        dw, db = _wgrad(gy, x, w, bias, relu_in=ctx.relu_in)
+        return dx, dw, db, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
-    _need_gpu(x)
-    return F.linear(F.relu(x) if relu_in else x, weight, bias)
+    """``F.linear(relu(x) if relu_in else x, weight, bias)`` over the last dim (any leading dims)."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]).contiguous(), weight, bias, relu_in)
+    return y.reshape(*lead, weight.shape[0])
 
 
-def resblock(xa: torch.Tensor, xb: Optional[torch.Tensor], w0, b0, w1, b1, ws) -> torch.Tensor:
-    """block/resnet.py:36-54 on ``x = [xa | xb]``: ``shortcut(x) + fc_1(relu(fc_0(relu(x))))``."""
-    _need_gpu(xa)
-    if xb is None:
-        h = F.linear(F.relu(xa), w0, b0)
-        xs = xa if ws is None else F.linear(xa, ws)
+# ------------------------------------------------------------------------------------------------ ResnetBlockFC
+def _resblock_fwd(x, w0, b0, w1, b1, ws, out):
+    """out (a [M, Cout] view) = shortcut(x) + fc_1(relu(fc_0(relu(x)))); returns Hr = relu(fc_0(relu(x)))."""
+    hr = _empty(x.shape[0], w0.shape[0], x)
+    linear_fwd_(x, w0, b0, hr, relu_in=True, relu_out=True)
+    if ws is not None:
+        linear_fwd_(x, ws, None, out)
     else:
-        ca = xa.shape[-1]
-        h = F.linear(F.relu(xa), w0[:, :ca], b0) + F.linear(F.relu(xb), w0[:, ca:])
-        xs = F.linear(xa, ws[:, :ca]) + F.linear(xb, ws[:, ca:])
-    return xs + F.linear(F.relu(h), w1, b1)
+        out.copy_(x)
+    linear_fwd_(hr, w1, b1, out, accumulate=True)
+    return hr
 
 
-def comm_mlp(sampled: torch.Tensor, w_a, b_a, w_b, b_b, c_last: Optional[torch.Tensor], w_c, b_c) -> torch.Tensor:
-    """ALTO point update (alto.py:121-128, 245-253): ``fc_comm(sampled) + fc_c(c_last)`` with
-    ``fc_comm = Linear(C,2C) -> ReLU -> Linear(2C,C)``."""
-    _need_gpu(sampled)
-    c = F.linear(F.relu(F.linear(sampled, w_a, b_a)), w_b, b_b)
-    if c_last is not None:
-        c = c + F.linear(c_last, w_c, b_c)
-    return c
+def _resblock_bwd(gy, x, hr, w0, b0, w1, b1, ws, need_dx=True):
+    """Gradients of one block; returns (dx [M,Cin] or None, dw0, db0, dw1, db1, dws)."""
+    dw1, db1 = _wgrad(gy, hr, w1, b1)
+    dhr = linear_dgrad_(gy, w1, torch.empty_like(hr), mask=hr)        # through fc_1 and the ReLU in front of it
+    dw0, db0 = _wgrad(dhr, x, w0, b0, relu_in=True)
+    dws = _wgrad(gy, x, ws, None)[0] if ws is not None else None
+    dx = None
+    if need_dx:
+        dx = _empty(x.shape[0], x.shape[1], x)
+        if ws is not None:
+            linear_dgrad_(gy, ws, dx)
+        else:
+            dx.copy_(gy)
+        linear_dgrad_(dhr, w0, dx, mask=x, accumulate=True)           # through fc_0 and relu(x)
+    return dx, dw0, db0, dw1, db1, dws
+
+
+class _ResBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, ws):
+        out = _empty(x.shape[0], w1.shape[0], x)
+        hr = _resblock_fwd(x, w0, b0, w1, b1, ws, out)
+        ctx.save_for_backward(x, hr, w0, b0, w1, b1, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, hr, w0, b0, w1, b1, ws = ctx.saved_tensors
+        dx, dw0, db0, dw1, db1, dws = _resblock_bwd(gy.contiguous(), x, hr, w0, b0, w1, b1, ws, ctx.needs_input_grad[0])
+        return dx, dw0, db0, dw1, db1, dws
+
+
+def resblock(x: torch.Tensor, w0, b0, w1, b1, ws) -> torch.Tensor:
+    """block/resnet.py:36-54 over the last dim."""
+    lead = x.shape[:-1]
+    y = _ResBlock.apply(x.reshape(-1, x.shape[-1]).contiguous(), w0, b0, w1, b1, ws)
+    return y.reshape(*lead, w1.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------ ALTO point update
+class _CommMLP(torch.autograd.Function):
+    """c = fc_comm.2(relu(fc_comm.0(sampled))) + fc_c(c_last)   (alto.py:121-128, 245-253)."""
+
+    @staticmethod
+    def forward(ctx, sampled, c_last, wa, ba, wb, bb, wc, bc):
+        m = sampled.shape[0]
+        h = _empty(m, wa.shape[0], sampled)
+        linear_fwd_(sampled, wa, ba, h, relu_out=True)
+        out = _empty(m, wb.shape[0], sampled)
+        linear_fwd_(h, wb, bb, out)
+        if c_last is not None:
+            linear_fwd_(c_last, wc, bc, out, accumulate=True)
+        ctx.has_last = c_last is not None
+        ctx.save_for_backward(sampled, c_last, h, wa, ba, wb, bb, wc, bc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sampled, c_last, h, wa, ba, wb, bb, wc, bc = ctx.saved_tensors
+        g = g.contiguous()
+        dwb, dbb = _wgrad(g, h, wb, bb)
+        dh = linear_dgrad_(g, wb, torch.empty_like(h), mask=h)
+        dwa, dba = _wgrad(dh, sampled, wa, ba)
+        ds = linear_dgrad_(dh, wa, torch.empty_like(sampled)) if ctx.needs_input_grad[0] else None
+        dlast = dwc = dbc = None
+        if ctx.has_last:
+            dwc, dbc = _wgrad(g, c_last, wc, bc)
+            if ctx.needs_input_grad[1]:
+                dlast = linear_dgrad_(g, wc, torch.empty_like(c_last))
+        return ds, dlast, dwa, dba, dwb, dbb, dwc, dbc
+
+
+def comm_mlp(sampled, w_a, b_a, w_b, b_b, c_last, w_c, b_c) -> torch.Tensor:
+    return _CommMLP.apply(sampled.contiguous(), None if c_last is None else c_last.contiguous(),
+                          w_a, b_a, w_b, b_b, w_c, b_c)
+
+
+# ------------------------------------------------------------------------------------------------ PointNet trunk
+class _PointTrunk(torch.autograd.Function):
+    """pointnet.py:72-82 on sorted rows: fc_pos -> block0 -> 4 x {pool_max, block} -> relu -> fc_c.
+
+    Buffers: ``cat[i]`` is the [M, 2h] input of block i (cat[0] = fc_pos output); block i writes its [M, h]
+    output into cat[i+1][:, :h] and the pool writes cat[i+1][:, h:].  Weights arrive flattened:
+    (w_pos, b_pos, [w0, b0, w1, b1, ws] * n_blocks, w_c, b_c)."""
+
+    @staticmethod
+    def forward(ctx, tile, pts, *params):
+        n_blocks = (len(params) - 4) // 5
+        w_pos, b_pos = params[0], params[1]
+        blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(n_blocks)]
+        w_c, b_c = params[-2], params[-1]
+        m = pts.shape[0]
+        h = blocks[0][2].shape[0]
+        cats, hrs, winners = [], [], []
+        cat0 = _empty(m, w_pos.shape[0], pts)
+        linear_fwd_(pts, w_pos, b_pos, cat0)                                   # pointnet.py:72
+        cats.append(cat0)
+        for i, (w0, b0, w1, b1, ws) in enumerate(blocks):
+            last = i == n_blocks - 1
+            nxt = _empty(m, h, pts) if last else _empty(m, 2 * h, pts)
+            hrs.append(_resblock_fwd(cats[i], w0, b0, w1, b1, ws, nxt[:, :h]))     # pointnet.py:73,79
+            if not last:
+                win = torch.empty(m, _lib.load().t2h_pool_winner_stride(h), dtype=torch.uint8, device=pts.device)
+                _pool_fwd_(tile, nxt[:, :h], nxt[:, h:], win)                      # pointnet.py:77-78
+                winners.append(win)
+            cats.append(nxt)
+        out = _empty(m, w_c.shape[0], pts)
+        linear_fwd_(cats[-1], w_c, b_c, out, relu_in=True)                          # pointnet.py:81-82
+        ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
+        ctx.save_for_backward(pts, *params, *cats, *hrs, *winners)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        nb, h, tile = ctx.n_blocks, ctx.h, ctx.tile
+        saved = ctx.saved_tensors
+        pts = saved[0]
+        n_params = 4 + 5 * nb
+        params = saved[1:1 + n_params]
+        cats = saved[1 + n_params: 2 + n_params + nb]          # nb + 1 buffers
+        hrs = saved[2 + n_params + nb: 2 + n_params + 2 * nb]
+        winners = saved[2 + n_params + 2 * nb:]
+        w_pos, b_pos = params[0], params[1]
+        blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
+        w_c, b_c = params[-2], params[-1]
+
+        g_out = g_out.contiguous()
+        dw_c, db_c = _wgrad(g_out, cats[-1], w_c, b_c, relu_in=True)
+        g = linear_dgrad_(g_out, w_c, torch.empty_like(cats[-1]), mask=cats[-1])     # grad of the last block output
+        grads = [None] * n_params
+        grads[-2], grads[-1] = dw_c, db_c
+        for i in range(nb - 1, -1, -1):
+            w0, b0, w1, b1, ws = blocks[i]
+            dx, dw0, db0, dw1, db1, dws = _resblock_bwd(g, cats[i], hrs[i], w0, b0, w1, b1, ws)
+            grads[2 + 5 * i: 7 + 5 * i] = [dw0, db0, dw1, db1, dws]
+            if i > 0:
+                # dx = [d net | d pooled]: fold the pool's gradient into the left half, which is then d(net_i)
+                _pool_bwd_(tile, dx[:, h:], winners[i - 1], dx[:, :h], accumulate=True)
+                g = dx[:, :h]
+            else:
+                g = dx
+        grads[0], grads[1] = _wgrad(g, pts, w_pos, b_pos)
+        return (None, None, *grads)
+
+
+def point_trunk(tile, pts, fc_pos, blocks, fc_c) -> torch.Tensor:
+    params = [fc_pos.weight, fc_pos.bias]
+    for b in blocks:
+        if b.shortcut is None:
+            raise NotImplementedError("trunk blocks always change width (2h -> h) and so carry a shortcut")
+        params += [b.fc_0.weight, b.fc_0.bias, b.fc_1.weight, b.fc_1.bias, b.shortcut.weight]
+    params += [fc_c.weight, fc_c.bias]
+    return _PointTrunk.apply(tile, pts, *params)

@@ -58,7 +58,7 @@ class _PoolMax(torch.autograd.Function):
             raise ValueError(f"pool_max: {n} feature rows for a tile of {tile.n_points} points")
         pooled = torch.empty_like(feat)
         winner = torch.empty(n, _lib.load().t2h_pool_winner_stride(c), dtype=torch.uint8, device=feat.device)
-        _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled),
+        _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled), c,
                   _lib.ptr(winner), _lib.stream(), nbytes=8 * c * n + 4 * n)
         ctx.tile, ctx.c = tile, c
         ctx.save_for_backward(winner)
@@ -70,8 +70,9 @@ class _PoolMax(torch.autograd.Function):
         tile = ctx.tile
         gpooled = gpooled.contiguous()
         gfeat = torch.empty_like(gpooled)
-        _lib.call("t2h_pool_max_bwd", _lib.ptr(gpooled), _lib.ptr(winner), _lib.ptr(tile.off0), tile.B, tile.nbits,
-                  ctx.c, 0, _lib.ptr(gfeat), _lib.stream(), nbytes=8 * ctx.c * tile.n_points + 4 * tile.n_points)
+        _lib.call("t2h_pool_max_bwd", _lib.ptr(gpooled), ctx.c, _lib.ptr(winner), _lib.ptr(tile.off0), tile.B,
+                  tile.nbits, ctx.c, 0, _lib.ptr(gfeat), ctx.c, _lib.stream(),
+                  nbytes=8 * ctx.c * tile.n_points + 4 * tile.n_points)
         return gfeat, None
 
 
