@@ -37,12 +37,23 @@ def parse():
     ap.add_argument("--points", type=int, default=131072, help="points per tile (SURVEY.md 8d default)")
     ap.add_argument("--optimize-every", type=int, default=64, help="tiles per optimizer step (reference: 64)")
     ap.add_argument("--tile-pool", type=int, default=4, help="distinct resident tiles cycled per rank")
-    ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--channels-last", type=int, default=1, help="grid side in NHWC (same numerics, no layout copies)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     return ap.parse_args()
+
+
+def pmc_traffic():
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under
+    profiles/ by profiles/collect_pmc.py for the N = 131072 workload; {} if not collected."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("bytes_per_launch", {})
+    except (OSError, ValueError):
+        return {}
 
 
 def cpu_baseline(points: int, threads: int):
@@ -152,16 +163,32 @@ def main():
             kernels = []
             for name, d in sorted(timeline.summary().items(), key=lambda kv: -kv[1]["ms"]):
                 avg_us = 1e3 * d["ms"] / d["calls"]
-                per_launch = d["bytes"] / d["calls"]
-                gbs = per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+                per_launch_b, per_launch_f = d["bytes"] / d["calls"], d["flops"] / d["calls"]
+                gbs = per_launch_b / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+                tfs = per_launch_f / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+                # roofline that bounds the launch: arithmetic intensity vs the machine balance (157.3 TF / 8 TB/s)
+                mfma_bound = per_launch_f > 0 and per_launch_f / max(per_launch_b, 1) > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
                 kernels.append({"kernel": name, "launches_per_step": round(d["calls"] / args.steps, 2),
-                                "avg_us": round(avg_us, 2), "bytes_per_launch": int(per_launch),
-                                "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                                "avg_us": round(avg_us, 2), "bytes_per_launch": int(per_launch_b),
+                                "flops_per_launch": int(per_launch_f), "GBps": round(gbs, 1), "TFLOPs": round(tfs, 2),
+                                "bound": "mfma" if mfma_bound else "hbm",
+                                "frac": round(tfs / MFMA_F32_PEAK_TFLOPS if mfma_bound else gbs / HBM_PEAK_GBS, 4),
                                 "ms_per_step": round(d["ms"] / args.steps, 4)})
+
+            def roof(k):
+                traffic = pmc_traffic().get(k["kernel"]) if args.points == 131072 else None
+                if k["bound"] == "mfma":
+                    return {"kernel": k["kernel"], "bound": "mfma", "achieved": k["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"]}
+                return {"kernel": k["kernel"], "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"]}
+
             if kernels:
-                top = kernels[0]
-                out["roofline"] = {"kernel": top["kernel"], "bound": "hbm", "achieved": top["GBps"],
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": None}
+                out["roofline"] = roof(kernels[0])                       # the launch with the largest time share
+                named = {k["kernel"]: k for k in kernels}
+                # the scatter-reduce kernels north_star names (pool_local and the largest mean)
+                out["roofline_scatter_reduce"] = [roof(named[n]) for n in
+                                                  ("t2h_segmean_fwd[C=512,r=32]", "t2h_pool_max_fwd") if n in named]
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
                 out["kernels"] = kernels
         if world == 1 and not args.skip_cpu_baseline:

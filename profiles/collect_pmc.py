@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes over profiles/pmc_probe.py (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_traffic.json.
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-byte
+streaming stores.  Per launch = mean over the probe's repetitions; ops made of two kernels are summed."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launch of the op
+    "t2h_linear_fwd[K=512,N=1024]": ["gemm_kernel<128, 128, 2, 2, true, true"],
+    "t2h_linear_dgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, true, false"],
+    "t2h_linear_wgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, false, false", "reduce_slabs_kernel"],
+    "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],
+    "t2h_pool_max_fwd": ["pool_max_fwd_kernel"],
+    "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
+    "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_kernel", "sample_bwd_gather9_kernel"],
+}
+
+
+def read_counter(folder, counter):
+    sums, counts = collections.defaultdict(float), collections.defaultdict(int)
+    for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] != counter:
+                continue
+            sums[row["Kernel_Name"]] += float(row["Counter_Value"])
+            counts[row["Kernel_Name"]] += 1
+    return {k: sums[k] / counts[k] for k in sums}, counts
+
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    fetch, nf = read_counter(fetch_dir, "FETCH_SIZE")
+    write, nw = read_counter(write_dir, "WRITE_SIZE")
+    out, detail = {}, {}
+    for tag, parts in OPS.items():
+        total, rows = 0.0, []
+        for sub in parts:
+            kf = [k for k in fetch if sub in k]
+            kw = [k for k in write if sub in k]
+            if not kf or not kw:
+                total = None
+                break
+            f_kib = sum(fetch[k] for k in kf) / len(kf) if len(kf) == 1 else max(fetch[k] for k in kf)
+            w_kib = sum(write[k] for k in kw) / len(kw) if len(kw) == 1 else max(write[k] for k in kw)
+            rows.append({"kernel": sub, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib})
+            total += (2.0 * f_kib + w_kib) * 1024.0
+        if total is not None:
+            out[tag] = int(total)
+            detail[tag] = rows
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "pmc_traffic.json"), "w") as f:
+        json.dump({"workload": "BASELINE.json configs[1], N=131072, profiles/pmc_probe.py",
+                   "formula": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts half of wide reads)",
+                   "bytes_per_launch": out, "detail": detail}, f, indent=1)
+    for k, v in out.items():
+        print(f"{k:<36s} {v / 1e6:10.1f} MB / launch")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Launch the roofline-relevant t2h kernels in isolation (BASELINE.json configs[1] shapes, N = 131072) so that a
+rocprofv3 --pmc pass can attribute HBM traffic per launch:
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_fetch -- python3 profiles/pmc_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_write -- python3 profiles/pmc_probe.py
+    python profiles/collect_pmc.py out_fetch out_write      # -> profiles/pmc_traffic.json
+
+Each op runs REPS times; inputs are > 256 MiB apart in time?  No: inputs stay resident, so re-reads that hit the
+256 MiB Infinity Cache are still counted by the fabric-side counters (MI355X_MICROARCH.md, HBM section)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tomosar2height_amd import mlp, ops                      # noqa: E402
+from tomosar2height_amd.synthetic import berlin_tile          # noqa: E402
+from tomosar2height_amd.tile import TileIndex                 # noqa: E402
+
+REPS = 3
+dev = torch.device("cuda:0")
+tile = TileIndex(berlin_tile(0)["inputs"].to(dev), 256)
+M = tile.n_points
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def rnd(*shape):
+    return torch.randn(*shape, device=dev, generator=g)
+
+
+x512, x1024, x32 = rnd(M, 512), rnd(M, 1024), rnd(M, 32)
+w = rnd(1024, 512) / 22.0
+b = rnd(1024)
+y = torch.empty(M, 1024, device=dev)
+dw, db = torch.empty(1024, 512, device=dev), torch.empty(1024, device=dev)
+torch.cuda.synchronize()
+for _ in range(REPS):
+    mlp.linear_fwd_(x512, w, b, y, relu_out=True)             # gemm_kernel<128,128,2,2,true,true>
+for _ in range(REPS):
+    mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_kernel<128,128,2,2,true,false>
+for _ in range(REPS):
+    mlp.linear_wgrad_(x1024, x512, dw, db)                    # gemm_kernel<128,128,2,2,false,false> + reduce_slabs
+for _ in range(REPS):
+    ops.rasterise_mean(tile, x512, 32, channels_last=True)    # segmean_cells_kernel + segmean_finalize_kernel
+for _ in range(REPS):
+    ops.pool_max(tile, x32)                                   # pool_max_fwd_kernel<4>
+plane = rnd(1, 512, 32, 32).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+for _ in range(REPS):
+    out = ops.sample_plane(tile, plane)                       # sample_fwd_kernel<4>
+    out.backward(x512)                                        # sample_bwd_cells_kernel + sample_bwd_gather9_kernel
+torch.cuda.synchronize()
+print("pmc_probe done")

@@ -87,7 +87,7 @@ class KernelTimeline:
     after the call.  ``summary()`` must be called after a device synchronise."""
 
     def __init__(self):
-        self.records = []          # (name, algorithmic_bytes, start_event, end_event)
+        self.records = []          # (name, algorithmic_bytes, flops, start_event, end_event)
 
     def __enter__(self):
         global _timeline
@@ -100,20 +100,22 @@ class KernelTimeline:
 
     def summary(self):
         out = {}
-        for name, nbytes, s, e in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0})
+        for name, nbytes, flops, s, e in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0})
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["bytes"] += nbytes
+            d["flops"] += flops
         return out
 
 
 _timeline = None
 
 
-def call(name: str, *args, nbytes: int = 0, tag: str = None):
-    """Invoke ``name`` from the library, raising on a non-zero return code.  ``nbytes`` = the ALGORITHMIC HBM
-    bytes of this launch, only used when a KernelTimeline is active."""
+def call(name: str, *args, nbytes: int = 0, flops: int = 0, tag: str = None):
+    """Invoke ``name`` from the library, raising on a non-zero return code.  ``nbytes`` / ``flops`` = the
+    ALGORITHMIC HBM bytes / floating-point operations of this launch, only used when a
+    KernelTimeline is active."""
     fn = getattr(load(), name)
     tl = _timeline
     if tl is None:
@@ -123,7 +125,7 @@ def call(name: str, *args, nbytes: int = 0, tag: str = None):
         s.record()
         rc = fn(*args)
         e.record()
-        tl.records.append((tag or name, nbytes, s, e))
+        tl.records.append((tag or name, nbytes, flops, s, e))
     check(rc, name)
 
 

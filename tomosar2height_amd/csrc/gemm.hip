@@ -16,14 +16,16 @@
 // The weight gradient reduces over M: the grid's z dimension splits M, every split writes its partial tile to a
 // slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
 // deterministic).
+#include <stdlib.h>
+
 #include "t2h_common.h"
 
 namespace t2h {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16;
 constexpr int kPad = 4;
+constexpr int kMinBK = 16;
 
 enum : int { F_RELU_A = 1, F_RELU_B = 2, F_RELU_OUT = 4, F_ACCUM = 8 };
 
@@ -41,7 +43,7 @@ struct GemmArgs {
 };
 
 // A(m,k): A_KC ? A[m*lda + k] : A[k*lda + m];   B(k,n): B_KC ? B[n*ldb + k] : B[k*ldb + n]
-template <int ROWS, int NT, bool KC>
+template <int ROWS, int NT, bool KC, int BK>
 struct TileLoader {
     static constexpr int TOTAL = ROWS * BK / 4;             // float4s per tile
     static constexpr int PER = (TOTAL + NT - 1) / NT;
@@ -86,24 +88,34 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int SA = BM + kPad, SB = BN + kPad;
     static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
+    constexpr int LDS_FLOATS = 2 * BK * (SA + SB) > 4 * NT ? 2 * BK * (SA + SB) : 4 * NT;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     constexpr int BUF = BK * (SA + SB);            // floats per LDS buffer: A slab then B slab
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (XCD) {
+        // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give every XCD a contiguous run of
+        // tiles so the n-tiles that re-read one A row-tile hit the same L2.  Placement only affects speed.
+        const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned q = nb / 8, r = nb % 8, x = b % 8, i = b / 8;
+        const unsigned t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        tile_m = t / gridDim.x; tile_n = t % gridDim.x;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const bool relu_a = p.flags & F_RELU_A, relu_b = p.flags & F_RELU_B;
 
-    TileLoader<BM, NT, A_KC> la;
-    TileLoader<BN, NT, B_KC> lb;
+    TileLoader<BM, NT, A_KC, BK> la;
+    TileLoader<BN, NT, B_KC, BK> lb;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p
         const int cur = kt & 1;
         if (do_colsum) {
 #pragma unroll
-            for (int f = 0; f < TileLoader<BM, NT, A_KC>::PER; ++f) {
+            for (int f = 0; f < TileLoader<BM, NT, A_KC, BK>::PER; ++f) {
                 csum.x += la.r[f].x; csum.y += la.r[f].y; csum.z += la.r[f].z; csum.w += la.r[f].w;
             }
         }
@@ -297,18 +309,33 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = false>
 static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC>), grid, dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD>), grid, dim3(64 * WM * WN), 0, s, a);
     return check_launch(what);
+}
+
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("T2H_GEMM_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 // pick the N tile for row-streaming GEMMs (M huge): 128 when it divides evenly enough, else 64 / 32
 template <bool B_KC>
 static int launch_rows(const GemmArgs &a, hipStream_t s, const char *what) {
-    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC>(a, 1, s, what);
+    if (a.N > 64) {
+        switch (gemm_variant()) {
+            case 1: return launch_gemm<128, 128, 2, 2, true, B_KC, 32, false>(a, 1, s, what);
+            case 2: return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true>(a, 1, s, what);
+            case 3: return launch_gemm<256, 128, 2, 2, true, B_KC, 16, false>(a, 1, s, what);
+            case 4: return launch_gemm<256, 128, 2, 2, true, B_KC, 16, true>(a, 1, s, what);
+            case 5: return launch_gemm<128, 128, 2, 2, true, B_KC, 32, true>(a, 1, s, what);
+            default: return launch_gemm<128, 128, 2, 2, true, B_KC>(a, 1, s, what);
+        }
+    }
     if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC>(a, 1, s, what);
     return launch_gemm<128, 32, 4, 1, true, B_KC>(a, 1, s, what);
 }
@@ -371,11 +398,11 @@ WgradPlan wgrad_plan(int M, int K, int N) {
     p.tiles = ((N + p.bm - 1) / p.bm) * ((K + p.bn - 1) / p.bn);
     int want = (1024 + p.tiles - 1) / p.tiles;                  // ~1024 workgroups in flight
     if (want > 512) want = 512;
-    int max_splits = (M + 16 * BK - 1) / (16 * BK);             // at least 16 reduction slabs per workgroup
+    int max_splits = (M + 16 * kMinBK - 1) / (16 * kMinBK);     // at least 16 reduction slabs per workgroup
     int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits < 1) splits = 1;
     int chunk = (M + splits - 1) / splits;
-    chunk = (chunk + BK - 1) / BK * BK;
+    chunk = (chunk + 31) / 32 * 32;
     p.k_chunk = chunk;
     p.splits = (M + chunk - 1) / chunk;
     return p;

@@ -35,7 +35,8 @@ def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
     w = w.contiguous()
     flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0)
     _lib.call("t2h_linear_fwd", xp, ldx, w.data_ptr(), bias.data_ptr() if bias is not None else None, yp, ldy, m, k, n,
-              flags, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), tag=f"t2h_linear_fwd[K={k},N={n}]")
+              flags, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
+              tag=f"t2h_linear_fwd[K={k},N={n}]")
     return y
 
 
@@ -47,7 +48,8 @@ def linear_dgrad_(dy, w, dx, mask=None, accumulate=False):
     w = w.contiguous()
     mp, ldm = (None, 0) if mask is None else _rows(mask, "linear_dgrad mask")
     _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm, _lib.ACCUM if accumulate else 0,
-              _lib.stream(), nbytes=4 * (m * k + m * n + n * k), tag=f"t2h_linear_dgrad[N={n},K={k}]")
+              _lib.stream(), nbytes=4 * (m * k + m * n + n * k + (m * k if mask is not None else 0)),
+              flops=2 * m * k * n, tag=f"t2h_linear_dgrad[N={n},K={k}]")
     return dx
 
 
@@ -68,7 +70,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
     ws = _lib.workspace(ws_bytes, dy.device)
     flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0)
     _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
-              ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k),
+              ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
               tag=f"t2h_linear_wgrad[N={n},K={k}]")
 
 
