@@ -88,13 +88,14 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int SA = BM + kPad, SB = BN + kPad;
     static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
-    constexpr int LDS_FLOATS = 2 * BK * (SA + SB) > 4 * NT ? 2 * BK * (SA + SB) : 4 * NT;
+    constexpr int LDS_MIN = (NT / 64) * 32 * 36 > 4 * NT ? (NT / 64) * 32 * 36 : 4 * NT;   // epilogue patches / colsum
+    constexpr int LDS_FLOATS = 2 * BK * (SA + SB) > LDS_MIN ? 2 * BK * (SA + SB) : LDS_MIN;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     constexpr int BUF = BK * (SA + SB);            // floats per LDS buffer: A slab then B slab
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p
                 csum.x += la.r[f].x; csum.y += la.r[f].y; csum.z += la.r[f].z; csum.w += la.r[f].w;
             }
         }
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk && ABLATE != 1) {
             la.load(p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid, relu_a);
             lb.load(p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid, relu_b);
         }
@@ -166,8 +167,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    if (ABLATE == 2) { asm volatile("" ::"v"(a[i]), "v"(b[j])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
         }
         if (kt + 1 < nk) {
             la.store(lds + (cur ^ 1) * BUF, tid);
@@ -190,28 +193,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(GemmArgs p
             for (int q = 0; q < 4; ++q)
                 if (m0 + tid * 4 + q < p.M) dst[q] = tv[q];
         }
+        __syncthreads();       // the epilogue reuses this LDS
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Each wave transposes one 32x32 tile at a time through its private LDS patch (32 x 36 floats) so that global
+    // traffic (store, mask load, accumulate load) is 16 bytes per lane: 4 vector-memory instructions per tile
+    // instead of 16 dword ones.
     float *C = p.C + (size_t)split * p.slab_stride;
     const bool accum = p.flags & F_ACCUM, relu_out = p.flags & F_RELU_OUT;
+    constexpr int EP = 36;
+    float *patch = lds + wave * (32 * EP);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            int col = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-            if (col >= p.N) continue;
-            float bv = p.bias ? p.bias[col] : 0.0f;
+            const int row0 = m0 + wm * (TM * 32) + i * 32, col0 = n0 + wn * (TN * 32) + j * 32;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int row = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][q] + bv;
-                if (p.mask) v = p.mask[(size_t)row * p.ldm + col] > 0.0f ? v : 0.0f;
-                if (relu_out) v = fmaxf(v, 0.0f);
-                float *dst = C + (size_t)row * p.ldc + col;
-                if (accum) v += *dst;
-                *dst = v;
+            for (int q = 0; q < 16; ++q)
+                patch[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[i][j][q];
+            const int col = col0 + ec;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && col < p.N) bv = *reinterpret_cast<const float4 *>(p.bias + col);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = row0 + pass * 8 + er;
+                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
+                if (row < p.M && col < p.N) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (p.mask) {
+                        float4 mk = *reinterpret_cast<const float4 *>(p.mask + (size_t)row * p.ldm + col);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    float4 *dst = reinterpret_cast<float4 *>(C + (size_t)row * p.ldc + col);
+                    if (accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *dst = v;
+                }
             }
         }
 }
@@ -315,11 +335,11 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1>
 static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD>), grid, dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, ABLATE, MINW>), grid, dim3(64 * WM * WN), 0, s, a);
     return check_launch(what);
 }
 
@@ -327,7 +347,17 @@ static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char 
 // 256x128 tiles (both lose occupancy: 2 resp. 1 waves/SIMD instead of 3).
 template <bool B_KC>
 static int launch_rows(const GemmArgs &a, hipStream_t s, const char *what) {
-    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC>(a, 1, s, what);
+    if (a.N > 64) {
+        static int ab = -1;
+        if (ab < 0) { const char *e = getenv("T2H_GEMM_ABLATE"); ab = e ? atoi(e) : 0; }
+        if (ab == 1) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 1>(a, 1, s, what);
+        if (ab == 2) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 2>(a, 1, s, what);
+        if (ab == 3) return launch_gemm<128, 256, 2, 2, true, B_KC, 16, true, 0, 2>(a, 1, s, what);
+        if (ab == 4) return launch_gemm<256, 128, 2, 2, true, B_KC, 16, true, 0, 2>(a, 1, s, what);
+        if (ab == 5) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 3>(a, 1, s, what);
+        if (ab == 6) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 4>(a, 1, s, what);
+        return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 4>(a, 1, s, what);
+    }
     if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC>(a, 1, s, what);
     return launch_gemm<128, 32, 4, 1, true, B_KC>(a, 1, s, what);
 }
@@ -352,8 +382,10 @@ T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float 
     if (M < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return fail(T2H_ERR_ARG, "linear_fwd: bad shape");
     if (M == 0) return T2H_OK;
     hipStream_t s = as_stream(stream);
-    if (K % 4 != 0 || !aligned4(x, ldx) || !aligned4(w, K)) {
-        if (K > 64) return fail(T2H_ERR_ARG, "linear_fwd: K=%d must be a multiple of 4 (16-byte rows)", K);
+    const bool vec_ok = K % 4 == 0 && N % 4 == 0 && aligned4(x, ldx) && aligned4(w, K) && aligned4(y, ldy) &&
+                        (!bias || (uintptr_t)bias % 16 == 0);
+    if (!vec_ok) {   // fc_pos (K = 3) and 1-channel heads: plain VALU kernel
+        if (K > 64) return fail(T2H_ERR_ARG, "linear_fwd: K=%d, N=%d need 16-byte rows (multiples of 4) beyond K=64", K, N);
         long long total = (long long)M * N;
         hipLaunchKernelGGL(linear_smallk_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ldx, w, bias,
                            M, K, N, ldy, map_flags(flags), y);
@@ -369,7 +401,8 @@ T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *d
                              const float *mask, int ldmask, int flags, t2h_stream_t stream) {
     if (!dy || !w || !dx) return fail(T2H_ERR_ARG, "linear_dgrad: null pointer");
     if (M < 0 || K < 1 || N < 1 || lddy < N || lddx < K) return fail(T2H_ERR_ARG, "linear_dgrad: bad shape");
-    if (N % 4 != 0 || K % 4 != 0 || !aligned4(dy, lddy) || !aligned4(w, K))
+    if (N % 4 != 0 || K % 4 != 0 || !aligned4(dy, lddy) || !aligned4(w, K) || !aligned4(dx, lddx) ||
+        (mask && !aligned4(mask, ldmask)))
         return fail(T2H_ERR_ARG, "linear_dgrad: N=%d, K=%d must be multiples of 4 (16-byte rows)", N, K);
     if (M == 0) return T2H_OK;
     GemmArgs a{};
@@ -432,7 +465,7 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
         a.M = N; a.N = K; a.K = M; a.flags = (flags & T2H_RELU_IN) ? F_RELU_B : 0;
         a.k_chunk = p.k_chunk; a.slab_stride = (long long)N * K;
         int rc;
-        if (p.bm == 128 && p.bn == 128) rc = launch_gemm<128, 128, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
+        if (p.bm == 128 && p.bn == 128) rc = launch_gemm<128, 128, 2, 2, false, false, 16, true, 0, 4>(a, p.splits, s, "linear_wgrad");
         else if (p.bm == 128 && p.bn == 64) rc = launch_gemm<128, 64, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
         else if (p.bm == 128 && p.bn == 32) rc = launch_gemm<128, 32, 4, 1, false, false>(a, p.splits, s, "linear_wgrad");
         else if (p.bm == 64 && p.bn == 128) rc = launch_gemm<64, 128, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
