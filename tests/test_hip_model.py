@@ -211,3 +211,33 @@ def test_full_size_properties():
     assert torch.isfinite(h1).all()
     assert torch.equal(h1, h2), "two runs on the same tile differ: a nondeterministic reduction crept in"
     _close(h3.cpu().numpy(), h1.cpu().numpy(), what="point-order invariance")
+
+
+def test_direct_grad_accumulation_matches_autograd():
+    """From the second optimizer window on, Trainer lets the wgrad kernels accumulate straight into the flat
+    gradient bucket; the accumulated gradients must equal plain autograd accumulation."""
+    from tomosar2height_amd import TomoSAR2Height, mlp
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.plane_resolution = 32
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 3
+    tiles = [{"inputs": synth_cloud(3000, seed=300 + i), "dsm": torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30}
+             for i in range(4)]
+    model = det_init_(TomoSAR2Height(cfg), seed=11).to(_dev())
+    tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=2, use_cloud=True)
+    assert tr.train_step(tiles[0]) is False and tr.train_step(tiles[1]) is True       # tile 0 builds the bucket
+    assert tr.bucket is not None
+    tr.train_step(tiles[2])
+    tr.accumulated_steps = 0                                                          # keep accumulating, no step
+    tr.train_step(tiles[3])
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref = det_init_(TomoSAR2Height(cfg), seed=11).to(_dev())
+    for t in tiles[2:]:
+        pa, _ = ref(input_cloud=t["inputs"].to(_dev()))
+        torch.nn.functional.l1_loss(pa.squeeze(), t["dsm"].squeeze().to(_dev())).backward()
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            assert k not in got
+            continue
+        _close(got[k].cpu().numpy(), p.grad.cpu().numpy(), rel=1e-5, what=k)

@@ -74,7 +74,33 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
               tag=f"t2h_linear_wgrad[N={n},K={k}]")
 
 
+_DIRECT_ACCUM = False
+
+
+class direct_grad_accumulation:
+    """While active, weight/bias gradients of the per-point layers are accumulated by the wgrad kernel straight into
+    an existing contiguous ``param.grad`` (e.g. the Trainer's flat bucket views) and the autograd Function returns
+    ``None`` for them -- this removes one elementwise add launch per parameter per tile.  Off by default so that
+    ``torch.autograd.grad`` and first-touch (``grad is None``) semantics stay the standard ones."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _DIRECT_ACCUM
+        self.prev, _DIRECT_ACCUM = _DIRECT_ACCUM, self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _DIRECT_ACCUM
+        _DIRECT_ACCUM = self.prev
+
+
 def _wgrad(dy, x, w, bias, relu_in=False):
+    if (_DIRECT_ACCUM and w.shape[0] % 4 == 0 and w.grad is not None and w.grad.is_contiguous()
+            and (bias is None or (bias.grad is not None and bias.grad.is_contiguous()))):
+        linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+        return None, None
     if w.shape[0] % 4 != 0:
         # odd output widths (the 1-channel head of the non-default per-pixel FC decoder, pixel.py:51) are off the
         # per-point hot path: library GEMM on the device

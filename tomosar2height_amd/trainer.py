@@ -11,11 +11,14 @@ single-device accumulated gradient.  Parameters that never receive a gradient
 (``up_convs[depth-2].{upconv,fc_comm,fc_c}``, alto.py:241-242) are a static set and stay out of the bucket, so
 AdamW skips them exactly as it does in the reference.
 """
+import os
 from collections import defaultdict
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+from . import mlp
 
 
 class GradBucket:
@@ -59,6 +62,7 @@ class Trainer:
         self.optimize_every = optimize_every
         self.local_every = optimize_every // self.world      # tiles per rank per optimizer step
         self.bucket = None
+        self.direct_accumulation = os.environ.get("T2H_DIRECT_ACCUM", "1") != "0"
 
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
@@ -87,7 +91,12 @@ class Trainer:
         self.model.train()
         loss_l1, loss_ce = self._losses(data, 0.0001)                     # trainer.py:63-69
         loss = loss_l1 + loss_ce
-        loss.backward()
+        with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation):
+            loss.backward()
+        if self.bucket is None:
+            # first tile: the set of parameters that receive gradients is now known (it is static); from here on
+            # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
+            self.bucket = GradBucket(list(self.model.parameters()))
 
         self.accumulated_steps += 1
         self.accumulated_loss += loss.detach()
@@ -96,8 +105,6 @@ class Trainer:
         if self.accumulated_steps < self.local_every:
             return False
 
-        if self.bucket is None:
-            self.bucket = GradBucket(list(self.model.parameters()))
         if self.world > 1:
             self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
         self.optimizer.step()
