@@ -21,6 +21,18 @@ import torch.nn as nn
 from . import mlp
 
 
+def _is_dense(t: torch.Tensor) -> bool:
+    """True if t's elements tile a contiguous block of memory exactly once (some permutation of a contiguous tensor)."""
+    expected = 1
+    for size, stride in sorted(zip(t.shape, t.stride()), key=lambda ss: ss[1]):
+        if size == 1:
+            continue
+        if stride != expected:
+            return False
+        expected *= size
+    return True
+
+
 class GradBucket:
     """One contiguous fp32 buffer holding every live gradient; ``p.grad`` are views into it."""
 
@@ -32,8 +44,14 @@ class GradBucket:
         off = 0
         for p in self.params:
             n = p.numel()
-            view = self.flat[off:off + n].view_as(p)
-            view.copy_(p.grad)
+            g = p.grad
+            # keep the gradient's own dense layout (channels_last conv weights get channels_last grads: autograd's
+            # "gradient layout contract"), so later accumulations are plain contiguous adds
+            if g.is_contiguous() or not _is_dense(g):
+                view = self.flat[off:off + n].view_as(p)
+            else:
+                view = torch.as_strided(self.flat, g.size(), g.stride(), storage_offset=off)
+            view.copy_(g)
             p.grad = view
             off += n
 
