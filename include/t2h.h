@@ -137,10 +137,12 @@ int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, i
  *   t2h_linear_wgrad  dw = [dw +] dy^T act_in(x);  db = [db +] colsum(dy)  flags: T2H_RELU_IN | T2H_ACCUM; db may be NULL
  *                     reduction over the M points is split across workgroups into slabs in `workspace`
  *                     (t2h_linear_wgrad_workspace_bytes) and summed in split order: deterministic.
- * K_in that is not a multiple of 4 (fc_pos: K = 3) takes a VALU path (K <= 64 forward, K <= 8 wgrad). */
+ * K_in that is not a multiple of 4 (fc_pos: K = 3) takes a VALU path (K <= 64 forward, K <= 8 wgrad), always fp32.
+ * T2H_BF16 (all three): v_mfma_f32_32x32x16_bf16 on bf16-rounded operands, fp32 accumulate and fp32 I/O. */
 #define T2H_RELU_IN 1
 #define T2H_RELU_OUT 2
 #define T2H_ACCUM 4
+#define T2H_BF16 8   /* operands rounded to bf16 (RNE) while staging, fp32 accumulate: BASELINE.json configs[2] */
 int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
                    int N, int flags, t2h_stream_t stream);
 int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,

@@ -94,3 +94,31 @@ def test_a_equals_identity_asymmetric_b():
     y = torch.empty(k, 96, device=_dev())
     mlp.linear_fwd_(x.to(_dev()), w.to(_dev()), None, y)
     assert torch.equal(y.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 32, 32), (4096, 64, 128), (3000, 256, 512), (2048, 512, 1024), (777, 128, 64)])
+def test_bf16_mode_is_exact_bf16_rounding(m, k, n):
+    """T2H_BF16: operands rounded to bf16 (RNE), products exact, fp32 accumulation -- so the result must equal a
+    float64 matmul of the bf16-rounded operands to fp32 accumulation error (2e-5), for all three GEMMs."""
+    from tomosar2height_amd import mlp
+    g = torch.Generator().manual_seed(m + k + n + 7)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    dy, mask = torch.randn(m, n, generator=g), torch.randn(m, k, generator=g)
+    r = lambda t: t.bfloat16().double()
+    mlp.set_precision("bf16")
+    try:
+        y = torch.empty(m, n, device=_dev())
+        mlp.linear_fwd_(x.to(_dev()), w.to(_dev()), b.to(_dev()), y, relu_in=True, relu_out=True)
+        want = (r(x.clamp(min=0)) @ r(w).t() + b.double()).clamp(min=0)
+        assert _rel(y, want) < 2e-5
+        fp32_err = _rel(y, (x.double().clamp(min=0) @ w.double().t() + b.double()).clamp(min=0))
+        assert 1e-4 < fp32_err < 3e-2          # really is bf16 arithmetic, and of the expected size
+        dx = torch.empty(m, k, device=_dev())
+        mlp.linear_dgrad_(dy.to(_dev()), w.to(_dev()), dx, mask=mask.to(_dev()))
+        assert _rel(dx, (r(dy) @ r(w)) * (mask > 0)) < 2e-5
+        dw, db = torch.empty(n, k, device=_dev()), torch.empty(n, device=_dev())
+        mlp.linear_wgrad_(dy.to(_dev()), x.to(_dev()), dw, db, relu_in=True)
+        assert _rel(dw, r(dy).t() @ r(x.clamp(min=0))) < 3e-5
+        assert _rel(db, dy.double().sum(0)) < 3e-5            # the bias gradient stays an fp32 sum
+    finally:
+        mlp.set_precision("fp32")

@@ -23,6 +23,7 @@
 namespace t2h {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kPad = 4;
 constexpr int kMinBK = 16;
@@ -88,7 +89,8 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1,
+          bool BF16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
@@ -157,6 +159,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
         }
         const float *a_base = lds + cur * BUF + (lane >> 5) * SA + wm * (TM * 32) + (lane & 31);
         const float *b_base = lds + cur * BUF + BK * SA + (lane >> 5) * SB + wn * (TN * 32) + (lane & 31);
+        if (BF16) {
+            // bf16 operands, fp32 accumulate (BASELINE.json configs[2]): the slab stays fp32 in LDS; each lane gathers
+            // the 8 k-values of its row/column (A[row][8h+j], B[8h+j][col]), rounds them to bf16 (RNE,
+            // v_cvt_pk_bf16_f32) and issues one 32x32x16 MFMA per 16-deep slab.
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        a[i][q] = (__bf16)(lds[cur * BUF + (ks * 16 + (lane >> 5) * 8 + q) * SA + wm * (TM * 32) + i * 32 + (lane & 31)]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        b[j][q] = (__bf16)(lds[cur * BUF + BK * SA + (ks * 16 + (lane >> 5) * 8 + q) * SB + wn * (TN * 32) + j * 32 + (lane & 31)]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[TM], b[TN];
@@ -171,6 +197,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
                     if (ABLATE == 2) { asm volatile("" ::"v"(a[i]), "v"(b[j])); continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
+        }
         }
         if (kt + 1 < nk) {
             la.store(lds + (cur ^ 1) * BUF, tid);
@@ -335,31 +362,26 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1>
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1,
+          bool BF16 = false>
 static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, ABLATE, MINW>), grid, dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, ABLATE, MINW, BF16>), grid, dim3(64 * WM * WN), 0, s, a);
     return check_launch(what);
 }
 
 // pick the N tile for row-streaming GEMMs (M huge).  128x128x16 with 4 waves won the A/B against BK = 32 and
-// 256x128 tiles (both lose occupancy: 2 resp. 1 waves/SIMD instead of 3).
+// 256x128 tiles (both lose occupancy: 2 resp. 1 waves/SIMD instead of 3-4).
+template <bool B_KC, bool BF16>
+static int launch_rows_p(const GemmArgs &a, hipStream_t s, const char *what) {
+    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, BF16 ? 3 : 4, BF16>(a, 1, s, what);
+    if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC, 16, true, 0, 1, BF16>(a, 1, s, what);
+    return launch_gemm<128, 32, 4, 1, true, B_KC, 16, true, 0, 1, BF16>(a, 1, s, what);
+}
 template <bool B_KC>
-static int launch_rows(const GemmArgs &a, hipStream_t s, const char *what) {
-    if (a.N > 64) {
-        static int ab = -1;
-        if (ab < 0) { const char *e = getenv("T2H_GEMM_ABLATE"); ab = e ? atoi(e) : 0; }
-        if (ab == 1) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 1>(a, 1, s, what);
-        if (ab == 2) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 2>(a, 1, s, what);
-        if (ab == 3) return launch_gemm<128, 256, 2, 2, true, B_KC, 16, true, 0, 2>(a, 1, s, what);
-        if (ab == 4) return launch_gemm<256, 128, 2, 2, true, B_KC, 16, true, 0, 2>(a, 1, s, what);
-        if (ab == 5) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 3>(a, 1, s, what);
-        if (ab == 6) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 4>(a, 1, s, what);
-        return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, 4>(a, 1, s, what);
-    }
-    if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC>(a, 1, s, what);
-    return launch_gemm<128, 32, 4, 1, true, B_KC>(a, 1, s, what);
+static int launch_rows(const GemmArgs &a, bool bf16, hipStream_t s, const char *what) {
+    return bf16 ? launch_rows_p<B_KC, true>(a, s, what) : launch_rows_p<B_KC, false>(a, s, what);
 }
 
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
@@ -394,7 +416,7 @@ T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float 
     GemmArgs a{};
     a.A = x; a.lda = ldx; a.B = w; a.ldb = K; a.C = y; a.ldc = ldy; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.flags = map_flags(flags); a.k_chunk = K; a.slab_stride = 0;
-    return launch_rows<true>(a, s, "linear_fwd");
+    return launch_rows<true>(a, (flags & T2H_BF16) != 0, s, "linear_fwd");
 }
 
 T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,
@@ -409,7 +431,7 @@ T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *d
     // dX[M,K] = dY[M,N] . W[N,K]: reduction over N; B(k=n, j) = W[n*K + j] is j-contiguous (direct layout)
     a.A = dy; a.lda = lddy; a.B = w; a.ldb = K; a.C = dx; a.ldc = lddx; a.mask = mask; a.ldm = ldmask;
     a.M = M; a.N = K; a.K = N; a.flags = map_flags(flags & T2H_ACCUM); a.k_chunk = N; a.slab_stride = 0;
-    return launch_rows<false>(a, as_stream(stream), "linear_dgrad");
+    return launch_rows<false>(a, (flags & T2H_BF16) != 0, as_stream(stream), "linear_dgrad");
 }
 
 namespace {
@@ -465,15 +487,20 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
         a.M = N; a.N = K; a.K = M; a.flags = (flags & T2H_RELU_IN) ? F_RELU_B : 0;
         a.k_chunk = p.k_chunk; a.slab_stride = (long long)N * K;
         int rc;
-        if (p.bm == 128 && p.bn == 128) rc = launch_gemm<128, 128, 2, 2, false, false, 16, true, 0, 4>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 128 && p.bn == 64) rc = launch_gemm<128, 64, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 128 && p.bn == 32) rc = launch_gemm<128, 32, 4, 1, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 64 && p.bn == 128) rc = launch_gemm<64, 128, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 64 && p.bn == 64) rc = launch_gemm<64, 64, 2, 2, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 64 && p.bn == 32) rc = launch_gemm<64, 32, 2, 1, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 32 && p.bn == 128) rc = launch_gemm<32, 128, 1, 4, false, false>(a, p.splits, s, "linear_wgrad");
-        else if (p.bm == 32 && p.bn == 64) rc = launch_gemm<32, 64, 1, 2, false, false>(a, p.splits, s, "linear_wgrad");
-        else rc = launch_gemm<32, 32, 1, 1, false, false>(a, p.splits, s, "linear_wgrad");
+        const bool bf = (flags & T2H_BF16) != 0;
+#define T2H_WG(BM_, BN_, WM_, WN_, MW_)                                                                              \
+    (bf ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, MW_, true>(a, p.splits, s, "linear_wgrad")       \
+        : launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, MW_, false>(a, p.splits, s, "linear_wgrad"))
+        if (p.bm == 128 && p.bn == 128) rc = bf ? T2H_WG(128, 128, 2, 2, 3) : T2H_WG(128, 128, 2, 2, 4);   // bf16 at 4 waves/SIMD spills
+        else if (p.bm == 128 && p.bn == 64) rc = T2H_WG(128, 64, 2, 2, 1);
+        else if (p.bm == 128 && p.bn == 32) rc = T2H_WG(128, 32, 4, 1, 1);
+        else if (p.bm == 64 && p.bn == 128) rc = T2H_WG(64, 128, 2, 2, 1);
+        else if (p.bm == 64 && p.bn == 64) rc = T2H_WG(64, 64, 2, 2, 1);
+        else if (p.bm == 64 && p.bn == 32) rc = T2H_WG(64, 32, 2, 1, 1);
+        else if (p.bm == 32 && p.bn == 128) rc = T2H_WG(32, 128, 1, 4, 1);
+        else if (p.bm == 32 && p.bn == 64) rc = T2H_WG(32, 64, 1, 2, 1);
+        else rc = T2H_WG(32, 32, 1, 1, 1);
+#undef T2H_WG
         if (rc) return rc;
     }
     long long total = (long long)N * K;

@@ -15,6 +15,28 @@ import torch
 from . import _lib
 
 
+# ------------------------------------------------------------------------------------------------ precision
+_BF16 = False
+
+
+def set_precision(name: str):
+    """'fp32' (default; exact fp32 MFMA, BASELINE.json configs[1]) or 'bf16' (operands rounded to bf16 while staging,
+    fp32 accumulate, fp32 tensors in HBM: configs[2] "bf16 MLP GEMMs on MFMA").  Process-wide; applies to the forward
+    and backward GEMMs of every per-point layer (fc_pos, K = 3, always stays fp32)."""
+    global _BF16
+    if name not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _BF16 = name == "bf16"
+
+
+def get_precision() -> str:
+    return "bf16" if _BF16 else "fp32"
+
+
+def _pflag() -> int:
+    return _lib.BF16 if _BF16 else 0
+
+
 # ------------------------------------------------------------------------------------------------ kernel calls
 def _rows(t: torch.Tensor, what: str):
     """A 2-D fp32 device view whose rows are contiguous (row stride >= width): returns (ptr, ld)."""
@@ -33,7 +55,7 @@ def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
     m, k = x.shape
     n = w.shape[0]
     w = w.contiguous()
-    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0)
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
     _lib.call("t2h_linear_fwd", xp, ldx, w.data_ptr(), bias.data_ptr() if bias is not None else None, yp, ldy, m, k, n,
               flags, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
               tag=f"t2h_linear_fwd[K={k},N={n}]")
@@ -47,7 +69,8 @@ def linear_dgrad_(dy, w, dx, mask=None, accumulate=False):
     k = w.shape[1]
     w = w.contiguous()
     mp, ldm = (None, 0) if mask is None else _rows(mask, "linear_dgrad mask")
-    _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm, _lib.ACCUM if accumulate else 0,
+    _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm,
+              (_lib.ACCUM if accumulate else 0) | _pflag(),
               _lib.stream(), nbytes=4 * (m * k + m * n + n * k + (m * k if mask is not None else 0)),
               flops=2 * m * k * n, tag=f"t2h_linear_dgrad[N={n},K={k}]")
     return dx
@@ -68,7 +91,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
         return
     ws_bytes = _lib.load().t2h_linear_wgrad_workspace_bytes(m, k, n)
     ws = _lib.workspace(ws_bytes, dy.device)
-    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0)
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
     _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
               ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
               tag=f"t2h_linear_wgrad[N={n},K={k}]")

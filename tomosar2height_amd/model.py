@@ -48,6 +48,12 @@ class TomoSAR2Height(nn.Module):
                 m.weight.data = m.weight.data.contiguous(memory_format=fmt)
         return self
 
+    @staticmethod
+    def set_mlp_precision(name: str):
+        """'fp32' (default) or 'bf16' for the per-point MLP GEMMs (process-wide; see ``mlp.set_precision``)."""
+        from . import mlp
+        mlp.set_precision(name)
+
     def forward(self, input_cloud=None, input_image=None):
         assert self.use_image or self.use_cloud, "At least one input modality must be used."
         feature_planes = self.encode_inputs(input_cloud, input_image)
