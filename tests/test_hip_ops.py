@@ -248,3 +248,37 @@ def test_cpu_tensor_is_rejected_loudly():
     from tomosar2height_amd.tile import TileIndex
     with pytest.raises(RuntimeError, match="no CPU path"):
         TileIndex(synth_cloud(10), 16)
+
+
+def test_operator_level_dropins_reference_signatures():
+    """scatter_mean / scatter_max / grid_sample with the reference's own call signatures (raw int64 index)."""
+    from tomosar2height_amd import ops
+    from oracle import c_oracle
+    g = load_golden("pointnet_main_vector")                      # the reference's own vector, pointnet.py:114-123
+    xy = torch.from_numpy(g["xy"]).to(_dev())
+    index = ops.coordinate2index(xy, 2)
+    out = ops.scatter_mean(xy.permute(0, 2, 1), index, out=xy.new_zeros(1, 2, 4))
+    np.testing.assert_allclose(out.reshape(1, 2, 2, 2).cpu().numpy(), g["plane"], rtol=1e-6)
+
+    gen = torch.Generator().manual_seed(5)
+    cloud = synth_cloud(700, seed=9, batch=2)
+    feat = (torch.randn(2, 700, 8, generator=gen) * 4).round() / 4
+    idx = c_oracle.coordinate2index(cloud.numpy(), 16)
+    want_v, want_a = c_oracle.scatter_max(feat.numpy(), idx, 256)
+    val, arg = ops.scatter_max(feat.permute(0, 2, 1).to(_dev()), torch.from_numpy(idx).to(_dev()), dim_size=256)
+    assert np.array_equal(val.cpu().numpy(), want_v) and np.array_equal(arg.cpu().numpy(), want_a)
+    want_m = c_oracle.scatter_mean_fwd(feat.numpy(), idx, 16).reshape(2, 8, 256)
+    got_m = ops.scatter_mean(feat.permute(0, 2, 1).to(_dev()), torch.from_numpy(idx).to(_dev()), dim_size=256)
+    np.testing.assert_allclose(got_m.cpu().numpy(), want_m, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        bad = torch.from_numpy(idx).to(_dev()).clone()
+        bad[0, 0, 0] = 256
+        ops.scatter_mean(feat.permute(0, 2, 1).to(_dev()), bad, dim_size=256)
+
+    gs = load_golden("grid_sample_points")
+    for r in (8, 16):
+        p = torch.from_numpy(gs[f"plane_r{r}"]).to(_dev()).requires_grad_(True)
+        out = ops.grid_sample_points(p, torch.from_numpy(gs[f"p_r{r}"]).to(_dev()))
+        np.testing.assert_allclose(out.detach().cpu().numpy(), gs[f"out_r{r}"], rtol=1e-5, atol=1e-6)
+        out.backward(torch.from_numpy(gs[f"gout_r{r}"]).to(_dev()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), gs[f"gplane_r{r}"], rtol=1e-4, atol=1e-5)

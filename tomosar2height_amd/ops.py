@@ -199,3 +199,75 @@ def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
     _lib.call("t2h_coordinate2index", _lib.ptr(x), d, b * n, int(reso), _lib.ptr(out), _lib.stream(),
               nbytes=16 * b * n)
     return out[:, None, :]
+
+
+# The next three mirror the reference's operator calls with their ORIGINAL signatures (original point order, raw
+# int64 cell index).  They are a compatibility seam for code that calls the operators directly: the tile index is
+# rebuilt from the index tensor (cell centres stand in for the coordinates), rows are permuted into sorted order,
+# and the same HIP kernels run.  The packaged modules never take this route (they produce features in sorted order).
+def _tile_from_index(index: torch.Tensor, dim_size: int) -> TileIndex:
+    if index.dim() != 3 or index.shape[1] != 1:
+        raise ValueError("index must be [B, 1, N] (what coordinate2index returns)")
+    reso = int(round(dim_size ** 0.5))
+    if reso * reso != dim_size:
+        raise ValueError(f"dim_size={dim_size} is not a square plane")
+    idx = index[:, 0, :]
+    ix, iy = (idx % reso).float(), torch.div(idx, reso, rounding_mode="floor").float()
+    centres = torch.stack([(ix + 0.5) / reso, (iy + 0.5) / reso, torch.zeros_like(ix)], dim=2)
+    tile = TileIndex(centres.contiguous(), reso)
+    tile.check_domain()        # index outside [0, dim_size) -> ValueError (torch_scatter raises an index error)
+    return tile
+
+
+def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: torch.Tensor = None,
+                 dim_size: int = None) -> torch.Tensor:
+    """``torch_scatter.scatter_mean(src[B,C,N], index[B,1,N], out=zeros[B,C,R*R])`` (pointnet.py:109; alto.py:85,194).
+    ``out`` must be all zero as at every reference call site; it is filled and returned."""
+    if dim not in (-1, 2):
+        raise NotImplementedError("only the last-dim form the reference uses is built")
+    cells = out.shape[-1] if out is not None else int(dim_size)
+    tile = _tile_from_index(index, cells)
+    feat = tile.sort_rows(src.permute(0, 2, 1).contiguous())
+    plane = rasterise_mean(tile, feat, tile.R)                       # [B, C, R, R]
+    flat = plane.reshape(plane.shape[0], plane.shape[1], cells)
+    if out is not None:
+        out.copy_(flat)
+        return out
+    return flat
+
+
+def scatter_max(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out=None, dim_size: int = None):
+    """``torch_scatter.scatter_max(src[B,C,N], index[B,1,N], dim_size=R*R) -> (out[B,C,R*R], arg[B,C,R*R])``
+    (pointnet.py:95).  Untouched cells: value 0, arg = N.  Ties: first point wins.  Forward only."""
+    if dim not in (-1, 2) or out is not None:
+        raise NotImplementedError("only scatter_max(src, index, dim_size=...) over the last dim is built")
+    b, c, n = src.shape
+    tile = _tile_from_index(index, int(dim_size))
+    feat = tile.sort_rows(src.permute(0, 2, 1).contiguous())
+    pooled = torch.empty_like(feat)
+    winner = torch.empty(b * n, _lib.load().t2h_pool_winner_stride(c), dtype=torch.uint8, device=src.device)
+    _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled), c,
+              _lib.ptr(winner), _lib.stream(), nbytes=8 * c * b * n + 4 * b * n)
+    # expand the winner bitmask to one flag per (point, channel), then scatter values / original indices to cells
+    vec = 4 if c % 4 == 0 else 1
+    shifts = torch.arange(vec, device=src.device, dtype=torch.uint8)
+    flags = ((winner[:, :, None] >> shifts) & 1).reshape(b * n, -1)[:, :c].bool()          # sorted order
+    rows, chans = flags.nonzero(as_tuple=True)
+    cell_of = index[:, 0, :].reshape(-1)[(tile.perm.long() + torch.arange(b, device=src.device).repeat_interleave(n) * n)]
+    batch_of = rows // n
+    val = torch.zeros(b, c, int(dim_size), dtype=src.dtype, device=src.device)
+    arg = torch.full((b, c, int(dim_size)), n, dtype=torch.int64, device=src.device)
+    val[batch_of, chans, cell_of[rows]] = pooled[rows, chans]
+    arg[batch_of, chans, cell_of[rows]] = tile.perm.long()[rows]
+    return val, arg
+
+
+def grid_sample_points(plane: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
+    """``F.grid_sample(plane, 2*xy[:, :, None]-1, padding_mode='border', align_corners=True).squeeze(-1)``
+    (alto.py:90-95): plane [B,C,r,r], xy [B,N,2+] -> [B,C,N].  Differentiable w.r.t. the plane."""
+    b, c, r, _ = plane.shape
+    pts = torch.cat([xy[..., :2], torch.zeros_like(xy[..., :1])], dim=2).contiguous()
+    tile = TileIndex(pts.clamp(0.0, 1.0 - 2.0 ** -24), r)            # binning needs [0,1); sampling uses the raw xy
+    tile.pts.copy_(tile.sort_rows(pts))
+    out_sorted = sample_plane(tile, plane)
+    return tile.unsort_rows(out_sorted).permute(0, 2, 1)
