@@ -52,11 +52,21 @@ __global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__r
         int arg[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { best[j] = -FLT_MAX; arg[j] = -1; }
-        for (int n = s; n < e; ++n) {
-            Vec<VEC> v = Vec<VEC>::load(feat + (size_t)n * ldf + c);
+        for (int n = s; n < e; n += 4) {
+            // four row loads in flight; rows past the segment end re-read the last row (a duplicate never wins the
+            // strict '>' so the first-occurrence arg-max is unaffected)
+            const int n1 = min(n + 1, e - 1), n2 = min(n + 2, e - 1), n3 = min(n + 3, e - 1);
+            Vec<VEC> v0 = Vec<VEC>::load(feat + (size_t)n * ldf + c);
+            Vec<VEC> v1 = Vec<VEC>::load(feat + (size_t)n1 * ldf + c);
+            Vec<VEC> v2 = Vec<VEC>::load(feat + (size_t)n2 * ldf + c);
+            Vec<VEC> v3 = Vec<VEC>::load(feat + (size_t)n3 * ldf + c);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (v.v[j] > best[j]) { best[j] = v.v[j]; arg[j] = n; }   // strict >: first point wins ties
+            for (int j = 0; j < VEC; ++j) {
+                if (v0.v[j] > best[j]) { best[j] = v0.v[j]; arg[j] = n; }   // strict >: first point wins ties
+                if (v1.v[j] > best[j]) { best[j] = v1.v[j]; arg[j] = n1; }
+                if (v2.v[j] > best[j]) { best[j] = v2.v[j]; arg[j] = n2; }
+                if (v3.v[j] > best[j]) { best[j] = v3.v[j]; arg[j] = n3; }
+            }
         }
         Vec<VEC> o;
 #pragma unroll
@@ -87,10 +97,16 @@ __global__ __launch_bounds__(kThreads) void pool_max_bwd_kernel(const float *__r
         float sum[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
-        for (int n = s; n < e; ++n) {
-            Vec<VEC> g = Vec<VEC>::load(gpooled + (size_t)n * ldg + c);
+        for (int n = s; n < e; n += 4) {   // four row loads in flight, rows past the end contribute 0
+            const int n1 = min(n + 1, e - 1), n2 = min(n + 2, e - 1), n3 = min(n + 3, e - 1);
+            Vec<VEC> g0 = Vec<VEC>::load(gpooled + (size_t)n * ldg + c);
+            Vec<VEC> g1 = Vec<VEC>::load(gpooled + (size_t)n1 * ldg + c);
+            Vec<VEC> g2 = Vec<VEC>::load(gpooled + (size_t)n2 * ldg + c);
+            Vec<VEC> g3 = Vec<VEC>::load(gpooled + (size_t)n3 * ldg + c);
+            const float k1 = n + 1 < e ? 1.0f : 0.0f, k2 = n + 2 < e ? 1.0f : 0.0f, k3 = n + 3 < e ? 1.0f : 0.0f;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) sum[j] += g.v[j];
+            for (int j = 0; j < VEC; ++j)
+                sum[j] = (((sum[j] + g0.v[j]) + k1 * g1.v[j]) + k2 * g2.v[j]) + k3 * g3.v[j];
         }
         for (int n = s; n < e; ++n) {
             uint8_t bits = winner[(size_t)n * wstride + c / VEC];
@@ -261,16 +277,23 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
             for (int cx = max(px - 1, 0); cx <= min(px + 1, r - 1); ++cx) {
                 size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
                 int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
-                for (int n = s; n < e; ++n) {
-                    Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-                    float wx = (tp.x0 == px) ? tp.wx0 : ((tp.x0 + 1 == px) ? tp.wx1 : 0.0f);
-                    float wy = (tp.y0 == py) ? tp.wy0 : ((tp.y0 + 1 == py) ? tp.wy1 : 0.0f);
-                    bool hit = (tp.x0 == px || tp.x0 + 1 == px) && (tp.y0 == py || tp.y0 + 1 == py);
-                    if (!hit) continue;
-                    float w = __fmul_rn(wx, wy);
-                    Vec<VEC> g = Vec<VEC>::load(gout + (size_t)n * C + c);
+                for (int n = s; n < e; n += 2) {   // two rows in flight; a row that misses this pixel gets weight 0
+                    const int n1 = min(n + 1, e - 1);
+                    Taps t0 = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+                    Taps t1 = make_taps(pts[(size_t)n1 * dim + 0], pts[(size_t)n1 * dim + 1], r);
+                    Vec<VEC> g0 = Vec<VEC>::load(gout + (size_t)n * C + c);
+                    Vec<VEC> g1 = Vec<VEC>::load(gout + (size_t)n1 * C + c);
+                    float wx0 = (t0.x0 == px) ? t0.wx0 : ((t0.x0 + 1 == px) ? t0.wx1 : 0.0f);
+                    float wy0 = (t0.y0 == py) ? t0.wy0 : ((t0.y0 + 1 == py) ? t0.wy1 : 0.0f);
+                    float wx1 = (t1.x0 == px) ? t1.wx0 : ((t1.x0 + 1 == px) ? t1.wx1 : 0.0f);
+                    float wy1 = (t1.y0 == py) ? t1.wy0 : ((t1.y0 + 1 == py) ? t1.wy1 : 0.0f);
+                    float w0 = __fmul_rn(wx0, wy0);
+                    float w1 = (n + 1 < e) ? __fmul_rn(wx1, wy1) : 0.0f;
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(w, g.v[j]));
+                    for (int j = 0; j < VEC; ++j) {
+                        acc[j] = __fadd_rn(acc[j], __fmul_rn(w0, g0.v[j]));
+                        acc[j] = __fadd_rn(acc[j], __fmul_rn(w1, g1.v[j]));
+                    }
                 }
             }
         Vec<VEC> o;
@@ -496,11 +519,11 @@ static int check_level(const char *what, int B, int nbits, int level, int C) {
 
 // ---- coarse-level strategy: used when a cell holds >= 16 points on average and rows are float4-able ----------
 struct CoarsePlan { bool use; int S; int lgG; int chunks; };
-static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C) {
+static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C, int min_pts_per_cell = 16) {
     CoarsePlan p{false, 1, 0, 1};
     if (C % 4 != 0 || N <= 0) return p;
     int64_t cells = (int64_t)1 << (2 * (nbits - level));
-    if ((int64_t)N < 16 * cells) return p;
+    if ((int64_t)N < (int64_t)min_pts_per_cell * cells) return p;
     p.use = true;
     int64_t want = (4096 + B * cells - 1) / (B * cells);            // aim at >= 4096 workgroups
     p.S = (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
@@ -517,8 +540,13 @@ T2H_API size_t t2h_segmean_workspace_bytes(int B, int N, int nbits, int level, i
     return ((size_t)B << (2 * (nbits - level))) * p.S * C * sizeof(float);
 }
 
+constexpr int kSampleBwdMinPts = 6;   // the 3x3 gather re-reads rows ~9x: switch to read-once partials early
+
 T2H_API size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C) {
-    return 9 * t2h_segmean_workspace_bytes(B, N, nbits, level, C);
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1) return 0;
+    CoarsePlan p = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
+    if (!p.use) return 0;
+    return 9 * ((size_t)B << (2 * (nbits - level))) * p.S * C * sizeof(float);
 }
 
 T2H_API int t2h_pool_winner_stride(int C) { return C % 4 == 0 ? C / 4 : C; }
@@ -640,7 +668,7 @@ T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const i
     if (rc) return rc;
     if (dim < 2 || N < 0) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
     int64_t groups = (int64_t)B << (2 * (nbits - level));
-    CoarsePlan cp = coarse_plan(B, N, nbits, level, C);
+    CoarsePlan cp = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
     if (cp.use) {
         size_t need = t2h_sample_bwd_workspace_bytes(B, N, nbits, level, C);
         if (!workspace || workspace_bytes < need)
