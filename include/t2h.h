@@ -162,6 +162,17 @@ int t2h_upsample_bilinear_bwd(const float *gout, int B, int C, int h, int w, int
                               t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DSM mosaic of the inference path                     generator.py:147-157
+ *   per tile: dsm[t:t+H, l:l+W] += flip_rows(height) * patch_weight;  weight[...] += patch_weight   (float64)
+ *   finally : dsm = maximum(dsm / weight, 0), NaN where no tile contributed
+ * height [H, W] fp32 = model(...)[0].squeeze(); flip_rows = 1 applies the reference's .flip(1). Region rows/cols that
+ * fall outside the [rows, cols] mosaic are skipped.  Launch one tile at a time on one stream (tiles overlap). */
+int t2h_mosaic_accumulate(const float *height, int H, int W, const double *patch_weight, double *dsm,
+                          double *weight, int rows, int cols, int t_row, int l_col, int flip_rows,
+                          t2h_stream_t stream);
+int t2h_mosaic_finalize(double *dsm, const double *weight, int64_t n, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Layout glue between the conv side (NCHW) and the point side (NHWC): [B, C, P] <-> [B, P, C]. */
 int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);

@@ -253,5 +253,33 @@ def main():
     save("trainer_accumulation", **arrs)
 
 
+
+
+def blend_weight_fixture():
+    """(10) DSMGenerator._linear_blend_patch_weight (generator.py:85-113).  generator.py cannot be imported as a
+    module here (dataset.py needs `transformations`), so the static method is compiled from the reference file where
+    it lies and executed; nothing is copied."""
+    import ast
+    import math
+    src = open("/root/reference/generator.py").read()
+    tree = ast.parse(src)
+    fn = next(n for cls in tree.body if isinstance(cls, ast.ClassDef) and cls.name == "DSMGenerator"
+              for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "_linear_blend_patch_weight")
+    fn.decorator_list = []
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "math": math}
+    exec(compile(mod, "/root/reference/generator.py", "exec"), ns)
+    arrs = {}
+    for shape, pct in (((64, 64), (0.5, 0.5)), ((32, 48), (0.25, 0.5)), ((16, 16), (0.0, 0.0)), ((10, 7), (0.3, 0.2))):
+        w = ns["_linear_blend_patch_weight"](shape, list(pct))
+        assert w.dtype == torch.float64
+        arrs[f"w_{shape[0]}x{shape[1]}_{pct[0]}_{pct[1]}"] = w
+    w = ns["_linear_blend_patch_weight"]((512, 512), [0.5, 0.5])      # the shipped configuration: store its two ramps
+    arrs["w512_row0"], arrs["w512_col0"], arrs["w512_centre"] = w[0, :], w[:, 0], w[255:257, 255:257]
+    save("mosaic_blend_weight", **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-blend" not in sys.argv:
+        main()
+    blend_weight_fixture()

@@ -39,6 +39,8 @@ SIGNATURES = {
     "t2h_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
     "t2h_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
