@@ -43,8 +43,9 @@ def parse():
     ap.add_argument("--timing-every", type=int, default=8, help="record per-kernel HIP events on every n-th timed step")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = BASELINE configs[1] (the headline); bf16 = bf16-operand MFMA for the per-point GEMMs")
+    ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="fp32 = native fp32 MFMA, BASELINE configs[1] (the headline); bf16 = bf16-operand MFMA "
+                         "(configs[2]); bf16x3 = fp32-grade products from 3-way bf16 splitting (opt-in experiment)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
@@ -168,7 +169,8 @@ def main():
             "metric": "training tiles/sec (Berlin crop, cloud-only)", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mlp_precision == "fp32" else "f32 tensors, bf16-operand MFMA in the per-point GEMMs",
+            "dtype": {"fp32": "f32", "bf16": "f32 tensors, bf16-operand MFMA in the per-point GEMMs",
+                      "bf16x3": "f32 tensors, per-point GEMM products via exact 3-way bf16 split (6 bf16 MFMAs)"}[args.mlp_precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Berlin cloud-only, fp32, B=1 tile, "
                                    f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "

@@ -143,6 +143,8 @@ int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, i
 #define T2H_RELU_OUT 2
 #define T2H_ACCUM 4
 #define T2H_BF16 8   /* operands rounded to bf16 (RNE) while staging, fp32 accumulate: BASELINE.json configs[2] */
+#define T2H_BF16X3 16 /* fp32-grade products from bf16 MFMAs: exact 3-way bf16 split of both operands, 6 piece products
+                         (error <= ~2^-23 relative per product, fp32 accumulate); opt-in, never the default */
 int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
                    int N, int flags, t2h_stream_t stream);
 int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,

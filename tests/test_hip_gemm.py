@@ -122,3 +122,30 @@ def test_bf16_mode_is_exact_bf16_rounding(m, k, n):
         assert _rel(db, dy.double().sum(0)) < 3e-5            # the bias gradient stays an fp32 sum
     finally:
         mlp.set_precision("fp32")
+
+
+@pytest.mark.parametrize("m,k,n", [(1000, 32, 32), (4096, 64, 128), (3000, 256, 512), (2048, 512, 1024), (1500, 1024, 512)])
+def test_bf16x3_mode_is_fp32_grade(m, k, n):
+    """T2H_BF16X3 (opt-in): products from an exact 3-way bf16 split.  Against float64 its error must be of the same
+    order as the native fp32 MFMA path's (within 4x), i.e. ~1e-7 .. 1e-6, nowhere near bf16's 1e-3."""
+    from tomosar2height_amd import mlp
+    g = torch.Generator().manual_seed(m + k + n + 9)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    dy, mask = torch.randn(m, n, generator=g), torch.randn(m, k, generator=g)
+    want_y = x.double() @ w.double().t() + b.double()
+    want_dx = (dy.double() @ w.double()) * (mask > 0)
+    want_dw = dy.double().t() @ x.double()
+    errs = {}
+    for mode in ("fp32", "bf16x3"):
+        mlp.set_precision(mode)
+        try:
+            y, dx = torch.empty(m, n, device=_dev()), torch.empty(m, k, device=_dev())
+            dw, db = torch.empty(n, k, device=_dev()), torch.empty(n, device=_dev())
+            mlp.linear_fwd_(x.to(_dev()), w.to(_dev()), b.to(_dev()), y)
+            mlp.linear_dgrad_(dy.to(_dev()), w.to(_dev()), dx, mask=mask.to(_dev()))
+            mlp.linear_wgrad_(dy.to(_dev()), x.to(_dev()), dw, db)
+            errs[mode] = (_rel(y, want_y), _rel(dx, want_dx), _rel(dw, want_dw))
+        finally:
+            mlp.set_precision("fp32")
+    for e32, e3 in zip(errs["fp32"], errs["bf16x3"]):
+        assert e3 < 2e-5 and e3 <= 4 * e32 + 2e-7, (errs)

@@ -45,7 +45,7 @@ SIGNATURES = {
     "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
-RELU_IN, RELU_OUT, ACCUM, BF16 = 1, 2, 4, 8
+RELU_IN, RELU_OUT, ACCUM, BF16, BF16X3 = 1, 2, 4, 8, 16
 
 _lib = None
 

@@ -90,7 +90,7 @@ struct TileLoader {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1,
-          bool BF16 = false>
+          int MODE = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
         }
         const float *a_base = lds + cur * BUF + (lane >> 5) * SA + wm * (TM * 32) + (lane & 31);
         const float *b_base = lds + cur * BUF + BK * SA + (lane >> 5) * SB + wn * (TN * 32) + (lane & 31);
-        if (BF16) {
+        if (MODE == 1) {
             // bf16 operands, fp32 accumulate (BASELINE.json configs[2]): the slab stays fp32 in LDS; each lane gathers
             // the 8 k-values of its row/column (A[row][8h+j], B[8h+j][col]), rounds them to bf16 (RNE,
             // v_cvt_pk_bf16_f32) and issues one 32x32x16 MFMA per 16-deep slab.
@@ -181,6 +181,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else if (MODE == 2) {
+            // fp32-grade product from bf16 MFMAs: every fp32 operand is split EXACTLY into three bf16 pieces
+            // v = v1 + v2 + v3 (+ <= 2^-24 |v|: v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2), the
+            // subtractions are exact in fp32).  bf16 x bf16 products are exact in fp32, so summing the six piece
+            // products with i + j <= 4 reproduces a*b to ~2^-23 relative (the dropped 2-3, 3-2, 3-3 terms), i.e. at
+            // the level of fp32 rounding itself; accumulation is the same fp32 chain as the native path.  Six
+            // 32-cycle MFMAs replace eight 64-cycle fp32 ones per 16-deep slab.  Small terms are added first.
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a1[TM], a2[TM], a3[TM], b1[TN], b2[TN], b3[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float v = lds[cur * BUF + (ks * 16 + (lane >> 5) * 8 + q) * SA + wm * (TM * 32) + i * 32 + (lane & 31)];
+                        __bf16 p1 = (__bf16)v; float r1 = v - (float)p1;
+                        __bf16 p2 = (__bf16)r1; float r2 = r1 - (float)p2;
+                        a1[i][q] = p1; a2[i][q] = p2; a3[i][q] = (__bf16)r2;
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float v = lds[cur * BUF + BK * SA + (ks * 16 + (lane >> 5) * 8 + q) * SB + wn * (TN * 32) + j * 32 + (lane & 31)];
+                        __bf16 p1 = (__bf16)v; float r1 = v - (float)p1;
+                        __bf16 p2 = (__bf16)r1; float r2 = r1 - (float)p2;
+                        b1[j][q] = p1; b2[j][q] = p2; b3[j][q] = (__bf16)r2;
+                    }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[i], b1[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b3[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b2[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b1[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b2[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
             }
         } else {
 #pragma unroll
@@ -363,25 +405,29 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int ABLATE = 0, int MINW = 1,
-          bool BF16 = false>
+          int MODE = 0>
 static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, ABLATE, MINW, BF16>), grid, dim3(64 * WM * WN), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, ABLATE, MINW, MODE>), grid, dim3(64 * WM * WN), 0, s, a);
     return check_launch(what);
 }
 
 // pick the N tile for row-streaming GEMMs (M huge).  128x128x16 with 4 waves won the A/B against BK = 32 and
 // 256x128 tiles (both lose occupancy: 2 resp. 1 waves/SIMD instead of 3-4).
-template <bool B_KC, bool BF16>
+template <bool B_KC, int MODE>
 static int launch_rows_p(const GemmArgs &a, hipStream_t s, const char *what) {
-    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, BF16 ? 3 : 4, BF16>(a, 1, s, what);
-    if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC, 16, true, 0, 1, BF16>(a, 1, s, what);
-    return launch_gemm<128, 32, 4, 1, true, B_KC, 16, true, 0, 1, BF16>(a, 1, s, what);
+    constexpr int MW = MODE == 0 ? 4 : (MODE == 1 ? 3 : 2);     // register budget: 128 / 168 / 256 per lane
+    if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, 0, MW, MODE>(a, 1, s, what);
+    if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC, 16, true, 0, 1, MODE>(a, 1, s, what);
+    return launch_gemm<128, 32, 4, 1, true, B_KC, 16, true, 0, 1, MODE>(a, 1, s, what);
 }
+static int mode_of(int flags) { return (flags & T2H_BF16X3) ? 2 : ((flags & T2H_BF16) ? 1 : 0); }
 template <bool B_KC>
-static int launch_rows(const GemmArgs &a, bool bf16, hipStream_t s, const char *what) {
-    return bf16 ? launch_rows_p<B_KC, true>(a, s, what) : launch_rows_p<B_KC, false>(a, s, what);
+static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *what) {
+    if (mode == 2) return launch_rows_p<B_KC, 2>(a, s, what);
+    if (mode == 1) return launch_rows_p<B_KC, 1>(a, s, what);
+    return launch_rows_p<B_KC, 0>(a, s, what);
 }
 
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
@@ -416,7 +462,7 @@ T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float 
     GemmArgs a{};
     a.A = x; a.lda = ldx; a.B = w; a.ldb = K; a.C = y; a.ldc = ldy; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.flags = map_flags(flags); a.k_chunk = K; a.slab_stride = 0;
-    return launch_rows<true>(a, (flags & T2H_BF16) != 0, s, "linear_fwd");
+    return launch_rows<true>(a, mode_of(flags), s, "linear_fwd");
 }
 
 T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,
@@ -431,7 +477,7 @@ T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *d
     // dX[M,K] = dY[M,N] . W[N,K]: reduction over N; B(k=n, j) = W[n*K + j] is j-contiguous (direct layout)
     a.A = dy; a.lda = lddy; a.B = w; a.ldb = K; a.C = dx; a.ldc = lddx; a.mask = mask; a.ldm = ldmask;
     a.M = M; a.N = K; a.K = N; a.flags = map_flags(flags & T2H_ACCUM); a.k_chunk = N; a.slab_stride = 0;
-    return launch_rows<false>(a, (flags & T2H_BF16) != 0, as_stream(stream), "linear_dgrad");
+    return launch_rows<false>(a, mode_of(flags), as_stream(stream), "linear_dgrad");
 }
 
 namespace {
@@ -487,11 +533,12 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
         a.M = N; a.N = K; a.K = M; a.flags = (flags & T2H_RELU_IN) ? F_RELU_B : 0;
         a.k_chunk = p.k_chunk; a.slab_stride = (long long)N * K;
         int rc;
-        const bool bf = (flags & T2H_BF16) != 0;
-#define T2H_WG(BM_, BN_, WM_, WN_, MW_)                                                                              \
-    (bf ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, MW_, true>(a, p.splits, s, "linear_wgrad")       \
-        : launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, MW_, false>(a, p.splits, s, "linear_wgrad"))
-        if (p.bm == 128 && p.bn == 128) rc = bf ? T2H_WG(128, 128, 2, 2, 3) : T2H_WG(128, 128, 2, 2, 4);   // bf16 at 4 waves/SIMD spills
+        const int mode = mode_of(flags);
+#define T2H_WG(BM_, BN_, WM_, WN_, MW_)                                                                                \
+    (mode == 2 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, (MW_ > 2 ? 2 : MW_), 2>(a, p.splits, s, "linear_wgrad") \
+     : mode == 1 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, (MW_ > 3 ? 3 : MW_), 1>(a, p.splits, s, "linear_wgrad") \
+                 : launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, 0, MW_, 0>(a, p.splits, s, "linear_wgrad"))
+        if (p.bm == 128 && p.bn == 128) rc = T2H_WG(128, 128, 2, 2, 4);
         else if (p.bm == 128 && p.bn == 64) rc = T2H_WG(128, 64, 2, 2, 1);
         else if (p.bm == 128 && p.bn == 32) rc = T2H_WG(128, 32, 4, 1, 1);
         else if (p.bm == 64 && p.bn == 128) rc = T2H_WG(64, 128, 2, 2, 1);

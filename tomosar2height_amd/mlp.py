@@ -16,25 +16,26 @@ from . import _lib
 
 
 # ------------------------------------------------------------------------------------------------ precision
-_BF16 = False
+_MODE = "fp32"
 
 
 def set_precision(name: str):
     """'fp32' (default; exact fp32 MFMA, BASELINE.json configs[1]) or 'bf16' (operands rounded to bf16 while staging,
-    fp32 accumulate, fp32 tensors in HBM: configs[2] "bf16 MLP GEMMs on MFMA").  Process-wide; applies to the forward
+    fp32 accumulate, fp32 tensors in HBM: configs[2] "bf16 MLP GEMMs on MFMA") or 'bf16x3' (opt-in: fp32-grade products
+    from an exact 3-way bf16 split of both operands, six bf16 MFMAs per product).  Process-wide; applies to the forward
     and backward GEMMs of every per-point layer (fc_pos, K = 3, always stays fp32)."""
-    global _BF16
-    if name not in ("fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
-    _BF16 = name == "bf16"
+    global _MODE
+    if name not in ("fp32", "bf16", "bf16x3"):
+        raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
+    _MODE = name
 
 
 def get_precision() -> str:
-    return "bf16" if _BF16 else "fp32"
+    return _MODE
 
 
 def _pflag() -> int:
-    return _lib.BF16 if _BF16 else 0
+    return {"fp32": 0, "bf16": _lib.BF16, "bf16x3": _lib.BF16X3}[_MODE]
 
 
 # ------------------------------------------------------------------------------------------------ kernel calls
