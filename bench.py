@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = native fp32 MFMA, BASELINE configs[1] (the headline); bf16 = bf16-operand MFMA "
                          "(configs[2]); bf16x3 = fp32-grade products from 3-way bf16 splitting (opt-in experiment)")
+    ap.add_argument("--hip-graph", type=int, default=0,
+                    help="1 = capture the fixed-N tile step (fwd+loss+bwd) into a hipGraph and replay it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
@@ -151,8 +153,11 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
+    if args.hip_graph:
+        trainer.capture_graph(tiles[0])
+        run(2)
     fence()
-    timeline = None if args.no_kernel_timing else _lib.KernelTimeline()
+    timeline = None if (args.no_kernel_timing or args.hip_graph) else _lib.KernelTimeline()
     t0 = time.perf_counter()
     run(args.steps, args.warmup, timeline, args.timing_every)
     fence()
@@ -177,7 +182,7 @@ def main():
                                    f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
                        "parallelism": f"dp{world}", "params": n_params, "channels_last": bool(args.channels_last),
-                       "miopen_find": bool(args.miopen_find)},
+                       "miopen_find": bool(args.miopen_find), "hip_graph": bool(args.hip_graph)},
         }
         if timeline is not None:
             timed_steps = max(1, len([i for i in range(args.steps) if i % args.timing_every == args.timing_every - 1]))

@@ -80,6 +80,7 @@ class Trainer:
         self.optimize_every = optimize_every
         self.local_every = optimize_every // self.world      # tiles per rank per optimizer step
         self.bucket = None
+        self._graph = None
         self.direct_accumulation = os.environ.get("T2H_DIRECT_ACCUM", "1") != "0"
 
         self.accumulated_steps = 0
@@ -100,17 +101,63 @@ class Trainer:
         if self.use_footprint:
             loss_ce = self.weight_ce * self.loss_ce(pb.squeeze(), (dsm_gt.squeeze() > mask_threshold).float())
         else:
-            loss_ce = torch.tensor(0.0, device=device)
+            loss_ce = torch.zeros((), device=device)      # (a fill kernel: capturable, unlike torch.tensor(0.0))
         return loss_l1, loss_ce
+
+    # ------------------------------------------------------------------------------------------ hipGraph
+    def capture_graph(self, example):
+        """Capture forward + loss + backward of one tile into a hipGraph (``torch.cuda.CUDAGraph``) for tiles of
+        ``example``'s shapes.  Later ``train_step`` calls with the same shapes copy the tile into static buffers and
+        replay the ~800 launches with one host call; other shapes (real tiles have varying N) run eagerly.  Needs the
+        gradient bucket, i.e. at least one eager ``train_step`` first.  Results equal eager execution up to MIOpen's own
+        run-to-run conv-wgrad rounding.  At N = 131072 the step is GPU-bound (measured: no gain); it pays for small tiles."""
+        if self.bucket is None:
+            raise RuntimeError("capture_graph: run one eager train_step first (the gradient bucket must exist)")
+        dev = self.device
+        static = {k: example[k].to(dev).clone() for k in ("inputs", "image", "dsm") if example.get(k) is not None}
+        self.model.train()
+        saved = self.bucket.flat.clone()                   # warm-up / capture passes must not pollute the accumulators
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up on a side stream, as torch.cuda.graphs prescribes
+            for _ in range(2):
+                l1, ce = self._losses(static, 0.0001)
+                with mlp.direct_grad_accumulation(self.direct_accumulation):
+                    (l1 + ce).backward()
+        del l1, ce                                         # drop the warm-up autograd graph (and its AccumulateGrad nodes)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):         # capture on the stream the warm-up ran on
+            l1, ce = self._losses(static, 0.0001)
+            with mlp.direct_grad_accumulation(self.direct_accumulation):
+                (l1 + ce).backward()
+        self.bucket.flat.copy_(saved)
+        self._graph = {"graph": graph, "static": static, "l1": l1.detach(), "ce": ce.detach(),
+                       "shapes": {k: tuple(v.shape) for k, v in static.items()}}
+        return graph
+
+    def _graph_matches(self, data) -> bool:
+        g = getattr(self, "_graph", None)
+        if g is None:
+            return False
+        return all(data.get(k) is not None and tuple(data[k].shape) == shp for k, shp in g["shapes"].items())
 
     # ------------------------------------------------------------------------------------------ train
     def train_step(self, data) -> bool:
         """One tile: forward, loss, backward.  Returns True when this call ended with an optimizer step."""
         self.model.train()
-        loss_l1, loss_ce = self._losses(data, 0.0001)                     # trainer.py:63-69
-        loss = loss_l1 + loss_ce
-        with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation):
-            loss.backward()
+        if self._graph_matches(data):
+            g = self._graph
+            for k, buf in g["static"].items():
+                buf.copy_(data[k], non_blocking=True)
+            g["graph"].replay()
+            loss_l1, loss_ce = g["l1"], g["ce"]
+            loss = loss_l1 + loss_ce
+        else:
+            loss_l1, loss_ce = self._losses(data, 0.0001)                 # trainer.py:63-69
+            loss = loss_l1 + loss_ce
+            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation):
+                loss.backward()
         if self.bucket is None:
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
             # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
