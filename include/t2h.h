@@ -164,6 +164,30 @@ int t2h_upsample_bilinear_bwd(const float *gout, int B, int C, int h, int w, int
                               t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Grid-side fusions around the (MIOpen) convolutions -- SURVEY 8f-1, first step.  NHWC tensors ([B,H,W,C],
+ * channels_last), P = B*H*W pixels, C % 4 == 0.
+ *   t2h_bias_relu_fwd   y = act(y + bias[c]) in place           conv bias + F.relu (alto.py:98-99,229-230; pixel.py:27-30)
+ *   t2h_bias_relu_bwd   g_masked = g * (y > 0) (if relu; else untouched, may be NULL); dbias = [dbias +] sum_p g_masked
+ *   t2h_head1x1_fwd/bwd out[p] = bias + sum_i <w_i, x_i[p,:]> over up to 4 inputs: torch.cat([x,x1,x2,x3]) + the 1x1
+ *                       conv4 of ConvDecoder (pixel.py:31) without materialising the 288-channel concat; backward gives
+ *                       dx_i = [dx_i +] g[p] w_i, dw (Ctot floats, concatenated order) and dbias.  out_channels = 1.
+ *   t2h_upsample_bilinear_nhwc_fwd/bwd   F.interpolate(bilinear, align_corners=True) on NHWC planes (pixel.py:107,110) */
+int t2h_bias_relu_fwd(float *y, const float *bias, int64_t P, int C, int relu, t2h_stream_t stream);
+size_t t2h_bias_relu_bwd_workspace_bytes(int64_t P, int C);
+int t2h_bias_relu_bwd(const float *g, const float *y, float *g_masked, int64_t P, int C, int relu, int accumulate,
+                      float *dbias, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+int t2h_head1x1_fwd(const float *const *x, const int *C, int n_in, const float *w, const float *bias, int64_t P,
+                    float *out, t2h_stream_t stream);
+size_t t2h_head1x1_bwd_workspace_bytes(int64_t P, int Ctot);
+int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *C, int n_in, const float *w, const float *g,
+                    int64_t P, int accumulate_dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                    t2h_stream_t stream);
+int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W,
+                                   float *out, t2h_stream_t stream);
+int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
+                                   t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DSM mosaic of the inference path                     generator.py:147-157
  *   per tile: dsm[t:t+H, l:l+W] += flip_rows(height) * patch_weight;  weight[...] += patch_weight   (float64)
  *   finally : dsm = maximum(dsm / weight, 0), NaN where no tile contributed

@@ -1,0 +1,78 @@
+"""GPU parity of the grid-side fusions (SURVEY 8f-1 first step) against the plain torch composition they replace
+(conv + bias + ReLU, cat + 1x1 conv, F.interpolate) on the same device, and against the C oracle for the upsample."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _cl(t):
+    return t.to(_dev()).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("cin,cout,k,hw,relu", [(32, 64, 3, 64, True), (64, 32, 1, 33, False), (8, 16, 3, 17, True)])
+def test_conv_bias_act(cin, cout, k, hw, relu):
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    conv = conv.to(_dev()).to(memory_format=torch.channels_last)
+    x = _cl(torch.randn(2, cin, hw, hw, generator=g)).requires_grad_(True)
+    gout = _cl(torch.randn(2, cout, hw, hw, generator=g))
+    y = grid.conv_bias_act(x, conv, relu=relu)
+    y.backward(gout)
+    got = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    x.grad = None
+    conv.zero_grad()
+    yr = conv(x)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gout)
+    want = (yr.detach(), x.grad, conv.weight.grad, conv.bias.grad)
+    for a, b, tol in zip(got, want, (1e-6, 1e-5, 1e-4, 1e-5)):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= tol * scale + 1e-7
+
+
+def test_head1x1_matches_cat_conv():
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(4)
+    conv = torch.nn.Conv2d(288, 1, 1).to(_dev())
+    xs = [_cl(torch.randn(1, c, 40, 40, generator=g)).requires_grad_(True) for c in (32, 64, 128, 64)]
+    gout = torch.randn(1, 1, 40, 40, generator=g).to(_dev())
+    out = grid.head1x1(xs, conv)
+    out.backward(gout)
+    got = [out.detach().clone()] + [x.grad.clone() for x in xs] + [conv.weight.grad.clone(), conv.bias.grad.clone()]
+    for x in xs:
+        x.grad = None
+    conv.zero_grad()
+    ref = conv(torch.cat(xs, dim=1))
+    ref.backward(gout)
+    want = [ref.detach()] + [x.grad for x in xs] + [conv.weight.grad, conv.bias.grad]
+    for a, b in zip(got, want):
+        scale = b.abs().max().item() + 1e-12
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("b,c,h,size", [(1, 32, 256, 512), (2, 8, 16, 32), (1, 4, 7, 19)])
+def test_upsample_cl_vs_oracle(b, c, h, size):
+    from tomosar2height_amd import grid
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(b, c, h, h, generator=g)
+    add = torch.randn(b, c, size, size, generator=g)
+    gout = torch.randn(b, c, size, size, generator=g)
+    xd = _cl(x).requires_grad_(True)
+    y = grid.upsample_bilinear_cl(xd, size)
+    assert y.permute(0, 2, 3, 1).is_contiguous()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), c_oracle.upsample_bilinear_fwd(x.numpy(), size), rtol=1e-6, atol=1e-6)
+    y.backward(_cl(gout))
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), c_oracle.upsample_bilinear_bwd(gout.numpy(), h, h), rtol=1e-5, atol=1e-5)
+    y2 = grid.upsample_bilinear_cl(xd.detach(), size, _cl(add))
+    np.testing.assert_allclose(y2.cpu().numpy(), y.detach().cpu().numpy() + add.numpy(), rtol=1e-6, atol=1e-6)

@@ -39,6 +39,14 @@ SIGNATURES = {
     "t2h_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_bias_relu_fwd": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "t2h_bias_relu_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "t2h_bias_relu_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "t2h_head1x1_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
+    "t2h_head1x1_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "t2h_head1x1_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_upsample_bilinear_nhwc_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
     "t2h_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),

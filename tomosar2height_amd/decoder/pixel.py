@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import mlp, ops
+from .. import grid, mlp, ops
 from ..block import ResnetBlockFC
 
 
@@ -25,7 +25,16 @@ class ConvDecoder(nn.Module):
         self.conv4 = nn.Conv2d(288, out_channels, kernel_size=1)
         self.act = F.leaky_relu if leaky else F.relu
 
+        self.leaky = leaky
+        self.channels_last = False
+
     def forward(self, x):
+        if self.channels_last and not self.leaky and x.is_cuda:
+            # fused bias+ReLU epilogues around the MIOpen convs and a concat-free 288 -> 1 head (grid.py)
+            x1 = grid.conv_bias_act(x, self.conv1)
+            x2 = grid.conv_bias_act(x1, self.conv2)
+            x3 = grid.conv_bias_act(x2, self.conv3)
+            return grid.head1x1([x, x1, x2, x3], self.conv4)
         x1 = self.act(self.conv1(x))
         x2 = self.act(self.conv2(x1))
         x3 = self.act(self.conv3(x2))
@@ -70,8 +79,18 @@ class PixelwiseDecoder(nn.Module):
         else:
             raise ValueError("Invalid mode. Use 'conv' or 'fc'.")
 
-    def _resample(self, x):
-        return ops.upsample_bilinear(x, self.output_size)
+        self.channels_last = False
+
+    def set_channels_last(self, flag: bool):
+        self.channels_last = bool(flag)
+        for m in self.modules():
+            if isinstance(m, ConvDecoder):
+                m.channels_last = bool(flag)
+
+    def _resample(self, x, addend=None):
+        if self.channels_last and x.shape[1] % 4 == 0:
+            return grid.upsample_bilinear_cl(x, self.output_size, addend)
+        return ops.upsample_bilinear(x, self.output_size, addend)
 
     def forward(self, feature_planes):
         xy, image = feature_planes.get("xy"), feature_planes.get("image")
@@ -79,7 +98,7 @@ class PixelwiseDecoder(nn.Module):
             raise ValueError("PixelwiseDecoder: no 'xy' or 'image' plane given")
         if xy is not None and image is not None:
             if image.shape[-1] == self.output_size and image.shape[-2] == self.output_size:
-                c = ops.upsample_bilinear(xy, self.output_size, addend=image)      # pixel.py:107+110 fused
+                c = self._resample(xy, addend=image)                                # pixel.py:107+110 fused
             else:
                 c = self._resample(xy) + self._resample(image)
         else:

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
-from .. import mlp, ops
+from .. import grid, mlp, ops
 from ..tile import TileIndex
 
 
@@ -43,12 +43,18 @@ class _PointGridLevel(nn.Module):
 
     channels_last = False
 
-    def _exchange(self, tile: TileIndex, grid: torch.Tensor, c_last):
-        sampled = ops.sample_plane(tile, grid)                                   # alto.py:121-122 / 245-246
+    def _conv_relu(self, conv, x):
+        """``F.relu(conv(x))``; in channels_last mode the bias add + ReLU (and their backward) run fused (grid.py)."""
+        if self.channels_last:
+            return grid.conv_bias_act(x, conv, relu=True)
+        return F.relu(conv(x))
+
+    def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
+        sampled = ops.sample_plane(tile, plane)                                   # alto.py:121-122 / 245-246
         fa, fb = self.fc_comm[0], self.fc_comm[2]
         c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
                          self.fc_c.weight, self.fc_c.bias)                       # alto.py:123-128 / 248-253
-        raster = ops.rasterise_mean(tile, c, grid.shape[2], self.channels_last)  # alto.py:130 / 255
+        raster = ops.rasterise_mean(tile, c, plane.shape[2], self.channels_last)  # alto.py:130 / 255
         return raster, c
 
 
@@ -69,8 +75,8 @@ class DownConv(_PointGridLevel):
         if i > 0:
             self.conv1x1 = conv1x1(in_channels, out_channels)
 
-    def forward(self, tile: TileIndex, grid, prev_conv=None, c_last=None):
-        g = F.relu(self.conv2(F.relu(self.conv1(grid))))
+    def forward(self, tile: TileIndex, grid_in, prev_conv=None, c_last=None):
+        g = self._conv_relu(self.conv2, self._conv_relu(self.conv1, grid_in))
         if prev_conv is not None:
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
             res_in = self.pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
@@ -103,7 +109,7 @@ class UpConv(_PointGridLevel):
     def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last):
         up = self.upconv_noup(from_up) if self.is_last else self.upconv(from_up)    # alto.py:215-218
         g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
-        g = F.relu(self.conv2(F.relu(self.conv1(g))))
+        g = self._conv_relu(self.conv2, self._conv_relu(self.conv1, g))
         if prev_conv is not None:
             g = g + self.conv1x1(prev_conv)                                         # alto.py:233-236
         if self.is_last:                                                            # alto.py:241-242
