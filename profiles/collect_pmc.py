@@ -15,6 +15,7 @@ OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launc
     "t2h_linear_fwd[K=512,N=1024]": ["gemm_kernel<128, 128, 2, 2, true, true"],
     "t2h_linear_dgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, true, false"],
     "t2h_linear_wgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, false, false", "reduce_slabs_kernel"],
+    "t2h_linear_wgrad[N=512,K=1024]": ["gemm_kernel<128, 128, 2, 2, false, false#2", "reduce_slabs_kernel#2"],
     "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],
     "t2h_pool_max_fwd": ["pool_max_fwd_kernel"],
     "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
@@ -22,14 +23,25 @@ OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launc
 }
 
 
+REPS = 3      # profiles/pmc_probe.py runs every op this many times
+
+
 def read_counter(folder, counter):
-    sums, counts = collections.defaultdict(float), collections.defaultdict(int)
+    """mean counter value per kernel name; a kernel that serves two probe ops (wgrad: 2 x REPS dispatches) is split by
+    dispatch order into name and name#2."""
+    rows = []
     for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(path)):
-            if row["Counter_Name"] != counter:
-                continue
-            sums[row["Kernel_Name"]] += float(row["Counter_Value"])
-            counts[row["Kernel_Name"]] += 1
+        rows += [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    seen, sums, counts = collections.defaultdict(int), collections.defaultdict(float), collections.defaultdict(int)
+    for r in rows:
+        name = r["Kernel_Name"]
+        seen[name] += 1
+        key = name if seen[name] <= REPS or "false, false" not in name else name + "#2"
+        if "reduce_slabs" in name:      # 2 launches (dw, db) per wgrad call: first 2*REPS belong to the first wgrad shape
+            key = name if seen[name] <= 2 * REPS else name + "#2"
+        sums[key] += float(r["Counter_Value"])
+        counts[key] += 1
     return {k: sums[k] / counts[k] for k in sums}, counts
 
 
@@ -41,13 +53,17 @@ def main():
     for tag, parts in OPS.items():
         total, rows = 0.0, []
         for sub in parts:
-            kf = [k for k in fetch if sub in k]
-            kw = [k for k in write if sub in k]
+            second = sub.endswith("#2")
+            stem = sub[:-2] if second else sub
+            kf = [k for k in fetch if stem in k and k.endswith("#2") == second]
+            kw = [k for k in write if stem in k and k.endswith("#2") == second]
             if not kf or not kw:
                 total = None
                 break
-            f_kib = sum(fetch[k] for k in kf) / len(kf) if len(kf) == 1 else max(fetch[k] for k in kf)
-            w_kib = sum(write[k] for k in kw) / len(kw) if len(kw) == 1 else max(write[k] for k in kw)
+            f_kib = max(fetch[k] for k in kf)
+            w_kib = max(write[k] for k in kw)
+            if "reduce_slabs" in stem:            # dw + db launches: mean per launch x 2
+                f_kib, w_kib = 2 * f_kib, 2 * w_kib
             rows.append({"kernel": sub, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib})
             total += (2.0 * f_kib + w_kib) * 1024.0
         if total is not None:

@@ -41,6 +41,9 @@ for _ in range(REPS):
     mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_kernel<128,128,2,2,true,false>
 for _ in range(REPS):
     mlp.linear_wgrad_(x1024, x512, dw, db)                    # gemm_kernel<128,128,2,2,false,false> + reduce_slabs
+dw2, db2 = torch.empty(512, 1024, device=dev), torch.empty(512, device=dev)
+for _ in range(REPS):
+    mlp.linear_wgrad_(x512, x1024, dw2, db2)                  # the mirrored shape dW[512,1024] (same kernel, 2nd in order)
 for _ in range(REPS):
     ops.rasterise_mean(tile, x512, 32, channels_last=True)    # segmean_cells_kernel + segmean_finalize_kernel
 for _ in range(REPS):
