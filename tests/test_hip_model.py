@@ -303,3 +303,21 @@ def test_hip_graph_replay_matches_eager():
     # accumulated gradients agree to rounding rather than bit for bit
     scale = g_eager.abs().max().item()
     assert (g_eager - g_graph).abs().max().item() <= 1e-5 * scale
+
+
+def test_batched_tiles_equal_single_tiles():
+    """BASELINE configs[4] (large-batch inference): B tiles of equal N in one forward (cell ids offset by b*R^2) give the
+    same heights as B single-tile forwards, for Munich (depth 6, footprint head, image encoder)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import munich_config
+    model = det_init_(TomoSAR2Height(munich_config(use_image=True)), seed=5).to(_dev()).eval()
+    model.set_channels_last(True)
+    clouds = torch.cat([synth_cloud(5000, seed=70 + i) for i in range(3)], 0).to(_dev())
+    images = torch.randn(3, 3, 512, 512, generator=torch.Generator().manual_seed(3)).to(_dev())
+    with torch.no_grad():
+        pa, pb = model(input_cloud=clouds, input_image=images)
+        assert pa.shape == (3, 512, 512, 1) and pb.shape == (3, 512, 512, 1)
+        for i in range(3):
+            qa, qb = model(input_cloud=clouds[i:i + 1].contiguous(), input_image=images[i:i + 1].contiguous())
+            _close(pa[i].cpu().numpy(), qa[0].cpu().numpy(), rel=2e-5, what=f"height tile {i}")
+            _close(pb[i].cpu().numpy(), qb[0].cpu().numpy(), rel=2e-5, what=f"footprint tile {i}")
