@@ -199,6 +199,21 @@ int t2h_mosaic_accumulate(const float *height, int H, int W, const double *patch
 int t2h_mosaic_finalize(double *dsm, const double *weight, int64_t n, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tile producer: the point half of TomoSARDataset.__getitem__   dataset.py:233-278, utils/crop_cloud.py:8-29
+ * chunk [P,3] float64 world points (resident in HBM) -> out [count,3] float32 normalised tile, original order kept:
+ *   strict crop to (min, max) in x/y; z_shift = min z of the cropped points ('local_min'); float64 normalise
+ *   (x - cx)/scale_x + 0.5, (y - cy)/scale_y + 0.5, (z - z_shift)/scale_z; cast to float32; strict re-crop to (0,1).
+ * out must hold P rows (upper bound); *count = rows written; src_index (may be NULL) = chunk row of each output row.
+ * t2h_tile_crop_finish converts the internal min key in *z_shift to the double value (NaN when the crop is empty);
+ * call it after t2h_tile_crop_normalise on the same stream. */
+size_t t2h_tile_crop_workspace_bytes(int64_t P);
+int t2h_tile_crop_normalise(const double *chunk, int64_t P, double min_x, double min_y, double max_x, double max_y,
+                            double scale_x, double scale_y, double scale_z, float *out, int32_t *src_index,
+                            int32_t *count, double *z_shift, void *workspace, size_t workspace_bytes,
+                            t2h_stream_t stream);
+int t2h_tile_crop_finish(double *z_shift, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Layout glue between the conv side (NCHW) and the point side (NHWC): [B, C, P] <-> [B, P, C]. */
 int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);

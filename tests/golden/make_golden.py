@@ -279,7 +279,52 @@ def blend_weight_fixture():
     save("mosaic_blend_weight", **arrs)
 
 
+
+
+def tile_producer_fixture():
+    """(11) the point half of TomoSARDataset.__getitem__ (dataset.py:229-278, default config) composed from the
+    reference's OWN utility functions (utils/crop_cloud.py:crop_pc_2d, utils/coordinate.py:apply_transform /
+    invert_transform); dataset.py itself cannot be imported (needs `transformations`, rasterio data)."""
+    import_reference()
+    from utils import crop_pc_2d, invert_transform, apply_transform
+    g = torch.Generator().manual_seed(11)
+    p = 6000
+    chunk = torch.stack([386000.0 + torch.rand(p, generator=g, dtype=torch.float64) * 1500.0,
+                         5820000.0 + torch.rand(p, generator=g, dtype=torch.float64) * 1500.0,
+                         30.0 + torch.rand(p, generator=g, dtype=torch.float64) * 60.0], 1)
+    anchors = torch.tensor([[386100.0, 5820200.0], [386700.25, 5820900.5], [385900.0, 5819900.0], [390000.0, 5830000.0]],
+                           dtype=torch.float64)
+    chunk[0, :2] = anchors[0]                                         # exactly on the window corner: excluded (strict)
+    chunk[1, 0], chunk[1, 1] = anchors[0, 0] + 512.0, anchors[0, 1] + 100.0   # on the right edge: excluded
+    chunk[2, :2] = anchors[0] + 1e-9                                  # just inside
+    patch_size = torch.tensor([512.0, 512.0], dtype=torch.float64)
+    z_bound = [-33.7, 156.5]
+    scale_mat = torch.diag(torch.tensor([512.0, 512.0, z_bound[1] - z_bound[0], 1], dtype=torch.float64))   # dataset.py:187-190
+    shift_norm = torch.cat([torch.eye(4, 3, dtype=torch.float64), torch.tensor([0.5, 0.5, 0, 1]).reshape(-1, 1)], 1)
+    arrs = {"chunk": chunk, "anchors": anchors}
+    for i, anchor in enumerate(anchors):
+        min_bound, max_bound = anchor, anchor + patch_size
+        inputs, index = crop_pc_2d(chunk, min_bound, max_bound)                                  # dataset.py:234
+        arrs[f"n_{i}"] = len(inputs)
+        if len(inputs) == 0:
+            continue
+        z_shift = torch.min(inputs[:, 2]).double().reshape(1)                                    # dataset.py:246
+        transform_mat = scale_mat.clone()
+        transform_mat[0:3, 3] = torch.cat([(min_bound + max_bound) / 2., z_shift], 0)            # dataset.py:268
+        normalize_mat = shift_norm.double() @ torch.eye(4, dtype=torch.float64) @ torch.eye(4, dtype=torch.float64) \
+            @ invert_transform(transform_mat).double()                                           # :269-270, no augmentation
+        inputs_norm = apply_transform(inputs, normalize_mat).float()                             # :275-276
+        inputs_norm, index2 = crop_pc_2d(inputs_norm, [0.0, 0.0], [1.0, 1.0])                    # :278
+        arrs[f"index_{i}"] = index[index2]
+        arrs[f"inputs_{i}"] = inputs_norm
+        arrs[f"zshift_{i}"] = z_shift
+    save("tile_producer", **arrs)
+
+
 if __name__ == "__main__":
-    if "--only-blend" not in sys.argv:
+    if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         main()
-    blend_weight_fixture()
+    if "--only-producer" not in sys.argv:
+        blend_weight_fixture()
+    if "--only-blend" not in sys.argv:
+        tile_producer_fixture()

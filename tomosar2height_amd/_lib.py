@@ -49,6 +49,9 @@ SIGNATURES = {
     "t2h_upsample_bilinear_nhwc_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
+    "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),
+    "t2h_tile_crop_normalise": (_i, [_vp, _i64] + [ctypes.c_double] * 7 + [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_tile_crop_finish": (_i, [_vp, _vp]),
     "t2h_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
