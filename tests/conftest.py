@@ -16,6 +16,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Fresh checkout: build the C-ABI library (hipcc cross-compiles without a GPU) and the C oracle once, so that
+    neither the CPU nor the GPU tier depends on a previous `__graft_entry__.build()`.  The product itself never
+    builds on demand: `tomosar2height_amd._lib.load()` raises if the library is missing."""
+    try:
+        from tomosar2height_amd.csrc import build as hip_build
+        if not os.path.exists(hip_build.OUT) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            hip_build.build()
+        from oracle import build as oracle_build
+        oracle_build.build()
+    except Exception as e:      # tests that need the libraries will report the real error
+        print(f"[conftest] library pre-build skipped: {e}")
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
