@@ -19,6 +19,7 @@
 // slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
 // deterministic).
 #include "t2h_common.h"
+#include "gemm_args.h"
 
 namespace t2h {
 
@@ -27,21 +28,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kPad = 4;
 constexpr int kMinBK = 16;
-
-enum : int { F_RELU_A = 1, F_RELU_B = 2, F_RELU_OUT = 4, F_ACCUM = 8 };
-
-struct GemmArgs {
-    const float *A, *B;
-    float *C;
-    const float *bias;     // [N] or null
-    const float *mask;     // [M, ldm] or null: result *= (mask > 0)
-    float *colsum;         // TN only: per-split column sums of A (i.e. sum over k of A(m,k)), [splits][M] or null
-    int M, N, K;
-    int lda, ldb, ldc, ldm;
-    int flags;
-    int k_chunk;           // reduction range per blockIdx.z
-    long long slab_stride; // C offset per blockIdx.z (floats)
-};
 
 // A(m,k): A_KC ? A[m*lda + k] : A[k*lda + m];   B(k,n): B_KC ? B[n*ldb + k] : B[k*ldb + n]
 template <int ROWS, int NT, bool KC, int BK>
@@ -422,6 +408,9 @@ static int launch_rows_p(const GemmArgs &a, hipStream_t s, const char *what) {
 static int mode_of(int flags) { return (flags & T2H_BF16X3) ? 2 : ((flags & T2H_BF16) ? 1 : 0); }
 template <bool B_KC>
 static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *what) {
+    // bf16: conversion-at-staging kernel (gemm_split.hip).  bf16x3 forward / data gradient: the in-loop split below is
+    // faster (0.87 vs 1.0 ms at 512 -> 1024: its 768-cycle MFMA phase hides less of the load latency there).
+    if (mode == 1 && a.N > 64) return launch_gemm_split(mode, true, B_KC, a, 1, s, what);
     if (mode == 2) return launch_rows_p<B_KC, 2>(a, s, what);
     if (mode == 1) return launch_rows_p<B_KC, 1>(a, s, what);
     return launch_rows_p<B_KC, 0>(a, s, what);
@@ -535,7 +524,8 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
     (mode == 2 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 2 ? 2 : MW_), 2>(a, p.splits, s, "linear_wgrad") \
      : mode == 1 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 3 ? 3 : MW_), 1>(a, p.splits, s, "linear_wgrad") \
                  : launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, MW_, 0>(a, p.splits, s, "linear_wgrad"))
-        if (p.bm == 128 && p.bn == 128) rc = T2H_WG(128, 128, 2, 2, 4);
+        if (p.bm == 128 && p.bn == 128)
+            rc = mode != 0 ? launch_gemm_split(mode, false, false, a, p.splits, s, "linear_wgrad") : T2H_WG(128, 128, 2, 2, 4);
         else if (p.bm == 128 && p.bn == 64) rc = T2H_WG(128, 64, 2, 2, 1);
         else if (p.bm == 128 && p.bn == 32) rc = T2H_WG(128, 32, 4, 1, 1);
         else if (p.bm == 64 && p.bn == 128) rc = T2H_WG(64, 128, 2, 2, 1);
