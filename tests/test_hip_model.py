@@ -321,3 +321,31 @@ def test_batched_tiles_equal_single_tiles():
             qa, qb = model(input_cloud=clouds[i:i + 1].contiguous(), input_image=images[i:i + 1].contiguous())
             _close(pa[i].cpu().numpy(), qa[0].cpu().numpy(), rel=2e-5, what=f"height tile {i}")
             _close(pb[i].cpu().numpy(), qb[0].cpu().numpy(), rel=2e-5, what=f"footprint tile {i}")
+
+
+def test_training_reduces_loss_over_optimizer_steps():
+    """End-to-end guard for the flat gradient bucket + direct wgrad accumulation + AdamW path: overfitting two tiles for
+    25 optimizer steps (2 tiles each) must cut the L1 loss substantially and keep everything finite."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    torch.manual_seed(0)
+    model = TomoSAR2Height(cfg).to(_dev())
+    model.set_channels_last(True)
+    tr = Trainer(model, torch.optim.AdamW(model.parameters(), lr=5e-4), device=_dev(), optimize_every=2, use_cloud=True)
+    tiles = []
+    for i in range(2):
+        t = berlin_tile(80 + i, n_points=8192)
+        tiles.append({"inputs": t["inputs"].to(_dev()), "dsm": t["dsm"].to(_dev())})
+    history = []
+    for it in range(25):
+        for t in tiles:
+            stepped = tr.train_step(t)
+        assert stepped
+        history.append(float(tr.last_avg_loss))
+    assert all(np.isfinite(history))
+    assert history[-1] < 0.7 * history[0], history
+    assert all(torch.isfinite(p).all() for p in model.parameters())
