@@ -48,6 +48,9 @@ def parse():
                          "(configs[2]); bf16x3 = fp32-grade products from 3-way bf16 splitting (opt-in experiment)")
     ap.add_argument("--hip-graph", type=int, default=0,
                     help="1 = capture the fixed-N tile step (fwd+loss+bwd) into a hipGraph and replay it")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline (configs[1]); infer = configs[4]: Munich cloud+image forward only")
+    ap.add_argument("--batch", type=int, default=1, help="tiles per forward in --mode infer")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
@@ -87,6 +90,58 @@ def cpu_baseline(points: int, threads: int):
             "sample": f"1 tile-step (fwd+bwd, N={points}, fp32) of the oracle torch restatement, {dt:.1f} s"}
 
 
+def infer_bench(args, world, rank, dev, group):
+    """BASELINE.json configs[4]: Munich (ALTO depth 6, footprint head, cloud + image), forward only as in
+    generator.py:142-147 (`model.eval(); no_grad`), `--batch` equal-N tiles per forward, tiles round-robin over ranks
+    (no collective on the data path).  One step = one forward of `--batch` tiles; value = tiles/s over all ranks."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import munich_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    torch.manual_seed(0)
+    model = TomoSAR2Height(munich_config(use_image=True)).to(dev).eval()
+    model.set_channels_last(bool(args.channels_last))
+    model.set_mlp_precision(args.mlp_precision)
+    batches = []
+    for i in range(args.tile_pool):
+        ts = [berlin_tile(seed=1000 * rank + 10 * i + j, n_points=args.points, with_image=True) for j in range(args.batch)]
+        batches.append((torch.cat([t["inputs"] for t in ts], 0).to(dev), torch.cat([t["image"] for t in ts], 0).to(dev)))
+
+    def run(n, off=0):
+        with torch.no_grad():
+            for s in range(n):
+                cloud, image = batches[(off + s) % len(batches)]
+                model(input_cloud=cloud, input_image=image)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "inference tiles/sec (Munich cloud+image+footprint, forward only)",
+            "value": round(world * args.steps * args.batch / elapsed, 4), "unit": "tiles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mlp_precision == "fp32" else args.mlp_precision, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4]: Munich cloud+image, ALTO depth 6, footprint head, "
+                                   f"N={args.points} points/tile, {args.batch} tile(s) per forward",
+                       "parallelism": f"dp{world}", "params": sum(p.numel() for p in model.parameters())}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,9 +168,12 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     from tomosar2height_amd import TomoSAR2Height, _lib
-    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.config import berlin_config, munich_config
     from tomosar2height_amd.synthetic import berlin_tile
     from tomosar2height_amd.trainer import Trainer, broadcast_parameters
+
+    if args.mode == "infer":
+        return infer_bench(args, world, rank, dev, group)
 
     cfg = berlin_config()
     torch.manual_seed(0)
