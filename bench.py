@@ -186,7 +186,6 @@ def main():
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate)     # train.py:97
     trainer = Trainer(model, opt, device=dev, optimize_every=args.optimize_every, use_cloud=True,
                       process_group=group)
-    n_params = sum(p.numel() for p in model.parameters())
 
     tiles = []
     for i in range(args.tile_pool):
@@ -198,7 +197,7 @@ def main():
         each of the ~370 t2h launches of a step costs ~5 ms of host time per step, so instrumenting all K steps would
         distort the headline number by ~15 %."""
         for s in range(n_steps):
-            if timeline is not None and s % every == every - 1:
+            if timeline is not None and (s % every == every - 1 or (n_steps < every and s == n_steps - 1)):
                 with timeline:
                     trainer.train_step(tiles[(offset + s) % len(tiles)])
             else:
@@ -239,11 +238,11 @@ def main():
                                    f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
                                    f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
-                       "parallelism": f"dp{world}", "params": n_params, "channels_last": bool(args.channels_last),
+                       "parallelism": f"dp{world}", "channels_last": bool(args.channels_last),
                        "miopen_find": bool(args.miopen_find), "hip_graph": bool(args.hip_graph)},
         }
         if timeline is not None:
-            timed_steps = max(1, len([i for i in range(args.steps) if i % args.timing_every == args.timing_every - 1]))
+            timed_steps = max(1, len([i for i in range(args.steps) if i % args.timing_every == args.timing_every - 1]))   # >= 1: see run()
             out["config"]["kernel_timing"] = f"HIP events on {timed_steps} of the {args.steps} timed steps"
             kernels = []
             for name, d in sorted(timeline.summary().items(), key=lambda kv: -kv[1]["ms"]):
