@@ -1,0 +1,109 @@
+"""GPU edge cases and skew through the whole point<->grid operator set, against the C oracle: single point, sizes
+around the 64-lane / 2048-key tile boundaries, every point in one cell, points on a line, two tiles of very different
+density in one batch, points on cell and plane borders.  Index results bit exact, fp32 as stated per assert."""
+import numpy as np
+import pytest
+import torch
+
+from detinit import synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _clouds():
+    g = torch.Generator().manual_seed(123)
+    out = {}
+    for n in (1, 2, 63, 64, 65, 2047, 2048, 2049):
+        out[f"uniform_{n}"] = synth_cloud(n, seed=n, clustered=False)
+    one_cell = torch.full((1, 777, 3), 0.3137)
+    one_cell[..., 2] = torch.rand(1, 777, generator=g)
+    out["one_cell"] = one_cell
+    line = torch.rand(1, 3000, 3, generator=g)
+    line[..., 1] = 0.5                                     # a vertical facade: one row of cells
+    out["line"] = line
+    corners = torch.tensor([[[2.0 ** -20, 2.0 ** -20, 0.1], [1 - 2.0 ** -24, 2.0 ** -20, 0.2], [2.0 ** -20, 1 - 2.0 ** -24, 0.3],
+                             [1 - 2.0 ** -24, 1 - 2.0 ** -24, 0.4], [0.5, 0.5, 0.5], [0.25, 0.75, 0.0]]])
+    out["corners"] = corners.repeat(1, 50, 1)
+    dense = synth_cloud(4000, seed=9)
+    sparse = torch.full((1, 4000, 3), 0.9)
+    sparse[0, :5] = synth_cloud(5, seed=3)[0]
+    out["uneven_batch"] = torch.cat([dense, sparse], 0)    # tile 1: 3995 points in one cell
+    return out
+
+
+CLOUDS = _clouds()
+
+
+@pytest.mark.parametrize("name", sorted(CLOUDS))
+@pytest.mark.parametrize("reso,level,c", [(16, 0, 8), (64, 2, 32), (256, 3, 64)])
+def test_ops_vs_oracle_on_edge_clouds(name, reso, level, c):
+    from oracle import c_oracle
+    from tomosar2height_amd import ops
+    from tomosar2height_amd.tile import TileIndex
+    cloud = CLOUDS[name]
+    b, n, _ = cloud.shape
+    r = reso >> level
+    g = torch.Generator().manual_seed(len(name) + reso)
+    t = TileIndex(cloud.to(_dev()), reso)
+    assert t.out_of_domain() == 0
+    # tile index
+    idx0 = c_oracle.coordinate2index(cloud.numpy(), reso)
+    counts = np.zeros(b * reso * reso, np.int64)
+    # pool (finest level), quantised values -> ties
+    feat = (torch.randn(b, n, c, generator=g) * 2).round() / 2
+    gout = torch.randn(b, n, c, generator=g)
+    f = t.sort_rows(feat.to(_dev())).requires_grad_(True)
+    pooled = ops.pool_max(t, f)
+    pooled.backward(t.sort_rows(gout.to(_dev())))
+    want, arg = c_oracle.pool_local_fwd(feat.numpy(), idx0, reso * reso)
+    assert np.array_equal(t.unsort_rows(pooled.detach()).cpu().numpy(), want)
+    want_g = c_oracle.pool_local_bwd(gout.numpy(), idx0, arg, reso * reso)
+    got_g = t.unsort_rows(f.grad).cpu().numpy()
+    scale = np.abs(want_g).max() + 1e-9
+    assert np.abs(got_g - want_g).max() <= 2e-5 * scale
+    assert np.array_equal(got_g != 0, want_g != 0)
+    # rasterise at level
+    idx = c_oracle.coordinate2index(cloud.numpy(), r)
+    f2 = t.sort_rows(feat.to(_dev())).requires_grad_(True)
+    plane = ops.rasterise_mean(t, f2, r)
+    wantp = c_oracle.scatter_mean_fwd(feat.numpy(), idx, r)
+    np.testing.assert_allclose(plane.detach().cpu().numpy(), wantp, rtol=2e-5, atol=2e-6)
+    gp = torch.randn(b, c, r, r, generator=g)
+    plane.backward(gp.to(_dev()))
+    np.testing.assert_allclose(t.unsort_rows(f2.grad).cpu().numpy(), c_oracle.scatter_mean_bwd(gp.numpy(), idx, n),
+                               rtol=1e-6, atol=1e-7)
+    # sample + deterministic backward
+    pl = torch.randn(b, c, r, r, generator=g)
+    p = pl.to(_dev()).requires_grad_(True)
+    out = ops.sample_plane(t, p)
+    np.testing.assert_allclose(t.unsort_rows(out.detach()).cpu().numpy(), c_oracle.grid_sample_fwd(pl.numpy(), cloud.numpy()),
+                               rtol=1e-5, atol=1e-6)
+    out.backward(t.sort_rows(gout.to(_dev())))
+    wantgp = c_oracle.grid_sample_bwd(gout.numpy(), cloud.numpy(), r, r)
+    sc = np.abs(wantgp).max() + 1e-9
+    assert np.abs(p.grad.cpu().numpy() - wantgp).max() <= 1e-4 * sc
+
+
+def test_full_model_on_degenerate_tiles():
+    """The whole network on a 1-point tile and on an all-in-one-cell tile: finite heights equal to the oracle's."""
+    from detinit import det_init_
+    from oracle import torch_ref
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    cfg = berlin_config()
+    ref = det_init_(torch_ref.TomoSAR2Height(cfg), seed=31)
+    model = TomoSAR2Height(cfg)
+    model.load_state_dict(ref.state_dict())
+    model.to(_dev())
+    for name in ("uniform_1", "one_cell", "uniform_65"):
+        cloud = CLOUDS[name]
+        with torch.no_grad():
+            want, _ = ref(input_cloud=cloud)
+            got, _ = model(input_cloud=cloud.to(_dev()))
+        assert torch.isfinite(got).all()
+        scale = want.abs().max().item() + 1e-9
+        assert (got.cpu() - want).abs().max().item() <= 1e-4 * scale, name
