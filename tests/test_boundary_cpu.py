@@ -62,3 +62,45 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
                 assert "libt2h_oracle" not in src
+
+
+def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
+    """The C side validates before launching: null pointers / impossible sizes come back as T2H_ERR_ARG (-1) or
+    T2H_ERR_WORKSPACE (-3) with a message, never a crash -- checked here without any device."""
+    from tomosar2height_amd import _lib
+    lib = _lib.load()
+    n = None
+    cases = {
+        "t2h_coordinate2index": (n, 3, 10, 16, n, n),
+        "t2h_tile_build": (n, 3, 1, 10, 8, n, n, n, n, n, n, 0, n),
+        "t2h_pool_max_fwd": (n, 32, n, 1, 8, 32, n, 32, n, n),
+        "t2h_pool_max_bwd": (n, 32, n, n, 1, 8, 32, 0, n, 32, n),
+        "t2h_segmean_fwd": (n, n, 1, 10, 8, 0, 32, n, n, 0, n),
+        "t2h_segmean_bwd": (n, n, n, 1, 10, 8, 0, 32, n, n),
+        "t2h_sample_fwd": (n, n, 3, 1, 10, 32, 32, n, n),
+        "t2h_sample_bwd": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n),
+        "t2h_sample_bwd_atomic": (n, n, 3, 1, 10, 32, 32, n, n),
+        "t2h_linear_fwd": (n, 32, n, n, n, 32, 10, 32, 32, 0, n),
+        "t2h_linear_dgrad": (n, 32, n, n, 32, 10, 32, 32, n, 0, 0, n),
+        "t2h_linear_wgrad": (n, 32, n, 32, 10, 32, 32, 0, n, n, n, 0, n),
+        "t2h_upsample_bilinear_fwd": (n, n, 1, 32, 16, 16, 32, 32, n, n),
+        "t2h_upsample_bilinear_bwd": (n, 1, 32, 16, 16, 32, 32, n, n),
+        "t2h_upsample_bilinear_nhwc_fwd": (n, n, 1, 32, 16, 16, 32, 32, n, n),
+        "t2h_upsample_bilinear_nhwc_bwd": (n, 1, 32, 16, 16, 32, 32, n, n),
+        "t2h_bias_relu_fwd": (n, n, 100, 32, 1, n),
+        "t2h_bias_relu_bwd": (n, n, n, 100, 32, 1, 0, n, n, 0, n),
+        "t2h_head1x1_fwd": (n, n, 4, n, n, 100, n, n),
+        "t2h_head1x1_bwd": (n, n, n, 4, n, n, 100, 0, n, n, n, 0, n),
+        "t2h_mosaic_accumulate": (n, 64, 64, n, n, n, 100, 100, 0, 0, 1, n),
+        "t2h_mosaic_finalize": (n, n, 100, n),
+        "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),
+        "t2h_tile_crop_finish": (n, n),
+        "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
+        "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
+    }
+    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride")]
+    assert sorted(cases) == sorted(launching), set(launching) ^ set(cases)
+    for name, args in cases.items():
+        rc = getattr(lib, name)(*args)
+        assert rc in (-1, -3), f"{name} returned {rc}"
+        assert len(lib.t2h_last_error_string()) > 8
