@@ -349,3 +349,34 @@ def test_training_reduces_loss_over_optimizer_steps():
     assert all(np.isfinite(history))
     assert history[-1] < 0.7 * history[0], history
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_side_stream_wgrad_overlap_gives_identical_gradients():
+    """Trainer issues the accumulating weight-gradient GEMMs on a side stream, joined at the end of each train_step.
+    MIOpen's conv backward uses split-K atomics, so upstream gradients differ in the last bits from run to run: the
+    accumulated gradients must agree to rounding (a lost or raced accumulation would be off by a whole tile)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    tiles = [{"inputs": synth_cloud(20000, seed=900 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(5)]
+
+    def run(overlap):
+        model = det_init_(TomoSAR2Height(cfg), seed=14).to(_dev())
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=5, use_cloud=True)
+        tr.overlap_wgrad = overlap
+        for t in tiles[:-1]:
+            assert tr.train_step(t) is False
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        assert (tr._side is not None) == overlap
+        return grads
+
+    a, b = run(False), run(True)
+    linear = [k for k in a if ".fc_" in k or "fc_comm" in k or k.endswith("shortcut.weight")]
+    assert len(linear) > 40
+    for k in a:
+        scale = a[k].abs().max().item() + 1e-12
+        assert (a[k] - b[k]).abs().max().item() <= 1e-4 * scale, k

@@ -99,6 +99,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
 
 
 _DIRECT_ACCUM = False
+_WGRAD_STREAM = None
 
 
 class direct_grad_accumulation:
@@ -107,23 +108,37 @@ class direct_grad_accumulation:
     ``None`` for them -- this removes one elementwise add launch per parameter per tile.  Off by default so that
     ``torch.autograd.grad`` and first-touch (``grad is None``) semantics stay the standard ones."""
 
-    def __init__(self, enabled: bool = True):
+    def __init__(self, enabled: bool = True, side_stream=None):
+        """``side_stream``: issue the accumulating weight-gradient GEMMs there.  They are off the backward's critical
+        path (nothing reads the bucket before the optimizer step), so they fill the GPU while MIOpen's small-grid conv
+        kernels run on the main stream.  The caller joins the stream before touching the gradients."""
         self.enabled = enabled
+        self.side_stream = side_stream if enabled else None
 
     def __enter__(self):
-        global _DIRECT_ACCUM
+        global _DIRECT_ACCUM, _WGRAD_STREAM
         self.prev, _DIRECT_ACCUM = _DIRECT_ACCUM, self.enabled
+        self.prev_stream, _WGRAD_STREAM = _WGRAD_STREAM, self.side_stream
         return self
 
     def __exit__(self, *exc):
-        global _DIRECT_ACCUM
+        global _DIRECT_ACCUM, _WGRAD_STREAM
         _DIRECT_ACCUM = self.prev
+        _WGRAD_STREAM = self.prev_stream
 
 
 def _wgrad(dy, x, w, bias, relu_in=False):
     if (_DIRECT_ACCUM and w.shape[0] % 4 == 0 and w.grad is not None and w.grad.is_contiguous()
             and (bias is None or (bias.grad is not None and bias.grad.is_contiguous()))):
-        linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+        side = _WGRAD_STREAM
+        if side is None:
+            linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+        else:
+            side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
+            with torch.cuda.stream(side):
+                linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+            dy.record_stream(side)                                  # keep the allocator from recycling them early
+            x.record_stream(side)
         return None, None
     if w.shape[0] % 4 != 0:
         # odd output widths (the 1-channel head of the non-default per-pixel FC decoder, pixel.py:51) are off the

@@ -82,6 +82,11 @@ class Trainer:
         self.bucket = None
         self._graph = None
         self.direct_accumulation = os.environ.get("T2H_DIRECT_ACCUM", "1") != "0"
+        # opt-in: weight-gradient GEMMs on a side stream (see mlp.direct_grad_accumulation), joined at the end of every
+        # train_step.  +2..3 % tiles/s; off by default so that per-kernel durations (the roofline accounting) are
+        # those of kernels running alone
+        self.overlap_wgrad = os.environ.get("T2H_OVERLAP_WGRAD", "0") == "1"
+        self._side = None
 
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
@@ -156,8 +161,17 @@ class Trainer:
         else:
             loss_l1, loss_ce = self._losses(data, 0.0001)                 # trainer.py:63-69
             loss = loss_l1 + loss_ce
-            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation):
+            side = None
+            if self.overlap_wgrad and self.bucket is not None and loss.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=loss.device)
+                side = self._side
+            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation, side):
                 loss.backward()
+            if side is not None:
+                # join: the overlap is with this tile's own conv backward; afterwards the gradients are visible in
+                # stream order on the current stream like any other result
+                torch.cuda.current_stream().wait_stream(side)
         if self.bucket is None:
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
             # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
