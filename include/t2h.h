@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 2
+#define T2H_ABI_VERSION 3
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -186,6 +186,29 @@ int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, 
                                    float *out, t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
                                    t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 grid convolutions as implicit GEMMs on the matrix cores (exact fp32) -- SURVEY 8f-1, second step.
+ * Replaces nn.Conv2d(kernel_size=3, stride=1, padding=1) forward and its autograd: conv3x3 of alto.py:59-61 used at
+ * alto.py:98-99,229-230 (with F.relu) and ConvDecoder.conv1..3 of pixel.py:20-30.
+ *   x  [B,H,W,Cin]  NHWC (torch channels_last), y / dy [B,H,W,Cout]; H, W powers of two
+ *   w  [Cout][3][3][Cin] = the channels_last memory of torch's [Cout,Cin,3,3] weight; dw has the same layout
+ *   fwd    y  = act(conv(x, w) + bias)             flags: T2H_RELU_OUT, T2H_ACCUM;   Cin % 16 == 0, Cout % 4 == 0
+ *   dgrad  dx = [dx +] conv_transpose(dy, w) * (mask > 0)   mask [B,H,W,Cin] or NULL; flags: T2H_ACCUM; Cout % 16 == 0
+ *   wgrad  dw = [dw +] sum_p dy[p] (x) x[p+tap];  db = [db +] sum_p dy[p]  (db may be NULL); flags: T2H_ACCUM
+ * t2h_relu_mask is the F.relu backward in front of dgrad / wgrad (the bias gradient comes out of wgrad).
+ * Plane sizes that give fewer workgroups than the chip has CUs split the reduction into slabs in the caller's
+ * workspace (sizes from *_workspace_bytes; 0 = none needed); slabs are summed in a fixed order: deterministic. */
+int t2h_relu_mask(const float *g, const float *y, float *g_masked, int64_t n, t2h_stream_t stream); /* g * (y > 0) */
+size_t t2h_conv3x3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_conv3x3_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
+                    int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+size_t t2h_conv3x3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_conv3x3_dgrad(const float *dy, const float *w, float *dx, const float *mask, int B, int H, int W, int Cin,
+                      int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+size_t t2h_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
+                      int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DSM mosaic of the inference path                     generator.py:147-157

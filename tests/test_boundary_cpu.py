@@ -91,6 +91,10 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_bias_relu_bwd": (n, n, n, 100, 32, 1, 0, n, n, 0, n),
         "t2h_head1x1_fwd": (n, n, 4, n, n, 100, n, n),
         "t2h_head1x1_bwd": (n, n, n, 4, n, n, 100, 0, n, n, n, 0, n),
+        "t2h_relu_mask": (n, n, n, 128, n),
+        "t2h_conv3x3_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
+        "t2h_conv3x3_dgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
+        "t2h_conv3x3_wgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_mosaic_accumulate": (n, 64, 64, n, n, n, 100, 100, 0, 0, 1, n),
         "t2h_mosaic_finalize": (n, n, 100, n),
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),

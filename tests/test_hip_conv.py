@@ -1,0 +1,202 @@
+"""GPU parity of the implicit-GEMM 3x3 convolutions (csrc/conv.hip, SURVEY 8f-1 second step) and of the 1x1 convolutions
+on the per-point GEMM kernels.  The reference's operator here is torch's own nn.Conv2d (alto.py:59-61,157-182;
+pixel.py:20-32), so the checker is F.conv2d / its autograd evaluated on the CPU in float64 on the same inputs.
+Tolerances: fp32 products with fp32 accumulation over K = 9*C <= 4608 terms (and over up to 2^18 pixels for the
+weight gradient) against float64: 2e-5 of the result's max-norm."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _cl(t):
+    return t.to(_dev()).contiguous(memory_format=torch.channels_last)
+
+
+def _close(got, want, tol=2e-5):
+    want = want.to(torch.float64)
+    scale = want.abs().max().item() + 1e-30
+    err = (got.detach().cpu().to(torch.float64) - want).abs().max().item()
+    assert got.shape == want.shape and err <= tol * scale, (err / scale, tuple(got.shape))
+
+
+# (B, H, W, Cin, Cout): decoder-like (many pixels, few channels), ALTO bottom levels (few pixels, many channels: split
+# reduction), non-square, batch > 1 (image borders inside a row tile), N tiles of 32 / 64 / 128 and a ragged one (Cout=80)
+SHAPES = [(1, 64, 64, 32, 32), (1, 32, 32, 64, 128), (2, 16, 16, 128, 64), (1, 8, 8, 512, 256), (3, 4, 8, 16, 16),
+          (1, 16, 64, 48, 80), (1, 128, 128, 32, 64), (2, 2, 2, 32, 32), (1, 1, 1, 16, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3x3_forward(shape, relu):
+    from tomosar2height_amd import grid
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x, wt, bias = torch.randn(b, cin, h, w, generator=g), torch.randn(cout, cin, 3, 3, generator=g) * 0.1, torch.randn(cout, generator=g)
+    want = F.conv2d(x.double(), wt.double(), bias.double(), padding=1)
+    want = F.relu(want) if relu else want
+    y = grid._empty_cl(b, cout, h, w, _dev())
+    grid.conv3x3_fwd_(_cl(x), _cl(wt), bias.to(_dev()), y, relu=relu)
+    _close(y, want)
+    # accumulate flag: y += act(conv)
+    base = torch.randn(b, cout, h, w, generator=g)
+    y2 = _cl(base.clone())
+    grid.conv3x3_fwd_(_cl(x), _cl(wt), None, y2, relu=relu, accumulate=True)
+    want2 = F.conv2d(x.double(), wt.double(), None, padding=1)
+    _close(y2, base.double() + (F.relu(want2) if relu else want2))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv3x3_data_and_weight_gradient(shape):
+    from tomosar2height_amd import grid
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(7 + sum(shape))
+    x = torch.randn(b, cin, h, w, generator=g).double().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    bias = torch.randn(cout, generator=g).double().requires_grad_(True)
+    gy = torch.randn(b, cout, h, w, generator=g)
+    F.conv2d(x, wt, bias, padding=1).backward(gy.double())
+    xd, wd, gyd = _cl(x.detach().float()), _cl(wt.detach().float()), _cl(gy)
+
+    dx = grid._empty_cl(b, cin, h, w, _dev())
+    grid.conv3x3_dgrad_(gyd, wd, dx)
+    _close(dx, x.grad)
+    # mask epilogue (ReLU backward of the producing layer) and accumulation
+    mask = torch.randn(b, cin, h, w, generator=g)
+    base = torch.randn(b, cin, h, w, generator=g)
+    dx2 = _cl(base.clone())
+    grid.conv3x3_dgrad_(gyd, wd, dx2, mask=_cl(mask), accumulate=True)
+    _close(dx2, base.double() + x.grad * (mask > 0))
+
+    dw = torch.empty(cout, cin, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+    db = torch.empty(cout, device=_dev())
+    grid.conv3x3_wgrad_(gyd, xd, dw, db)
+    _close(dw, wt.grad)
+    _close(db, bias.grad)
+    dw0, db0 = dw.clone(), db.clone()
+    grid.conv3x3_wgrad_(gyd, xd, dw, db, accumulate=True)
+    assert torch.equal(dw, dw0 + dw0) and torch.equal(db, db0 + db0)          # same slabs, same order: exact doubling
+    grid.conv3x3_wgrad_(gyd, xd, dw, None)                                    # bias gradient optional
+    assert torch.equal(dw, dw0)
+
+
+def test_conv3x3_is_deterministic():
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(3)
+    x, wt, gy = _cl(torch.randn(1, 256, 32, 32, generator=g)), _cl(torch.randn(512, 256, 3, 3, generator=g)), _cl(torch.randn(1, 512, 32, 32, generator=g))
+    outs = []
+    for _ in range(2):
+        y = grid._empty_cl(1, 512, 32, 32, _dev())
+        dx = grid._empty_cl(1, 256, 32, 32, _dev())
+        dw = torch.empty_like(wt)
+        grid.conv3x3_fwd_(x, wt, None, y)
+        grid.conv3x3_dgrad_(gy, wt, dx)
+        grid.conv3x3_wgrad_(gy, x, dw, None)
+        outs.append((y, dx, dw))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,mid,cout,hw", [(32, 32, 32, 64), (64, 128, 128, 32), (512, 256, 256, 16)])
+def test_conv_chain_matches_torch_autograd(cin, mid, cout, hw):
+    """conv1 -> ReLU -> conv2 -> ReLU with the fused ReLU-backward (mask in the data-gradient epilogue) against the
+    plain composition differentiated by torch in float64."""
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(cin + cout)
+    c1, c2 = torch.nn.Conv2d(cin, mid, 3, padding=1), torch.nn.Conv2d(mid, cout, 3, padding=1)
+    with torch.no_grad():
+        for c in (c1, c2):
+            c.bias.copy_(torch.randn(c.bias.shape, generator=g) * 0.1)
+    x = torch.randn(2, cin, hw, hw, generator=g)
+    gout = torch.randn(2, cout, hw, hw, generator=g)
+    import copy
+    r1, r2 = copy.deepcopy(c1).double(), copy.deepcopy(c2).double()
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(r2(F.relu(r1(xr))))
+    yr.backward(gout.double())
+
+    c1, c2 = (c.to(_dev()).to(memory_format=torch.channels_last) for c in (c1, c2))
+    xg = _cl(x).requires_grad_(True)
+    y = grid.conv3x3_chain(xg, (c1, c2))
+    y.backward(_cl(gout))
+    _close(y, yr.detach())
+    # a ReLU decision that flips under fp32 rounding moves single entries; judge gradients in L2 as well
+    for got, want in ((xg.grad, xr.grad), (c1.weight.grad, r1.weight.grad), (c1.bias.grad, r1.bias.grad),
+                      (c2.weight.grad, r2.weight.grad), (c2.bias.grad, r2.bias.grad)):
+        want = want.double()
+        diff = got.detach().cpu().double() - want
+        assert diff.abs().max().item() <= 1e-3 * want.abs().max().item()
+        assert diff.norm().item() <= 1e-4 * want.norm().item()
+
+
+def test_conv_module_path_uses_hip_and_accumulates_directly():
+    """conv_bias_act on a 3x3 conv: same numbers as torch's module, weight.grad keeps the parameter's channels_last
+    layout, and with direct accumulation the gradient lands in the existing .grad buffers (the trainer's bucket)."""
+    from tomosar2height_amd import grid, mlp
+    g = torch.Generator().manual_seed(11)
+    conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(_dev()).to(memory_format=torch.channels_last)
+    x = _cl(torch.randn(1, 32, 64, 64, generator=g)).requires_grad_(True)
+    gout = _cl(torch.randn(1, 64, 64, 64, generator=g))
+    assert grid.conv3x3_supported(x, conv)
+    y = grid.conv_bias_act(x, conv, relu=True)
+    y.backward(gout)
+    got = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    x.grad = None
+    conv.zero_grad()
+    yr = F.relu(conv(x))
+    yr.backward(gout)
+    for a, b in zip(got, (yr.detach(), x.grad, conv.weight.grad, conv.bias.grad)):
+        _close(a, b.cpu(), tol=1e-4)
+    # direct accumulation into pre-existing gradient buffers
+    wbuf, bbuf = conv.weight.grad, conv.bias.grad
+    w0, b0 = wbuf.clone(), bbuf.clone()
+    with mlp.direct_grad_accumulation(True):
+        grid.conv_bias_act(x, conv, relu=True).backward(gout)
+    assert conv.weight.grad is wbuf and conv.bias.grad is bbuf
+    _close(wbuf - w0, got[2].cpu(), tol=1e-6)
+    _close(bbuf - b0, got[3].cpu(), tol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 32, 64), (32, 32, 33), (256, 512, 8)])
+def test_conv1x1_on_gemm_kernels(cin, cout, hw):
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(cin * cout)
+    conv = torch.nn.Conv2d(cin, cout, 1)
+    x = torch.randn(2, cin, hw, hw, generator=g)
+    gout = torch.randn(2, cout, hw, hw, generator=g)
+    import copy
+    ref = copy.deepcopy(conv).double()
+    xr = x.double().requires_grad_(True)
+    ref(xr).backward(gout.double())
+    conv = conv.to(_dev()).to(memory_format=torch.channels_last)
+    xg = _cl(x).requires_grad_(True)
+    y = grid.conv1x1(xg, conv)
+    y.backward(_cl(gout))
+    _close(y, ref(xr).detach())
+    _close(xg.grad, xr.grad)
+    _close(conv.weight.grad, ref.weight.grad)
+    _close(conv.bias.grad, ref.bias.grad)
+
+
+def test_conv3x3_argument_errors():
+    from tomosar2height_amd import _lib, grid
+    x = grid._empty_cl(1, 32, 12, 16, _dev())
+    w = torch.empty(32, 32, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+    y = grid._empty_cl(1, 32, 12, 16, _dev())
+    with pytest.raises(RuntimeError, match="powers of two"):
+        grid.conv3x3_fwd_(x, w, None, y)
+    x8 = grid._empty_cl(1, 8, 16, 16, _dev())
+    w8 = torch.empty(32, 8, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        grid.conv3x3_fwd_(x8, w8, None, grid._empty_cl(1, 32, 16, 16, _dev()))
+    # the module-level entry falls back to MIOpen for unsupported geometry instead of raising
+    conv = torch.nn.Conv2d(8, 32, 3, padding=1).to(_dev())
+    assert not grid.conv3x3_supported(x8, conv)
+    assert grid.conv_bias_act(x8, conv).shape == (1, 32, 16, 16)
+    assert _lib.load().t2h_conv3x3_fwd_workspace_bytes(1, 32, 32, 512, 512) > 0
+    assert _lib.load().t2h_conv3x3_fwd_workspace_bytes(1, 512, 512, 32, 64) == 0

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -47,6 +47,13 @@ SIGNATURES = {
     "t2h_head1x1_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_nhwc_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_relu_mask": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "t2h_conv3x3_fwd_workspace_bytes": (_sz, [_i] * 5),
+    "t2h_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_conv3x3_dgrad_workspace_bytes": (_sz, [_i] * 5),
+    "t2h_conv3x3_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
+    "t2h_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),

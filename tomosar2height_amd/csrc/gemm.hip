@@ -20,60 +20,11 @@
 // deterministic).
 #include "t2h_common.h"
 #include "gemm_args.h"
+#include "gemm_tile.h"
 
 namespace t2h {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-
-constexpr int kPad = 4;
-constexpr int kMinBK = 16;
-
-// A(m,k): A_KC ? A[m*lda + k] : A[k*lda + m];   B(k,n): B_KC ? B[n*ldb + k] : B[k*ldb + n]
-template <int ROWS, int NT, bool KC, int BK>
-struct TileLoader {
-    static constexpr int TOTAL = ROWS * BK / 4;             // float4s per tile
-    static constexpr int PER = (TOTAL + NT - 1) / NT;
-    float4 r[PER];
-
-    __device__ inline void load(const float *__restrict__ src, int ld, int row0, int rows, int k0, int kend, int tid,
-                                bool relu) {
-#pragma unroll
-        for (int f = 0; f < PER; ++f) {
-            int idx = tid + f * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TOTAL % NT == 0 || idx < TOTAL) {
-                if (KC) {
-                    int i = idx / (BK / 4), kc = idx % (BK / 4);
-                    int m = row0 + i, k = k0 + kc * 4;
-                    if (m < rows && k < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)m * ld + k);
-                } else {
-                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
-                    int m = row0 + ic * 4, kk = k0 + k;
-                    if (m < rows && kk < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)kk * ld + m);
-                }
-            }
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            r[f] = v;
-        }
-    }
-    __device__ inline void store(float *__restrict__ lds, int tid) const {   // lds: [BK][ROWS + kPad]
-#pragma unroll
-        for (int f = 0; f < PER; ++f) {
-            int idx = tid + f * NT;
-            if (TOTAL % NT == 0 || idx < TOTAL) {
-                if (KC) {
-                    int i = idx / (BK / 4), kc = idx % (BK / 4);
-                    float *p = lds + (kc * 4) * (ROWS + kPad) + i;
-                    p[0] = r[f].x; p[ROWS + kPad] = r[f].y; p[2 * (ROWS + kPad)] = r[f].z; p[3 * (ROWS + kPad)] = r[f].w;
-                } else {
-                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
-                    *reinterpret_cast<float4 *>(lds + k * (ROWS + kPad) + ic * 4) = r[f];
-                }
-            }
-        }
-    }
-};
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int MINW = 1,
           int MODE = 0>
@@ -418,6 +369,14 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
 
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
+int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
+                        float *out, hipStream_t s) {
+    long long total = (long long)rows * cols;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, slabs, splits, stride, rows,
+                       cols, ld_out, accumulate, out);
+    return check_launch("reduce_slabs");
+}
+
 }  // namespace t2h
 
 using namespace t2h;
@@ -537,11 +496,7 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
 #undef T2H_WG
         if (rc) return rc;
     }
-    long long total = (long long)N * K;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, slab, p.splits,
-                       (long long)N * K, N, K, K, accumulate, dw);
-    if (db)
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, s, colslab, p.splits,
-                           (long long)N, 1, N, N, accumulate, db);
-    return check_launch("linear_wgrad/reduce");
+    if (int rc = launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, s)) return rc;
+    if (db) return launch_reduce_slabs(colslab, p.splits, (long long)N, 1, N, N, accumulate, db, s);
+    return T2H_OK;
 }

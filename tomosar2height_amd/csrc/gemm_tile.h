@@ -1,0 +1,128 @@
+// Building blocks shared by the fp32 MFMA kernels (gemm.hip: per-point GEMMs; conv.hip: implicit-GEMM 3x3 convs):
+// the global -> register -> LDS tile loader, one 16-deep MFMA slab and the float4 epilogue.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace t2h {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kPad = 4;
+constexpr int kMinBK = 16;
+
+// A(m,k): A_KC ? A[m*lda + k] : A[k*lda + m];   B(k,n): B_KC ? B[n*ldb + k] : B[k*ldb + n]
+template <int ROWS, int NT, bool KC, int BK>
+struct TileLoader {
+    static constexpr int TOTAL = ROWS * BK / 4;             // float4s per tile
+    static constexpr int PER = (TOTAL + NT - 1) / NT;
+    float4 r[PER];
+
+    __device__ inline void load(const float *__restrict__ src, int ld, int row0, int rows, int k0, int kend, int tid,
+                                bool relu) {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            int idx = tid + f * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TOTAL % NT == 0 || idx < TOTAL) {
+                if (KC) {
+                    int i = idx / (BK / 4), kc = idx % (BK / 4);
+                    int m = row0 + i, k = k0 + kc * 4;
+                    if (m < rows && k < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)m * ld + k);
+                } else {
+                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
+                    int m = row0 + ic * 4, kk = k0 + k;
+                    if (m < rows && kk < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)kk * ld + m);
+                }
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            r[f] = v;
+        }
+    }
+    __device__ inline void store(float *__restrict__ lds, int tid) const {   // lds: [BK][ROWS + kPad]
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            int idx = tid + f * NT;
+            if (TOTAL % NT == 0 || idx < TOTAL) {
+                if (KC) {
+                    int i = idx / (BK / 4), kc = idx % (BK / 4);
+                    float *p = lds + (kc * 4) * (ROWS + kPad) + i;
+                    p[0] = r[f].x; p[ROWS + kPad] = r[f].y; p[2 * (ROWS + kPad)] = r[f].z; p[3 * (ROWS + kPad)] = r[f].w;
+                } else {
+                    int k = idx / (ROWS / 4), ic = idx % (ROWS / 4);
+                    *reinterpret_cast<float4 *>(lds + k * (ROWS + kPad) + ic * 4) = r[f];
+                }
+            }
+        }
+    }
+};
+
+
+// One BK-deep slab of v_mfma_f32_32x32x2_f32 on k-major LDS tiles (row strides SA / SB floats).  a_base / b_base
+// already point at this lane's first element: slab + (lane >> 5) * S + wave offset + (lane & 31).
+template <int TM, int TN, int SA, int SB, int BK>
+__device__ inline void mfma_slab_f32(const float *a_base, const float *b_base, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = a_base[kp * 2 * SA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = b_base[kp * 2 * SB + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+struct EpilogueArgs {
+    float *C;
+    const float *bias, *mask;
+    int M, N, ldc, ldm;
+    bool accum, relu_out;
+};
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
+// transposes one 32x32 tile at a time through its private LDS patch (32 x 36 floats) so that global traffic (store,
+// mask load, accumulate load) is 16 bytes per lane.  row_base / col_base: first row / column of this wave's tiles.
+template <int TM, int TN>
+__device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int lane, int row_base, int col_base,
+                                       const EpilogueArgs &e) {
+    constexpr int EP = 36;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = row_base + i * 32, col0 = col_base + j * 32;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                patch[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[i][j][q];
+            const int col = col0 + ec;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + col);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = row0 + pass * 8 + er;
+                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
+                if (row < e.M && col < e.N) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (e.mask) {
+                        float4 mk = *reinterpret_cast<const float4 *>(e.mask + (size_t)row * e.ldm + col);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (e.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    float4 *dst = reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col);
+                    if (e.accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *dst = v;
+                }
+            }
+        }
+}
+
+// reduce_slabs_kernel of gemm.hip: out[r, c] = [out +] sum_z slabs[z][r * cols + c] in a fixed order
+int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
+                        float *out, hipStream_t s);
+
+}  // namespace t2h

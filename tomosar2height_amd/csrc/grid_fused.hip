@@ -27,6 +27,19 @@ __global__ __launch_bounds__(kT) void bias_relu_fwd_kernel(float *__restrict__ y
     reinterpret_cast<float4 *>(y)[i] = v;
 }
 
+// gm = g * (y > 0): the ReLU backward in front of the conv3x3 data / weight gradients (conv.hip), whose weight-gradient
+// kernel produces the bias gradient itself
+__global__ __launch_bounds__(kT) void relu_mask_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                       float *__restrict__ gm, long long n4) {
+    long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    if (i >= n4) return;
+    float4 gv = reinterpret_cast<const float4 *>(g)[i];
+    float4 yv = reinterpret_cast<const float4 *>(y)[i];
+    gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f;
+    gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+    reinterpret_cast<float4 *>(gm)[i] = gv;
+}
+
 // one workgroup = kRowsPerBlock pixels; thread (slot, lane): lane covers float4 channel group(s), slot strides pixels
 constexpr int kRowsPerBlock = 256;
 __global__ __launch_bounds__(kT) void bias_relu_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y,
@@ -270,6 +283,16 @@ T2H_API int t2h_bias_relu_fwd(float *y, const float *bias, int64_t P, int C, int
     hipLaunchKernelGGL(bias_relu_fwd_kernel, dim3((unsigned)((n4 + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), y, bias, n4,
                        C / 4, relu);
     return check_launch("bias_relu_fwd");
+}
+
+T2H_API int t2h_relu_mask(const float *g, const float *y, float *g_masked, int64_t n, t2h_stream_t stream) {
+    if (!g || !y || !g_masked) return fail(T2H_ERR_ARG, "relu_mask: null pointer");
+    if (n < 0 || n % 4 != 0 || (uintptr_t)g % 16 || (uintptr_t)y % 16 || (uintptr_t)g_masked % 16)
+        return fail(T2H_ERR_ARG, "relu_mask: n must be a multiple of 4 and the pointers 16-byte aligned");
+    if (n == 0) return T2H_OK;
+    long long n4 = n / 4;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n4 + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), g, y, g_masked, n4);
+    return check_launch("relu_mask");
 }
 
 T2H_API size_t t2h_bias_relu_bwd_workspace_bytes(int64_t P, int C) {

@@ -43,11 +43,15 @@ class _PointGridLevel(nn.Module):
 
     channels_last = False
 
-    def _conv_relu(self, conv, x):
-        """``F.relu(conv(x))``; in channels_last mode the bias add + ReLU (and their backward) run fused (grid.py)."""
+    def _conv_pair(self, x):
+        """``F.relu(conv2(F.relu(conv1(x))))`` (alto.py:98-99, 229-230); in channels_last mode on the implicit-GEMM
+        kernels with fused bias / ReLU / ReLU-backward (grid.py, csrc/conv.hip)."""
         if self.channels_last:
-            return grid.conv_bias_act(x, conv, relu=True)
-        return F.relu(conv(x))
+            return grid.conv3x3_chain(x, (self.conv1, self.conv2))
+        return F.relu(self.conv2(F.relu(self.conv1(x))))
+
+    def _conv1x1(self, conv, x):
+        return grid.conv1x1(x, conv) if self.channels_last else conv(x)
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
         sampled = ops.sample_plane(tile, plane)                                   # alto.py:121-122 / 245-246
@@ -76,11 +80,11 @@ class DownConv(_PointGridLevel):
             self.conv1x1 = conv1x1(in_channels, out_channels)
 
     def forward(self, tile: TileIndex, grid_in, prev_conv=None, c_last=None):
-        g = self._conv_relu(self.conv2, self._conv_relu(self.conv1, grid_in))
+        g = self._conv_pair(grid_in)
         if prev_conv is not None:
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
             res_in = self.pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
-            g = g + self.conv1x1(res_in)
+            g = g + self._conv1x1(self.conv1x1, res_in)
         raster, c = self._exchange(tile, g, c_last)
         pooled = self.pool(raster) if self.pooling else raster
         return pooled, raster, g, c
@@ -107,11 +111,11 @@ class UpConv(_PointGridLevel):
         self.conv2 = conv3x3(out_channels, out_channels)
 
     def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last):
-        up = self.upconv_noup(from_up) if self.is_last else self.upconv(from_up)    # alto.py:215-218
+        up = self._conv1x1(self.upconv_noup, from_up) if self.is_last else self.upconv(from_up)    # alto.py:215-218
         g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
-        g = self._conv_relu(self.conv2, self._conv_relu(self.conv1, g))
+        g = self._conv_pair(g)
         if prev_conv is not None:
-            g = g + self.conv1x1(prev_conv)                                         # alto.py:233-236
+            g = g + self._conv1x1(self.conv1x1, prev_conv)                          # alto.py:233-236
         if self.is_last:                                                            # alto.py:241-242
             return g, g, c_last
         raster, c = self._exchange(tile, g, c_last)
@@ -173,6 +177,8 @@ class UNet(nn.Module):
             skips.append(raster)
         for i, up in enumerate(self.up_convs):
             plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c)
+        if self.down_convs[0].channels_last:
+            return grid.conv1x1(plane, self.conv_final)
         return self.conv_final(plane)
 
     def forward(self, p, x, c):

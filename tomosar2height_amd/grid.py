@@ -1,8 +1,10 @@
 """Grid-side fused operators (first step): the elementwise passes around the MIOpen convolutions of the
 ALTO U-Net and the pixel decoder as HIP kernels on channels_last (NHWC) tensors.
 
-    conv_bias_act(x, conv, relu)   conv (MIOpen, bias-free call) + fused bias/ReLU; backward = fused ReLU-mask +
-                                   bias gradient, then MIOpen's data / weight gradients
+    conv_bias_act(x, conv, relu)   3x3 stride-1 convs: implicit-GEMM MFMA kernels of csrc/conv.hip (forward with fused
+                                   bias/ReLU, data gradient, deterministic weight + bias gradient); any other conv:
+                                   MIOpen (bias-free call) + fused bias/ReLU passes around it
+    conv1x1(x, conv)               1x1 convs as the per-point GEMM kernels on the [pixels, C] rows of the NHWC plane
     head1x1(xs, conv4)             torch.cat(xs, 1) -> 1x1 conv to one channel without the concat (pixel.py:31)
     upsample_bilinear_cl(x, size)  F.interpolate(bilinear, align_corners=True) on channels_last planes (pixel.py:107)
 
@@ -10,11 +12,15 @@ Every function requires channels_last device tensors; callers (alto.py / pixel.p
 runs in channels_last mode and otherwise keep the plain torch composition.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, mlp
+
+# A/B switch: T2H_HIP_CONV=0 keeps every convolution on MIOpen
+USE_HIP_CONV = os.environ.get("T2H_HIP_CONV", "1") != "0"
 
 
 def is_cl(x: torch.Tensor) -> bool:
@@ -24,6 +30,10 @@ def is_cl(x: torch.Tensor) -> bool:
 
 def _as_cl(x: torch.Tensor) -> torch.Tensor:
     return x if is_cl(x) else x.contiguous(memory_format=torch.channels_last)
+
+
+def _empty_cl(b, c, h, w, device) -> torch.Tensor:
+    return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
 
 
 # ------------------------------------------------------------------------------------------------ conv + bias + relu
@@ -58,12 +68,189 @@ class _ConvBiasAct(torch.autograd.Function):
         return dx, dw, dbias, None, None, None
 
 
-def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True) -> torch.Tensor:
-    """``relu(conv(x))`` (or ``conv(x)``) with the bias add, the ReLU and their backward fused into one pass each."""
+# ------------------------------------------------------------------------------------------------ conv3x3 (HIP)
+def _pow2(v: int) -> bool:
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def _w_cl(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] weight whose memory is [Cout][3][3][Cin] (what the kernels read)."""
+    return w if w.permute(0, 2, 3, 1).is_contiguous() else w.contiguous(memory_format=torch.channels_last)
+
+
+def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
+    return (USE_HIP_CONV and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4 and x.is_cuda
+            and x.dtype == torch.float32 and _pow2(x.shape[2]) and _pow2(x.shape[3]))
+
+
+def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
+    """y [B,Cout,H,W] (channels_last) = [y +] act(conv3x3(x, w) + bias); raw kernel call on NHWC-dense tensors."""
+    b, cin, h, wd = x.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    nws = lib.t2h_conv3x3_fwd_workspace_bytes(b, h, wd, cin, cout)
+    ws = _lib.workspace(nws, x.device)
+    flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
+    _lib.call("t2h_conv3x3_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
+              b, h, wd, cin, cout, flags, _lib.ptr(ws), nws, _lib.stream(),
+              nbytes=4 * (x.numel() + y.numel() + w.numel()), flops=2 * 9 * cin * cout * b * h * wd,
+              tag=f"t2h_conv3x3_fwd[{cin}->{cout},{h}x{wd}]")
+    return y
+
+
+def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
+    b, cout, h, wd = gy.shape
+    cin = w.shape[1]
+    lib = _lib.load()
+    nws = lib.t2h_conv3x3_dgrad_workspace_bytes(b, h, wd, cin, cout)
+    ws = _lib.workspace(nws, gy.device)
+    _lib.call("t2h_conv3x3_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(mask) if mask is not None else None,
+              b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
+              nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel()),
+              flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
+    return dx
+
+
+def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
+    b, cout, h, wd = gy.shape
+    cin = x.shape[1]
+    lib = _lib.load()
+    nws = lib.t2h_conv3x3_wgrad_workspace_bytes(b, h, wd, cin, cout)
+    ws = _lib.workspace(nws, gy.device)
+    _lib.call("t2h_conv3x3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
+              b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
+              nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
+              tag=f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
+
+
+class _Conv3x3(torch.autograd.Function):
+    """relu?(conv3x3(x) + bias) on csrc/conv.hip.  ``mask_input``: x is a ReLU output consumed by this conv only, so the
+    data gradient is returned already multiplied by (x > 0); the producer is then built with ``grad_premasked`` and
+    skips its own ReLU-backward pass (the pair is set up by ``conv3x3_chain``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool, mask_input: bool, grad_premasked: bool):
+        x = _as_cl(x)
+        w = _w_cl(weight)
+        b, _, h, wd = x.shape
+        y = _empty_cl(b, w.shape[0], h, wd, x.device)
+        conv3x3_fwd_(x, w, bias, y, relu=relu)
+        need_y = relu and not grad_premasked
+        ctx.save_for_backward(x, weight, bias, y if need_y else None)
+        ctx.conf = (relu, mask_input, grad_premasked)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, y = ctx.saved_tensors
+        relu, mask_input, grad_premasked = ctx.conf
+        g = _as_cl(g)
+        w = _w_cl(weight)
+        if relu and not grad_premasked:
+            gm = torch.empty_like(g, memory_format=torch.channels_last)
+            _lib.call("t2h_relu_mask", _lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), g.numel(), _lib.stream(),
+                      nbytes=12 * g.numel())
+        else:
+            gm = g
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            conv3x3_dgrad_(gm, w, dx, mask=x if mask_input else None)
+        wg, bg = weight.grad, (bias.grad if bias is not None else None)
+        if (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
+                and (bias is None or (bg is not None and bg.is_contiguous()))):
+            conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)          # straight into the gradient bucket (trainer.py)
+            return dx, None, None, None, None, None
+        dw = torch.empty_like(weight, memory_format=torch.channels_last)
+        db = torch.empty_like(bias) if bias is not None else None
+        conv3x3_wgrad_(gm, x, dw, db)
+        return dx, dw, db, None, None, None
+
+
+def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True, mask_input: bool = False,
+                  grad_premasked: bool = False) -> torch.Tensor:
+    """``relu(conv(x))`` (or ``conv(x)``).  3x3 / stride 1 / padding 1 convs with 16-aligned channel counts run on the
+    implicit-GEMM kernels of csrc/conv.hip; other convs stay on MIOpen with the bias add, the ReLU and their backward
+    fused into one pass each."""
+    if conv3x3_supported(x, conv):
+        return _Conv3x3.apply(x, conv.weight, conv.bias, relu, mask_input, grad_premasked)
+    if mask_input or grad_premasked:
+        raise ValueError("conv_bias_act: mask_input / grad_premasked need the HIP conv3x3 path")
     if conv.bias is None or conv.out_channels % 4 or conv.groups != 1 or conv.dilation != (1, 1) or not x.is_cuda:
         y = conv(x)
         return F.relu(y) if relu else y
     return _ConvBiasAct.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, relu)
+
+
+def conv3x3_chain(x: torch.Tensor, convs, relu_last: bool = True) -> torch.Tensor:
+    """``relu(conv_n(... relu(conv_1(x))))`` where every intermediate activation feeds the next conv only (the
+    conv1 -> conv2 pairs of alto.py:98-99,229-230): each data gradient applies the previous ReLU's mask in its
+    epilogue, so only the last ReLU needs a backward pass of its own."""
+    convs = list(convs)
+    fused = all(conv3x3_supported(x, c) for c in convs)
+    for i, conv in enumerate(convs):
+        last = i == len(convs) - 1
+        if fused:
+            x = conv_bias_act(x, conv, relu=relu_last or not last, mask_input=i > 0, grad_premasked=not last)
+        else:
+            x = conv_bias_act(x, conv, relu=relu_last or not last)
+    return x
+
+
+class _Conv1x1(torch.autograd.Function):
+    """1x1 convolution = the per-point GEMM kernels (always exact fp32 here) on the [pixels, C] rows of the NHWC plane."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _as_cl(x)
+        b, cin, h, wd = x.shape
+        cout, m = weight.shape[0], b * h * wd
+        w2 = weight.reshape(cout, cin).contiguous()
+        y = _empty_cl(b, cout, h, wd, x.device)
+        _lib.call("t2h_linear_fwd", _lib.ptr(x), cin, _lib.ptr(w2), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
+                  cout, m, cin, cout, 0, _lib.stream(), nbytes=4 * (m * cin + m * cout + cin * cout),
+                  flops=2 * m * cin * cout, tag=f"t2h_linear_fwd[K={cin},N={cout}]")
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias = ctx.saved_tensors
+        g = _as_cl(g)
+        b, cin, h, wd = x.shape
+        cout, m = weight.shape[0], b * h * wd
+        w2 = weight.reshape(cout, cin).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_cl(b, cin, h, wd, x.device)
+            _lib.call("t2h_linear_dgrad", _lib.ptr(g), cout, _lib.ptr(w2), _lib.ptr(dx), cin, m, cin, cout, None, 0, 0,
+                      _lib.stream(), nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
+                      tag=f"t2h_linear_dgrad[N={cout},K={cin}]")
+        wg, bg = weight.grad, (bias.grad if bias is not None else None)
+        direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
+                  and (bias is None or (bg is not None and bg.is_contiguous())))
+        dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
+        db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
+        lib = _lib.load()
+        nws = lib.t2h_linear_wgrad_workspace_bytes(m, cin, cout)
+        ws = _lib.workspace(nws, g.device)
+        _lib.call("t2h_linear_wgrad", _lib.ptr(g), cout, _lib.ptr(x), cin, m, cin, cout, _lib.ACCUM if direct else 0,
+                  _lib.ptr(dw), _lib.ptr(db) if db is not None else None, _lib.ptr(ws), nws, _lib.stream(),
+                  nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
+                  tag=f"t2h_linear_wgrad[N={cout},K={cin}]")
+        return (dx, None, None) if direct else (dx, dw, db)
+
+
+def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
+    """1x1 convolution (alto.py conv1x1 residuals, upconv_noup, conv_final) on the per-point GEMM kernels."""
+    ok = (USE_HIP_CONV and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+          and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and x.is_cuda
+          and x.dtype == torch.float32)
+    if not ok:
+        return conv(x)
+    return _Conv1x1.apply(x, conv.weight, conv.bias)
 
 
 # ------------------------------------------------------------------------------------------------ concat-free 1x1 head
@@ -126,7 +313,7 @@ class _UpsampleCL(torch.autograd.Function):
     def forward(ctx, x, size: int, addend):
         x = _as_cl(x)
         b, c, h, w = x.shape
-        out = torch.empty(b, c, size, size, dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+        out = _empty_cl(b, c, size, size, x.device)
         if addend is not None:
             addend = _as_cl(addend)
             if addend.shape != out.shape:
@@ -142,7 +329,7 @@ class _UpsampleCL(torch.autograd.Function):
     def backward(ctx, g):
         b, c, h, w, size = ctx.shape
         g = _as_cl(g)
-        gin = torch.empty(b, c, h, w, dtype=torch.float32, device=g.device).contiguous(memory_format=torch.channels_last)
+        gin = _empty_cl(b, c, h, w, g.device)
         _lib.call("t2h_upsample_bilinear_nhwc_bwd", _lib.ptr(g), b, c, h, w, size, size, _lib.ptr(gin), _lib.stream(),
                   nbytes=4 * (g.numel() + gin.numel()), tag="t2h_upsample_bilinear_bwd")
         return gin, None, (g if ctx.has_addend else None)
