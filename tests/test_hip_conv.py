@@ -134,6 +134,45 @@ def test_conv_chain_matches_torch_autograd(cin, mid, cout, hw):
         assert diff.norm().item() <= 1e-4 * want.norm().item()
 
 
+@pytest.mark.parametrize("need_x", [True, False])
+def test_fused_conv_decoder_matches_torch_autograd(need_x):
+    """ConvDecoder (pixel.py:20-32) as one autograd node -- head gradient written ReLU-masked, conv data gradients
+    accumulated onto it -- against cat + convs differentiated by torch in float64."""
+    import copy
+    from tomosar2height_amd.decoder.pixel import ConvDecoder
+    torch.manual_seed(5)
+    dec = ConvDecoder(32, 1)
+    with torch.no_grad():
+        for c in (dec.conv1, dec.conv2, dec.conv3, dec.conv4):
+            c.bias.uniform_(-0.2, 0.2)
+    ref = copy.deepcopy(dec).double()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 32, 32, 32, generator=g)
+    gout = torch.randn(2, 1, 32, 32, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gout.double())
+
+    dec = dec.to(_dev()).to(memory_format=torch.channels_last)
+    dec.channels_last = True
+    xg = _cl(x).requires_grad_(need_x)
+    y = dec(xg)
+    assert type(y.grad_fn).__name__ == "_ConvDecoderBackward"
+    y.backward(gout.to(_dev()))
+    _close(y, yr.detach())
+    pairs = [(getattr(dec, n).weight.grad, getattr(ref, n).weight.grad) for n in ("conv1", "conv2", "conv3", "conv4")]
+    pairs += [(getattr(dec, n).bias.grad, getattr(ref, n).bias.grad) for n in ("conv1", "conv2", "conv3", "conv4")]
+    if need_x:
+        pairs.append((xg.grad, xr.grad))
+    else:
+        assert xg.grad is None
+    for got, want in pairs:
+        want = want.double()
+        diff = got.detach().cpu().double() - want
+        assert diff.abs().max().item() <= 1e-3 * want.abs().max().item()       # single ReLU flips under fp32 rounding
+        assert diff.norm().item() <= 1e-4 * want.norm().item()
+
+
 def test_conv_module_path_uses_hip_and_accumulates_directly():
     """conv_bias_act on a 3x3 conv: same numbers as torch's module, weight.grad keeps the parameter's channels_last
     layout, and with direct accumulation the gradient lands in the existing .grad buffers (the trainer's bucket)."""

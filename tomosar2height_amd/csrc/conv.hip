@@ -452,7 +452,5 @@ T2H_API int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float 
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(NT), 0, s, a);
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
     const int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
-    if (int rc = launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, s)) return rc;
-    if (db) return launch_reduce_slabs(colslab, p.splits, (long long)Cout, 1, Cout, Cout, accumulate, db, s);
-    return T2H_OK;
+    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, colslab, db, s);
 }

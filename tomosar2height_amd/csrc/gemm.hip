@@ -243,31 +243,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
 // out[e] = [out[e] +] sum_z slabs[z][e].  16 consecutive elements x 16 split-lanes per workgroup: lane q sums the
 // splits z = q, q+16, ... in order (4 loads in flight), the 16 lane sums are then added in lane order through LDS:
 // a fixed summation tree, so the result is deterministic, and the chain per thread is splits/16 loads deep.
+// Workgroups past the matrix part reduce the bias-gradient slabs (col_slabs [splits][rows] -> col_out[rows]) in the
+// same launch.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
                                                           int rows, int cols, int ld_out, int accumulate,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, const float *__restrict__ col_slabs,
+                                                          float *__restrict__ col_out, unsigned matrix_blocks) {
     __shared__ float red[256];
     const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-    long long e = (long long)blockIdx.x * 16 + el;
-    const long long total = (long long)rows * cols;
+    const bool colpart = blockIdx.x >= matrix_blocks;
+    const float *src = colpart ? col_slabs : slabs;
+    const long long st = colpart ? rows : stride;
+    const long long total = colpart ? rows : (long long)rows * cols;
+    long long e = (long long)(colpart ? blockIdx.x - matrix_blocks : blockIdx.x) * 16 + el;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < total) {
         int z = q;
         for (; z + 48 < splits; z += 64) {
-            s0 += slabs[(size_t)z * stride + e];
-            s1 += slabs[(size_t)(z + 16) * stride + e];
-            s2 += slabs[(size_t)(z + 32) * stride + e];
-            s3 += slabs[(size_t)(z + 48) * stride + e];
+            s0 += src[(size_t)z * st + e];
+            s1 += src[(size_t)(z + 16) * st + e];
+            s2 += src[(size_t)(z + 32) * st + e];
+            s3 += src[(size_t)(z + 48) * st + e];
         }
-        for (; z < splits; z += 16) s0 += slabs[(size_t)z * stride + e];
+        for (; z < splits; z += 16) s0 += src[(size_t)z * st + e];
     }
     red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (q == 0 && e < total) {
         float t = red[el];
         for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
-        int r = (int)(e / cols), c = (int)(e % cols);
-        float *dst = out + (size_t)r * ld_out + c;
+        float *dst = colpart ? col_out + e : out + (size_t)(e / cols) * ld_out + (e % cols);
         *dst = accumulate ? *dst + t : t;
     }
 }
@@ -370,10 +375,11 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, hipStream_t s) {
-    long long total = (long long)rows * cols;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, slabs, splits, stride, rows,
-                       cols, ld_out, accumulate, out);
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s) {
+    const long long total = (long long)rows * cols;
+    const unsigned mb = (unsigned)((total + 15) / 16), cb = col_out ? (unsigned)((rows + 15) / 16) : 0u;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
+                       accumulate, out, col_slabs, col_out, mb);
     return check_launch("reduce_slabs");
 }
 
@@ -496,7 +502,5 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
 #undef T2H_WG
         if (rc) return rc;
     }
-    if (int rc = launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, s)) return rc;
-    if (db) return launch_reduce_slabs(colslab, p.splits, (long long)N, 1, N, N, accumulate, db, s);
-    return T2H_OK;
+    return launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, colslab, db, s);
 }

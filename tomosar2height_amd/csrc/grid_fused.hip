@@ -125,9 +125,10 @@ __global__ __launch_bounds__(kT) void head1x1_fwd_kernel(HeadArgs a, const float
     if (p < P && lane == 0) out[p] = acc + (bias ? bias[0] : 0.f);
 }
 
-// dx_i[p, c] = [dx_i +] g[p] * w_i[c]
+// dx_i[p, c] = [dx_i +] g[p] * w_i[c] (* (x_i[p, c] > 0) when bit 8+i of flags is set); bit 0 of flags = accumulate
 __global__ __launch_bounds__(kT) void head1x1_dgrad_kernel(HeadArgs a, const float *__restrict__ w, const float *__restrict__ g,
-                                                           long long P, int accumulate) {
+                                                           long long P, int flags) {
+    const int accumulate = flags & 1;
     long long t = (long long)blockIdx.x * kT + threadIdx.x;
     long long p = t >> 4;
     int lane = threadIdx.x & 15;
@@ -140,6 +141,11 @@ __global__ __launch_bounds__(kT) void head1x1_dgrad_kernel(HeadArgs a, const flo
         for (int c = lane * 4; c < a.C[i]; c += 64) {
             float4 k = *reinterpret_cast<const float4 *>(wi + c);
             float4 v = make_float4(gp * k.x, gp * k.y, gp * k.z, gp * k.w);
+            if ((flags >> (8 + i)) & 1) {
+                float4 xv = *reinterpret_cast<const float4 *>(a.x[i] + p * a.C[i] + c);
+                v.x = xv.x > 0.f ? v.x : 0.f; v.y = xv.y > 0.f ? v.y : 0.f;
+                v.z = xv.z > 0.f ? v.z : 0.f; v.w = xv.w > 0.f ? v.w : 0.f;
+            }
             if (accumulate) { float4 o = *reinterpret_cast<float4 *>(row + c); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *reinterpret_cast<float4 *>(row + c) = v;
         }
@@ -345,7 +351,7 @@ T2H_API size_t t2h_head1x1_bwd_workspace_bytes(int64_t P, int Ctot) {
 }
 
 T2H_API int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *C, int n_in, const float *w, const float *g,
-                            int64_t P, int accumulate_dx, float *dw, float *dbias, void *workspace, size_t workspace_bytes,
+                            int64_t P, int dx_flags, float *dw, float *dbias, void *workspace, size_t workspace_bytes,
                             t2h_stream_t stream) {
     if (!x || !dx || !C || !w || !g || !dw || P < 1) return fail(T2H_ERR_ARG, "head1x1_bwd: bad argument");
     HeadArgs a;
@@ -355,7 +361,7 @@ T2H_API int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *
         return fail(T2H_ERR_WORKSPACE, "head1x1_bwd: workspace too small");
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(head1x1_dgrad_kernel, dim3((unsigned)((P * 16 + kT - 1) / kT)), dim3(kT), 0, s, a, w, g, (long long)P,
-                       accumulate_dx);
+                       dx_flags);
     int nblocks = (int)((P + kRowsPerBlock - 1) / kRowsPerBlock);
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(head1x1_wgrad_kernel, dim3(nblocks), dim3(kT), 0, s, a, g, (long long)P, partial);

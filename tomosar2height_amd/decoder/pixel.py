@@ -2,8 +2,8 @@
 
 ``PixelwiseDecoder.forward`` sums the feature planes, resamples them to the output raster with the HIP
 bilinear kernel (``ops.upsample_bilinear`` == ``F.interpolate(..., align_corners=True)``, image-plane add
-fused when it is already at output size) and runs the conv / per-pixel FC head.  The 3x3 convolutions stay on
-MIOpen.  Parameter names follow the reference: ``conv_decoder.conv{1..4}``,
+fused when it is already at output size) and runs the conv / per-pixel FC head.  In channels_last mode the 3x3
+convolutions run on the implicit-GEMM kernels of csrc/conv.hip, otherwise on MIOpen.  Parameter names follow the reference: ``conv_decoder.conv{1..4}``,
 ``conv_decoder_footprint.*``, ``fc_decoder.{blocks,fc_out}``.
 """
 import torch
@@ -30,11 +30,8 @@ class ConvDecoder(nn.Module):
 
     def forward(self, x):
         if self.channels_last and not self.leaky and x.is_cuda:
-            # fused bias+ReLU epilogues around the MIOpen convs and a concat-free 288 -> 1 head (grid.py)
-            x1 = grid.conv_bias_act(x, self.conv1)
-            x2 = grid.conv_bias_act(x1, self.conv2)
-            x3 = grid.conv_bias_act(x2, self.conv3)
-            return grid.head1x1([x, x1, x2, x3], self.conv4)
+            # implicit-GEMM 3x3 convs with fused bias/ReLU and a concat-free 288 -> 1 head as one autograd node (grid.py)
+            return grid.conv_decoder(x, self.conv1, self.conv2, self.conv3, self.conv4)
         x1 = self.act(self.conv1(x))
         x2 = self.act(self.conv2(x1))
         x3 = self.act(self.conv3(x2))

@@ -158,15 +158,22 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=torch.channels_last)
             conv3x3_dgrad_(gm, w, dx, mask=x if mask_input else None)
-        wg, bg = weight.grad, (bias.grad if bias is not None else None)
-        if (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
-                and (bias is None or (bg is not None and bg.is_contiguous()))):
-            conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)          # straight into the gradient bucket (trainer.py)
-            return dx, None, None, None, None, None
-        dw = torch.empty_like(weight, memory_format=torch.channels_last)
-        db = torch.empty_like(bias) if bias is not None else None
-        conv3x3_wgrad_(gm, x, dw, db)
+        dw, db = _conv3x3_param_grads(gm, x, weight, bias)
         return dx, dw, db, None, None, None
+
+
+def _conv3x3_param_grads(gm, x, weight, bias):
+    """Weight / bias gradient of one conv3x3: straight into the existing ``.grad`` buffers (the trainer's bucket) under
+    ``mlp.direct_grad_accumulation`` -- returns (None, None) then -- else as fresh tensors."""
+    wg, bg = weight.grad, (bias.grad if bias is not None else None)
+    if (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
+            and (bias is None or (bg is not None and bg.is_contiguous()))):
+        conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
+        return None, None
+    dw = torch.empty_like(weight, memory_format=torch.channels_last)
+    db = torch.empty_like(bias) if bias is not None else None
+    conv3x3_wgrad_(gm, x, dw, db)
+    return dw, db
 
 
 def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True, mask_input: bool = False,
@@ -259,43 +266,105 @@ def _ptr_array(tensors):
     return arr
 
 
+def _head_fwd(xs, weight, bias):
+    b, _, h, w = xs[0].shape
+    chans = [x.shape[1] for x in xs]
+    wflat = weight.reshape(-1).contiguous()
+    out = torch.empty(b, 1, h, w, dtype=torch.float32, device=xs[0].device)
+    xarr = _ptr_array(xs)
+    carr = (ctypes.c_int * len(xs))(*chans)
+    _lib.call("t2h_head1x1_fwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(carr, ctypes.c_void_p), len(xs),
+              _lib.ptr(wflat), _lib.ptr(bias) if bias is not None else None, b * h * w, _lib.ptr(out), _lib.stream(),
+              nbytes=4 * (sum(chans) + 1) * b * h * w)
+    return out
+
+
+def _head_bwd(xs, dxs, weight, bias, g, relu_inputs=()):
+    """dxs[i] (may be None) = g * w_i, times (x_i > 0) for i in ``relu_inputs``; returns (dw, db)."""
+    g = g.contiguous()
+    b, _, h, w = xs[0].shape
+    chans = [x.shape[1] for x in xs]
+    ctot = sum(chans)
+    wflat = weight.reshape(-1).contiguous()
+    dw = torch.empty(ctot, dtype=torch.float32, device=g.device)
+    db = torch.empty(1, dtype=torch.float32, device=g.device) if bias is not None else None
+    ws_bytes = _lib.load().t2h_head1x1_bwd_workspace_bytes(b * h * w, ctot)
+    ws = _lib.workspace(ws_bytes, g.device)
+    xarr, dxarr = _ptr_array(xs), _ptr_array(dxs)
+    carr = (ctypes.c_int * len(xs))(*chans)
+    flags = sum(1 << (8 + i) for i in relu_inputs)
+    nmask = sum(chans[i] for i in relu_inputs)
+    _lib.call("t2h_head1x1_bwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(dxarr, ctypes.c_void_p),
+              ctypes.cast(carr, ctypes.c_void_p), len(xs), _lib.ptr(wflat), _lib.ptr(g), b * h * w, flags, _lib.ptr(dw),
+              _lib.ptr(db) if db is not None else None, _lib.ptr(ws), ws_bytes, _lib.stream(),
+              nbytes=4 * (2 * ctot + nmask + 1) * b * h * w)
+    return dw.reshape(weight.shape), db
+
+
 class _Head1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, *xs):
         xs = [_as_cl(x) for x in xs]
-        b, _, h, w = xs[0].shape
-        chans = [x.shape[1] for x in xs]
-        wflat = weight.reshape(-1).contiguous()
-        out = torch.empty(b, 1, h, w, dtype=torch.float32, device=xs[0].device)
-        xarr = _ptr_array(xs)
-        carr = (ctypes.c_int * len(xs))(*chans)
-        _lib.call("t2h_head1x1_fwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(carr, ctypes.c_void_p), len(xs),
-                  _lib.ptr(wflat), _lib.ptr(bias) if bias is not None else None, b * h * w, _lib.ptr(out), _lib.stream(),
-                  nbytes=4 * (sum(chans) + 1) * b * h * w)
+        out = _head_fwd(xs, weight, bias)
         ctx.save_for_backward(weight, bias, *xs)
         return out
 
     @staticmethod
     def backward(ctx, g):
         weight, bias, *xs = ctx.saved_tensors
-        g = g.contiguous()
-        b, _, h, w = xs[0].shape
-        chans = [x.shape[1] for x in xs]
-        ctot = sum(chans)
-        wflat = weight.reshape(-1).contiguous()
         dxs = [torch.empty_like(x, memory_format=torch.channels_last) if ctx.needs_input_grad[2 + i] else None
                for i, x in enumerate(xs)]
-        dw = torch.empty(ctot, dtype=torch.float32, device=g.device)
-        db = torch.empty(1, dtype=torch.float32, device=g.device) if bias is not None else None
-        ws_bytes = _lib.load().t2h_head1x1_bwd_workspace_bytes(b * h * w, ctot)
-        ws = _lib.workspace(ws_bytes, g.device)
-        xarr, dxarr = _ptr_array(xs), _ptr_array(dxs)
-        carr = (ctypes.c_int * len(xs))(*chans)
-        _lib.call("t2h_head1x1_bwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(dxarr, ctypes.c_void_p),
-                  ctypes.cast(carr, ctypes.c_void_p), len(xs), _lib.ptr(wflat), _lib.ptr(g), b * h * w, 0, _lib.ptr(dw),
-                  _lib.ptr(db) if db is not None else None, _lib.ptr(ws), ws_bytes, _lib.stream(),
-                  nbytes=4 * (2 * ctot + 1) * b * h * w)
-        return (dw.reshape(weight.shape), db, *dxs)
+        dw, db = _head_bwd(xs, dxs, weight, bias, g)
+        return (dw, db, *dxs)
+
+
+class _ConvDecoder(torch.autograd.Function):
+    """ConvDecoder of pixel.py:20-32 as one autograd node: x1 = relu(conv1(x)), x2 = relu(conv2(x1)), x3 = relu(conv3(x2)),
+    out = conv4(cat[x, x1, x2, x3]).  Every activation has two consumers (the next conv and the head); in the backward
+    the head writes its rank-1 share of each gradient already ReLU-masked, and every conv data gradient accumulates onto
+    it with the same mask in its epilogue -- no gradient-sum and no ReLU-backward passes over the 512 x 512 planes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w4, b4):
+        acts = [_as_cl(x)]
+        b, _, h, wd = acts[0].shape
+        for w, bias in ((w1, b1), (w2, b2), (w3, b3)):
+            y = _empty_cl(b, w.shape[0], h, wd, x.device)
+            conv3x3_fwd_(acts[-1], _w_cl(w), bias, y, relu=True)
+            acts.append(y)
+        out = _head_fwd(acts, w4, b4)
+        ctx.save_for_backward(w1, b1, w2, b2, w3, b3, w4, b4, *acts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w1, b1, w2, b2, w3, b3, w4, b4, *acts = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        dxs = [torch.empty_like(a, memory_format=torch.channels_last) if (i > 0 or need_x) else None
+               for i, a in enumerate(acts)]
+        dw4, db4 = _head_bwd(acts, dxs, w4, b4, g, relu_inputs=(1, 2, 3))
+        grads = []
+        for level, (w, bias) in reversed(list(enumerate(((w1, b1), (w2, b2), (w3, b3)), start=1))):
+            gm, xin = dxs[level], acts[level - 1]            # gm: complete and already ReLU-masked
+            grads.append(_conv3x3_param_grads(gm, xin, w, bias))
+            if dxs[level - 1] is not None:
+                conv3x3_dgrad_(gm, _w_cl(w), dxs[level - 1], mask=xin if level > 1 else None, accumulate=True)
+        (dw3, db3), (dw2, db2), (dw1, db1) = grads
+        return dxs[0], dw1, db1, dw2, db2, dw3, db3, dw4, db4
+
+
+def conv_decoder(x: torch.Tensor, conv1, conv2, conv3, conv4) -> torch.Tensor:
+    """The whole ConvDecoder head (pixel.py:20-32) on the HIP kernels; falls back to the unfused pieces when a layer is
+    outside the conv3x3 kernels' geometry."""
+    if (all(conv3x3_supported(x, c) and c.bias is not None for c in (conv1, conv2, conv3)) and conv4.out_channels == 1
+            and conv4.kernel_size == (1, 1) and conv4.in_channels == x.shape[1] + conv1.out_channels + conv2.out_channels
+            + conv3.out_channels and conv2.in_channels == conv1.out_channels and conv3.in_channels == conv2.out_channels):
+        return _ConvDecoder.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias,
+                                  conv4.weight, conv4.bias)
+    x1 = conv_bias_act(x, conv1)
+    x2 = conv_bias_act(x1, conv2)
+    x3 = conv_bias_act(x2, conv3)
+    return head1x1([x, x1, x2, x3], conv4)
 
 
 def head1x1(xs, conv: torch.nn.Conv2d) -> torch.Tensor:
