@@ -212,6 +212,19 @@ size_t t2h_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout)
 int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
                       int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
+/* nn.ConvTranspose2d(kernel_size=2, stride=2) of the ALTO up path (upconv2x2 in alto.py, used at alto.py:175,215-218,236):
+ * output pixel (2y+dy, 2x+dx) = bias + sum_ci x[y, x, ci] w[ci, dy, dx, co].  H, W = INPUT plane dims (powers of two),
+ * x [B,H,W,Cin], y / dy [B,2H,2W,Cout] NHWC; w [Cin][2][2][Cout] = channels_last memory of torch's [Cin,Cout,2,2]
+ * weight (dw likewise); Cin, Cout multiples of 16.  The bias gradient is sum_p dy[p] = t2h_bias_relu_bwd with relu = 0. */
+int t2h_upconv2x2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
+                      int flags, t2h_stream_t stream);
+size_t t2h_upconv2x2_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_upconv2x2_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+                        void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+size_t t2h_upconv2x2_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int B, int H, int W, int Cin, int Cout, int flags,
+                        void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DSM mosaic of the inference path                     generator.py:147-157
  *   per tile: dsm[t:t+H, l:l+W] += flip_rows(height) * patch_weight;  weight[...] += patch_weight   (float64)

@@ -10,6 +10,14 @@
 //   dgrad  dX[p, ci] = [dX +] ( sum_{tap,co} dY[p - off(tap), co] W[co, tap, ci] ) * (mask > 0)          K = 9 Cout
 //   wgrad  dW[co, tap, ci] = [dW +] sum_p dY[p, co] X[p + off(tap), ci];  db[co] = [db +] sum_p dY[p, co]   K = pixels
 //
+// The 2x2 stride-2 transposed convolutions of the ALTO up path (upconv2x2 of alto.py, used at alto.py:175,215-218,236)
+// are the same kernels with another pixel geometry: output pixel (2y+dy, 2x+dx) takes tap (dy,dx) of input pixel (y,x),
+// weights [Cin][2][2][Cout] (channels_last memory of torch's [Cin,Cout,2,2]):
+//
+//   up fwd    Y[up(p,tap), co] = sum_ci X[p, ci] W[ci, tap, co] + b[co]       plain rows, N = 4 Cout, scattering epilogue
+//   up dgrad  dX[p, ci] = [dX +] sum_{tap,co} dY[up(p,tap), co] W[ci, tap, co]                gathered rows, K = 4 Cout
+//   up wgrad  dW[ci, tap, co] = [dW +] sum_p X[p, ci] dY[up(p,tap), co]                         gathered columns
+//
 // The kernels are gemm.hip's 128 x BN x 16 MFMA loop with a gathering loader on the activation operand (per-row pixel
 // coordinates kept in registers, out-of-image taps read as zero).  Small planes with many channels (32^2 x 512: 32
 // output tiles) split the reduction over grid.z into slabs in caller workspace, summed in a fixed order by the
@@ -49,11 +57,51 @@ __device__ inline void xcd_remap(int &tile_m, int &tile_n, int &split) {
     split = t / (gridDim.x * gridDim.y);
 }
 
+enum : int { G_CONV_FWD = 0, G_CONV_DGRAD = 1, G_UP_FWD = 2, G_UP_DGRAD = 3 };
+
+// scattering epilogue of the transposed convolution: GEMM row = input pixel, column n = tap * Cout + co goes to output
+// pixel up(row, tap).  Same LDS-patch transpose as store_tiles_f32 (16 bytes per lane).
+template <int TM, int TN>
+__device__ inline void store_tiles_up2x2(f32x16 (&acc)[TM][TN], float *patch, int lane, int row_base, int col_base,
+                                         const EpilogueArgs &e, int logW, int W, int Cout) {
+    constexpr int EP = 36;
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row0 = row_base + i * 32, col = col_base + j * 32 + ec;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                patch[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[i][j][q];
+            const int tap = col / Cout, co = col - tap * Cout;
+            const long long tap_off = (long long)(tap >> 1) * 2 * W + (tap & 1);
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + co);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int row = row0 + pass * 8 + er;
+                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
+                if (row < e.M && col < e.N) {
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    const long long opix = (long long)(row >> logW) * 4 * W + 2 * (row & (W - 1)) + tap_off;
+                    float4 *dst = reinterpret_cast<float4 *>(e.C + opix * Cout + co);
+                    if (e.accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *dst = v;
+                }
+            }
+        }
+}
+
 // ---- fwd / dgrad: rows = pixels -------------------------------------------------------------------------------
-// A(m, k = tap * Ca + c) = act[pixel(m) + off(tap)][c], zero outside the image; 128 rows x 16 k per slab, 2 float4 per
-// thread: rows (tid >> 2) and (tid >> 2) + 64, channel group tid & 3.
-template <int BN, int WAVES_M, int WAVES_N, bool DGRAD, int MINW>
+// A(m, k = tap * Ca + c) = act[src(m, tap)][c]; 128 rows x 16 k per slab, 2 float4 per thread: rows (tid >> 2) and
+// (tid >> 2) + 64, channel group tid & 3.  src = pixel(m) + off(tap), zero outside the image (3x3); pixel m itself
+// (transposed-conv forward, one "tap"); up(m, tap) (transposed-conv data gradient).
+template <int BN, int WAVES_M, int WAVES_N, int GEOM, int MINW>
 __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
+    constexpr bool DGRAD = GEOM == G_CONV_DGRAD;
+    constexpr bool IS3X3 = GEOM == G_CONV_FWD || GEOM == G_CONV_DGRAD;
+    constexpr bool B_KC = GEOM == G_CONV_FWD || GEOM == G_UP_DGRAD;
     constexpr int BM = 128;
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int SA = BM + kPad, SB = BN + kPad;
@@ -71,33 +119,49 @@ __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int nk = (kend - kbeg) / BK;
 
-    // pixel coordinates of this thread's two gather rows; rows past M get a y that fails every bounds test
+    // pixel coordinates of this thread's two gather rows; rows past M get a y that fails every bounds test.
+    // 3x3: (gy, gx) = pixel coordinates; transposed conv: gy = 0 / out of range, gx = up(m, tap 0)
     const int kc4 = (tid & 3) * 4;
     int gy[2], gx[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int m = m0 + (tid >> 2) + f * 64;
-        gx[f] = m & (p.W - 1);
-        gy[f] = m < p.M ? ((m >> p.logW) & (p.H - 1)) : (1 << 20);
+        if (IS3X3) {
+            gx[f] = m & (p.W - 1);
+            gy[f] = m < p.M ? ((m >> p.logW) & (p.H - 1)) : (1 << 20);
+        } else {
+            gx[f] = (m >> p.logW) * 4 * p.W + 2 * (m & (p.W - 1));
+            gy[f] = m < p.M ? 0 : (1 << 20);
+        }
     }
     float4 ra[2];
-    TileLoader<BN, NT, !DGRAD, BK> lb;
+    TileLoader<BN, NT, B_KC, BK> lb;
     int tap = kbeg / p.Ca, c0 = kbeg - tap * p.Ca;     // position of the next slab to load
 
     auto load_slab = [&]() {
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        const int dy = DGRAD ? 1 - ky : ky - 1, dx = DGRAD ? 1 - kx : kx - 1;
-        const long long shift = ((long long)dy * p.W + dx) * p.Ca + c0 + kc4;
+        if (IS3X3) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int dy = DGRAD ? 1 - ky : ky - 1, dx = DGRAD ? 1 - kx : kx - 1;
+            const long long shift = ((long long)dy * p.W + dx) * p.Ca + c0 + kc4;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const bool ok = (unsigned)(gy[f] + dy) < (unsigned)p.H && (unsigned)(gx[f] + dx) < (unsigned)p.W;
-            const long long m = m0 + (tid >> 2) + f * 64;
-            ra[f] = ok ? *reinterpret_cast<const float4 *>(p.act + m * p.Ca + shift) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f = 0; f < 2; ++f) {
+                const bool ok = (unsigned)(gy[f] + dy) < (unsigned)p.H && (unsigned)(gx[f] + dx) < (unsigned)p.W;
+                const long long m = m0 + (tid >> 2) + f * 64;
+                ra[f] = ok ? *reinterpret_cast<const float4 *>(p.act + m * p.Ca + shift) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const long long tap_off = (long long)(tap >> 1) * 2 * p.W + (tap & 1);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const long long src = GEOM == G_UP_FWD ? (long long)(m0 + (tid >> 2) + f * 64) : gx[f] + tap_off;
+                ra[f] = gy[f] == 0 ? *reinterpret_cast<const float4 *>(p.act + src * p.Ca + c0 + kc4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-        if (DGRAD)   // B(k = co, n = ci) = W[co][tap][ci]: direct layout, rows co0.. at stride 9 Cin
-            lb.load(p.mat + (size_t)tap * p.N, p.ldmat, n0, p.N, c0, p.Ca, tid, false);
-        else         // B(k, n = co) = W[co][k]: k-contiguous rows
+        if (B_KC)    // B(k, n) = mat[n][k]: k-contiguous rows (3x3 forward: W[co][tap][ci]; up dgrad: W[ci][tap][co])
             lb.load(p.mat, p.ldmat, n0, p.N, tap * p.Ca + c0, p.K, tid, false);
+        else         // B(k, n) = mat[k][tap][n]: direct layout (3x3 dgrad: W[co][tap][ci]; up forward: W[ci][(tap,co)])
+            lb.load(p.mat + (size_t)tap * p.N, p.ldmat, n0, p.N, c0, p.Ca, tid, false);
         c0 += BK;
         if (c0 >= p.Ca) { c0 = 0; ++tap; }
     };
@@ -134,7 +198,11 @@ __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
     e.C = p.C + (size_t)split * p.slab_stride;
     e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
     e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
-    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
+    if (GEOM == G_UP_FWD)
+        store_tiles_up2x2<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e, p.logW, p.W,
+                                  p.N / 4);
+    else
+        store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
 }
 
 // out[r, c] = [out +] act( sum_z slabs[z][r, c] + bias[c] ) * (mask > 0); one float4 per thread, splits in order
@@ -169,7 +237,8 @@ __global__ __launch_bounds__(256) void reduce_rows_epilogue_kernel(const float *
 // A(i = co, k = pixel) = dY[pixel][co] (plain direct-layout loader, column sums = bias gradient);
 // B(k = pixel, n = tap * Cin + ci) = X[pixel + off(tap)][ci]: every thread owns one float4 column group (fixed tap
 // and ci, Cin % 4 == 0) and walks pixels.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW>
+// Transposed conv (UP): A = X[pixel][ci], B(k = pixel, n = tap * Cout + co) = dY[up(pixel, tap)][co].
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MINW, bool UP>
 __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int SA = BM + kPad, SB = BN + kPad;
@@ -194,9 +263,9 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
     const int ic = tid % GROUPS, krow = tid / GROUPS;
     const int n = n0 + ic * 4;
     const int tap = n / p.Ca, ci = n - tap * p.Ca;
-    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    const int ky = UP ? tap >> 1 : (tap * 11) >> 5, kx = UP ? tap & 1 : tap - 3 * ky;
     const int dy = n < p.N ? ky - 1 : (1 << 20), dx = kx - 1;      // columns past N fail every bounds test
-    const long long shift = ((long long)(ky - 1) * p.W + dx) * p.Ca + ci;
+    const long long shift = UP ? ((long long)ky * 2 * p.W + kx) * p.Ca + ci : ((long long)(ky - 1) * p.W + dx) * p.Ca + ci;
 
     LoaderA la;
     float4 rb[PER];
@@ -207,9 +276,14 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (BK % KSTEP == 0 || k < BK) {
                 const int pix = k0 + k;
-                const int x = pix & (p.W - 1), y = (pix >> p.logW) & (p.H - 1);
-                const bool ok = pix < kend && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
-                if (ok) v = *reinterpret_cast<const float4 *>(p.act + (long long)pix * p.Ca + shift);
+                if (UP) {
+                    const long long up0 = (long long)(pix >> p.logW) * 4 * p.W + 2 * (pix & (p.W - 1));
+                    if (pix < kend && n < p.N) v = *reinterpret_cast<const float4 *>(p.act + up0 * p.Ca + shift);
+                } else {
+                    const int x = pix & (p.W - 1), y = (pix >> p.logW) & (p.H - 1);
+                    const bool ok = pix < kend && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+                    if (ok) v = *reinterpret_cast<const float4 *>(p.act + (long long)pix * p.Ca + shift);
+                }
             }
             rb[f] = v;
         }
@@ -313,38 +387,56 @@ RowsPlan rows_plan(long long M, int N, int K) {
     return r;
 }
 
-template <bool DGRAD>
+template <int GEOM>
 int launch_rows(const ConvArgs &a, const RowsPlan &r, hipStream_t s, const char *what) {
     dim3 grid((a.N + r.bn - 1) / r.bn, (a.M + 127) / 128, r.splits);
     if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: too many pixels", what);
-    if (r.bn == 128) hipLaunchKernelGGL((conv_rows_kernel<128, 2, 2, DGRAD, 4>), grid, dim3(NT), 0, s, a);
-    else if (r.bn == 64) hipLaunchKernelGGL((conv_rows_kernel<64, 2, 2, DGRAD, 4>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((conv_rows_kernel<32, 4, 1, DGRAD, 4>), grid, dim3(NT), 0, s, a);
+    if (r.bn == 128) hipLaunchKernelGGL((conv_rows_kernel<128, 2, 2, GEOM, 4>), grid, dim3(NT), 0, s, a);
+    else if (r.bn == 64) hipLaunchKernelGGL((conv_rows_kernel<64, 2, 2, GEOM, 4>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((conv_rows_kernel<32, 4, 1, GEOM, 4>), grid, dim3(NT), 0, s, a);
     return check_launch(what);
 }
 
-// shared body of fwd / dgrad
-template <bool DGRAD>
+// GEMM extents of the four row-streaming geometries; H, W = dims of the plane whose pixels are the GEMM rows
+struct RowsShape { int Ca, N, K, ldmat; };
+template <int GEOM>
+RowsShape rows_shape(int Cin, int Cout) {
+    if (GEOM == G_CONV_FWD) return {Cin, Cout, 9 * Cin, 9 * Cin};
+    if (GEOM == G_CONV_DGRAD) return {Cout, Cin, 9 * Cout, 9 * Cin};
+    if (GEOM == G_UP_FWD) return {Cin, 4 * Cout, Cin, 4 * Cout};
+    return {Cout, Cin, 4 * Cout, 4 * Cout};
+}
+template <int GEOM>
+RowsPlan rows_plan_for(long long M, int Cin, int Cout) {
+    RowsShape sh = rows_shape<GEOM>(Cin, Cout);
+    RowsPlan r = rows_plan(M, sh.N, sh.K);
+    if (GEOM == G_UP_FWD && r.splits > 1) { r.splits = 1; r.k_chunk = sh.K; }     // scattering epilogue: no slabs
+    return r;
+}
+
+// shared body of the row-streaming entry points
+template <int GEOM>
 int conv_rows(const float *act, const float *w, const float *bias, const float *mask, float *out, int B, int H, int W,
               int Cin, int Cout, int flags, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
-    const int Ca = DGRAD ? Cout : Cin, N = DGRAD ? Cin : Cout;
+    const RowsShape sh = rows_shape<GEOM>(Cin, Cout);
+    const int Ca = sh.Ca, N = sh.N;
     const long long M = (long long)B * H * W;
-    RowsPlan r = rows_plan(M, N, 9 * Ca);
+    RowsPlan r = rows_plan_for<GEOM>(M, Cin, Cout);
     ConvArgs a{};
     a.act = act; a.mat = w; a.H = H; a.W = W; a.logW = ilog2_exact(W); a.Ca = Ca;
-    a.M = (int)M; a.N = N; a.K = 9 * Ca; a.ldmat = 9 * Cin; a.k_chunk = r.k_chunk;
+    a.M = (int)M; a.N = N; a.K = sh.K; a.ldmat = sh.ldmat; a.k_chunk = r.k_chunk;
     EpilogueArgs e{};
     e.C = out; e.bias = bias; e.mask = mask; e.M = (int)M; e.N = N; e.ldc = N; e.ldm = N;
     e.accum = flags & T2H_ACCUM; e.relu_out = flags & T2H_RELU_OUT;
     if (r.splits == 1) {
         a.C = out; a.bias = bias; a.mask = mask; a.ldc = N; a.ldm = N; a.slab_stride = 0;
         a.flags = (e.accum ? F_ACCUM : 0) | (e.relu_out ? F_RELU_OUT : 0);
-        return launch_rows<DGRAD>(a, r, s, what);
+        return launch_rows<GEOM>(a, r, s, what);
     }
     const size_t need = (size_t)r.splits * M * N * sizeof(float);
     if (!ws || ws_bytes < need) return fail(T2H_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     a.C = static_cast<float *>(ws); a.ldc = N; a.slab_stride = M * N; a.flags = 0;
-    if (int rc = launch_rows<DGRAD>(a, r, s, what)) return rc;
+    if (int rc = launch_rows<GEOM>(a, r, s, what)) return rc;
     const long long total = M * (N / 4);
     hipLaunchKernelGGL(reduce_rows_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        static_cast<const float *>(ws), r.splits, M * N, (int)M, N, e);
@@ -360,12 +452,12 @@ int check_geometry(const char *what, int B, int H, int W, int Cin, int Cout) {
 }
 
 struct WgradPlan { int bm, bn, splits, k_chunk; };
-WgradPlan conv_wgrad_plan(long long P, int Cin, int Cout) {
+// rows = channels of the dense operand, ncols = taps x channels of the gathered one, P = pixels reduced over
+WgradPlan wgrad_plan_for(long long P, int rows, int ncols) {
     WgradPlan p{};
-    const int Ncols = 9 * Cin;
-    p.bm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    p.bm = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
     p.bn = 128;
-    const long long tiles = (long long)((Cout + p.bm - 1) / p.bm) * ((Ncols + p.bn - 1) / p.bn);
+    const long long tiles = (long long)((rows + p.bm - 1) / p.bm) * ((ncols + p.bn - 1) / p.bn);
     long long want = (1024 + tiles - 1) / tiles;
     if (want > 512) want = 512;
     long long max_splits = (P + 16 * BK - 1) / (16 * BK);      // at least 16 slabs per workgroup
@@ -377,6 +469,7 @@ WgradPlan conv_wgrad_plan(long long P, int Cin, int Cout) {
     p.splits = (int)((P + chunk - 1) / chunk);
     return p;
 }
+WgradPlan conv_wgrad_plan(long long P, int Cin, int Cout) { return wgrad_plan_for(P, Cout, 9 * Cin); }
 
 bool al16(const void *q) { return (uintptr_t)q % 16 == 0; }
 
@@ -388,7 +481,7 @@ using namespace t2h;
 T2H_API size_t t2h_conv3x3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
     const long long M = (long long)B * H * W;
-    RowsPlan r = rows_plan(M, Cout, 9 * Cin);
+    RowsPlan r = rows_plan_for<G_CONV_FWD>(M, Cin, Cout);
     return r.splits > 1 ? (size_t)r.splits * M * Cout * sizeof(float) : 0;
 }
 
@@ -398,14 +491,14 @@ T2H_API int t2h_conv3x3_fwd(const float *x, const float *w, const float *bias, f
     if (int rc = check_geometry("conv3x3_fwd", B, H, W, Cin, Cout)) return rc;
     if (Cin % 16 != 0 || Cout % 4 != 0 || !al16(x) || !al16(w) || !al16(y) || (bias && !al16(bias)))
         return fail(T2H_ERR_ARG, "conv3x3_fwd: Cin=%d must be a multiple of 16, Cout=%d of 4, pointers 16-byte aligned", Cin, Cout);
-    return conv_rows<false>(x, w, bias, nullptr, y, B, H, W, Cin, Cout, flags, workspace, workspace_bytes, as_stream(stream),
+    return conv_rows<G_CONV_FWD>(x, w, bias, nullptr, y, B, H, W, Cin, Cout, flags, workspace, workspace_bytes, as_stream(stream),
                             "conv3x3_fwd");
 }
 
 T2H_API size_t t2h_conv3x3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
     const long long M = (long long)B * H * W;
-    RowsPlan r = rows_plan(M, Cin, 9 * Cout);
+    RowsPlan r = rows_plan_for<G_CONV_DGRAD>(M, Cin, Cout);
     return r.splits > 1 ? (size_t)r.splits * M * Cin * sizeof(float) : 0;
 }
 
@@ -415,7 +508,7 @@ T2H_API int t2h_conv3x3_dgrad(const float *dy, const float *w, float *dx, const 
     if (int rc = check_geometry("conv3x3_dgrad", B, H, W, Cin, Cout)) return rc;
     if (Cout % 16 != 0 || Cin % 4 != 0 || !al16(dy) || !al16(w) || !al16(dx) || (mask && !al16(mask)))
         return fail(T2H_ERR_ARG, "conv3x3_dgrad: Cout=%d must be a multiple of 16, Cin=%d of 4, pointers 16-byte aligned", Cout, Cin);
-    return conv_rows<true>(dy, w, nullptr, mask, dx, B, H, W, Cin, Cout, flags & T2H_ACCUM, workspace, workspace_bytes,
+    return conv_rows<G_CONV_DGRAD>(dy, w, nullptr, mask, dx, B, H, W, Cin, Cout, flags & T2H_ACCUM, workspace, workspace_bytes,
                            as_stream(stream), "conv3x3_dgrad");
 }
 
@@ -447,10 +540,77 @@ T2H_API int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float 
     a.k_chunk = p.k_chunk; a.slab_stride = (long long)Cout * Ncols;
     dim3 grid((Ncols + p.bn - 1) / p.bn, (Cout + p.bm - 1) / p.bm, p.splits);
     if (grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_wgrad: too many splits");
-    if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4>), grid, dim3(NT), 0, s, a);
-    else if (p.bm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 4>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4>), grid, dim3(NT), 0, s, a);
+    if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, false>), grid, dim3(NT), 0, s, a);
+    else if (p.bm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 4, false>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4, false>), grid, dim3(NT), 0, s, a);
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
     const int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, colslab, db, s);
+}
+
+// ---- ConvTranspose2d(kernel_size=2, stride=2): H, W are the INPUT plane's dims, the output is 2H x 2W ----------------
+static int check_up(const char *what, int B, int H, int W, int Cin, int Cout) {
+    if (int rc = check_geometry(what, B, H, W, Cin, Cout)) return rc;
+    if ((long long)B * H * W > (1LL << 28)) return fail(T2H_ERR_ARG, "%s: more than 2^28 input pixels", what);
+    if (Cin % 16 != 0 || Cout % 16 != 0) return fail(T2H_ERR_ARG, "%s: Cin=%d and Cout=%d must be multiples of 16", what, Cin, Cout);
+    return T2H_OK;
+}
+
+T2H_API int t2h_upconv2x2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                              int Cout, int flags, t2h_stream_t stream) {
+    if (!x || !w || !y) return fail(T2H_ERR_ARG, "upconv2x2_fwd: null pointer");
+    if (int rc = check_up("upconv2x2_fwd", B, H, W, Cin, Cout)) return rc;
+    if (!al16(x) || !al16(w) || !al16(y) || (bias && !al16(bias))) return fail(T2H_ERR_ARG, "upconv2x2_fwd: pointers must be 16-byte aligned");
+    return conv_rows<G_UP_FWD>(x, w, bias, nullptr, y, B, H, W, Cin, Cout, flags & T2H_ACCUM, nullptr, 0, as_stream(stream),
+                               "upconv2x2_fwd");
+}
+
+T2H_API size_t t2h_upconv2x2_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+    const long long M = (long long)B * H * W;
+    RowsPlan r = rows_plan_for<G_UP_DGRAD>(M, Cin, Cout);
+    return r.splits > 1 ? (size_t)r.splits * M * Cin * sizeof(float) : 0;
+}
+
+T2H_API int t2h_upconv2x2_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+                                void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !w || !dx) return fail(T2H_ERR_ARG, "upconv2x2_dgrad: null pointer");
+    if (int rc = check_up("upconv2x2_dgrad", B, H, W, Cin, Cout)) return rc;
+    if (!al16(dy) || !al16(w) || !al16(dx)) return fail(T2H_ERR_ARG, "upconv2x2_dgrad: pointers must be 16-byte aligned");
+    return conv_rows<G_UP_DGRAD>(dy, w, nullptr, nullptr, dx, B, H, W, Cin, Cout, flags & T2H_ACCUM, workspace, workspace_bytes,
+                                 as_stream(stream), "upconv2x2_dgrad");
+}
+
+T2H_API size_t t2h_upconv2x2_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+    WgradPlan p = wgrad_plan_for((long long)B * H * W, Cin, 4 * Cout);
+    return (size_t)p.splits * (size_t)Cin * 4 * Cout * sizeof(float);
+}
+
+T2H_API int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int B, int H, int W, int Cin, int Cout, int flags,
+                                void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "upconv2x2_wgrad: null pointer");
+    if (int rc = check_up("upconv2x2_wgrad", B, H, W, Cin, Cout)) return rc;
+    if (!al16(dy) || !al16(x)) return fail(T2H_ERR_ARG, "upconv2x2_wgrad: pointers must be 16-byte aligned");
+    const size_t need = t2h_upconv2x2_wgrad_workspace_bytes(B, H, W, Cin, Cout);
+    if (!workspace || workspace_bytes < need)
+        return fail(T2H_ERR_WORKSPACE, "upconv2x2_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    const long long P = (long long)B * H * W;
+    const int Ncols = 4 * Cout;
+    WgradPlan p = wgrad_plan_for(P, Cin, Ncols);
+    float *slab = static_cast<float *>(workspace);
+    ConvArgs a{};
+    a.act = dy; a.mat = x; a.C = slab; a.colsum = nullptr;
+    a.H = H; a.W = W; a.logW = ilog2_exact(W); a.Ca = Cout;
+    a.M = Cin; a.N = Ncols; a.K = (int)P; a.ldmat = Cin; a.ldc = Ncols;
+    a.k_chunk = p.k_chunk; a.slab_stride = (long long)Cin * Ncols;
+    dim3 grid((Ncols + p.bn - 1) / p.bn, (Cin + p.bm - 1) / p.bm, p.splits);
+    if (grid.z > 65535) return fail(T2H_ERR_ARG, "upconv2x2_wgrad: too many splits");
+    if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, true>), grid, dim3(NT), 0, s, a);
+    else if (p.bm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 4, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(NT), 0, s, a);
+    if (int rc = check_launch("upconv2x2_wgrad")) return rc;
+    return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw,
+                               nullptr, nullptr, s);
 }

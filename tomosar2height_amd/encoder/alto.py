@@ -51,7 +51,10 @@ class _PointGridLevel(nn.Module):
         return F.relu(self.conv2(F.relu(self.conv1(x))))
 
     def _conv1x1(self, conv, x):
-        return grid.conv1x1(x, conv) if self.channels_last else conv(x)
+        """1x1 convs and 2x2 transposed convs (UpConv.conv1x1 is either, alto.py:172-175)."""
+        if not self.channels_last:
+            return conv(x)
+        return grid.upconv2x2(x, conv) if isinstance(conv, nn.ConvTranspose2d) else grid.conv1x1(x, conv)
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
         sampled = ops.sample_plane(tile, plane)                                   # alto.py:121-122 / 245-246
@@ -111,7 +114,7 @@ class UpConv(_PointGridLevel):
         self.conv2 = conv3x3(out_channels, out_channels)
 
     def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last):
-        up = self._conv1x1(self.upconv_noup, from_up) if self.is_last else self.upconv(from_up)    # alto.py:215-218
+        up = self._conv1x1(self.upconv_noup if self.is_last else self.upconv, from_up)            # alto.py:215-218
         g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
         g = self._conv_pair(g)
         if prev_conv is not None:

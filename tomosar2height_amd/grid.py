@@ -260,6 +260,74 @@ def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
     return _Conv1x1.apply(x, conv.weight, conv.bias)
 
 
+# ------------------------------------------------------------------------------------------------ upconv2x2 (HIP)
+def upconv2x2_supported(x: torch.Tensor, conv) -> bool:
+    return (USE_HIP_CONV and type(conv) is torch.nn.ConvTranspose2d and conv.kernel_size == (2, 2) and conv.stride == (2, 2)
+            and conv.padding == (0, 0) and conv.output_padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.dim() == 4 and x.is_cuda
+            and x.dtype == torch.float32 and _pow2(x.shape[2]) and _pow2(x.shape[3]))
+
+
+class _UpConv2x2(torch.autograd.Function):
+    """nn.ConvTranspose2d(kernel_size=2, stride=2) (upconv2x2, alto.py:175,215-218,236) on csrc/conv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _as_cl(x)
+        w = _w_cl(weight)                                   # [Cin][2][2][Cout] in memory
+        b, cin, h, wd = x.shape
+        cout = weight.shape[1]
+        y = _empty_cl(b, cout, 2 * h, 2 * wd, x.device)
+        _lib.call("t2h_upconv2x2_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
+                  b, h, wd, cin, cout, 0, _lib.stream(), nbytes=4 * (x.numel() + y.numel() + w.numel()),
+                  flops=2 * 4 * cin * cout * b * h * wd, tag=f"t2h_upconv2x2_fwd[{cin}->{cout},{h}x{wd}]")
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias = ctx.saved_tensors
+        g = _as_cl(g)
+        w = _w_cl(weight)
+        b, cin, h, wd = x.shape
+        cout = weight.shape[1]
+        lib = _lib.load()
+        flops = 2 * 4 * cin * cout * b * h * wd
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            nws = lib.t2h_upconv2x2_dgrad_workspace_bytes(b, h, wd, cin, cout)
+            ws = _lib.workspace(nws, g.device)
+            _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(g), _lib.ptr(w), _lib.ptr(dx), b, h, wd, cin, cout, 0, _lib.ptr(ws), nws,
+                      _lib.stream(), nbytes=4 * (g.numel() + dx.numel() + w.numel()), flops=flops,
+                      tag=f"t2h_upconv2x2_dgrad[{cout}->{cin},{h}x{wd}]")
+        wg, bg = weight.grad, (bias.grad if bias is not None else None)
+        direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
+                  and (bias is None or (bg is not None and bg.is_contiguous())))
+        dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
+        db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
+        nws = lib.t2h_upconv2x2_wgrad_workspace_bytes(b, h, wd, cin, cout)
+        ws = _lib.workspace(nws, g.device)
+        _lib.call("t2h_upconv2x2_wgrad", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), b, h, wd, cin, cout,
+                  _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
+                  nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
+                  tag=f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
+        if db is not None:
+            pix = 4 * b * h * wd
+            nws = lib.t2h_bias_relu_bwd_workspace_bytes(pix, cout)
+            ws = _lib.workspace(nws, g.device)
+            _lib.call("t2h_bias_relu_bwd", _lib.ptr(g), None, None, pix, cout, 0, 1 if direct else 0, _lib.ptr(db),
+                      _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * g.numel())
+        return (dx, None, None) if direct else (dx, dw, db)
+
+
+def upconv2x2(x: torch.Tensor, conv) -> torch.Tensor:
+    """``conv(x)`` for the 2x2 stride-2 transposed convolutions of the ALTO up path."""
+    if not upconv2x2_supported(x, conv):
+        return conv(x)
+    return _UpConv2x2.apply(x, conv.weight, conv.bias)
+
+
 # ------------------------------------------------------------------------------------------------ concat-free 1x1 head
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
