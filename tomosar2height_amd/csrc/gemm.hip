@@ -240,40 +240,79 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
         }
 }
 
-// out[e] = [out[e] +] sum_z slabs[z][e].  16 consecutive elements x 16 split-lanes per workgroup: lane q sums the
-// splits z = q, q+16, ... in order (4 loads in flight), the 16 lane sums are then added in lane order through LDS:
-// a fixed summation tree, so the result is deterministic, and the chain per thread is splits/16 loads deep.
-// Workgroups past the matrix part reduce the bias-gradient slabs (col_slabs [splits][rows] -> col_out[rows]) in the
-// same launch.
+// out[e] = [out[e] +] sum_z slabs[z][e].  Per workgroup 16 element-lanes x 16 split-lanes: split-lane q sums the splits
+// z = q, q+16, ... in order (4 loads in flight), the 16 lane sums are then added in lane order through LDS: a fixed
+// summation tree, so the result is deterministic, and the chain per thread is splits/16 loads deep.  VEC = 4: every
+// element-lane owns a float4 (64 consecutive elements = 256-byte row segments per workgroup); VEC = 1 for shapes
+// that are not multiples of 4.  Workgroups past the matrix part reduce the bias-gradient slabs
+// (col_slabs [splits][rows] -> col_out[rows]) in the same launch, one element per lane.
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
                                                           int rows, int cols, int ld_out, int accumulate,
                                                           float *__restrict__ out, const float *__restrict__ col_slabs,
                                                           float *__restrict__ col_out, unsigned matrix_blocks) {
-    __shared__ float red[256];
+    __shared__ float red[256 * VEC];
     const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-    const bool colpart = blockIdx.x >= matrix_blocks;
-    const float *src = colpart ? col_slabs : slabs;
-    const long long st = colpart ? rows : stride;
-    const long long total = colpart ? rows : (long long)rows * cols;
-    long long e = (long long)(colpart ? blockIdx.x - matrix_blocks : blockIdx.x) * 16 + el;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (blockIdx.x >= matrix_blocks) {
+        const long long e = (long long)(blockIdx.x - matrix_blocks) * 16 + el;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < rows) {
+            int z = q;
+            for (; z + 48 < splits; z += 64) {
+                s0 += col_slabs[(size_t)z * rows + e];
+                s1 += col_slabs[(size_t)(z + 16) * rows + e];
+                s2 += col_slabs[(size_t)(z + 32) * rows + e];
+                s3 += col_slabs[(size_t)(z + 48) * rows + e];
+            }
+            for (; z < splits; z += 16) s0 += col_slabs[(size_t)z * rows + e];
+        }
+        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && e < rows) {
+            float t = red[el];
+            for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
+            col_out[e] = accumulate ? col_out[e] + t : t;
+        }
+        return;
+    }
+    using V = Vec<VEC>;
+    const long long total = (long long)rows * cols;
+    const long long e = ((long long)blockIdx.x * 16 + el) * VEC;
+    V s0, s1, s2, s3;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) s0.v[c] = s1.v[c] = s2.v[c] = s3.v[c] = 0.f;
     if (e < total) {
         int z = q;
         for (; z + 48 < splits; z += 64) {
-            s0 += src[(size_t)z * st + e];
-            s1 += src[(size_t)(z + 16) * st + e];
-            s2 += src[(size_t)(z + 32) * st + e];
-            s3 += src[(size_t)(z + 48) * st + e];
+            V a0 = V::load(slabs + (size_t)z * stride + e), a1 = V::load(slabs + (size_t)(z + 16) * stride + e);
+            V a2 = V::load(slabs + (size_t)(z + 32) * stride + e), a3 = V::load(slabs + (size_t)(z + 48) * stride + e);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { s0.v[c] += a0.v[c]; s1.v[c] += a1.v[c]; s2.v[c] += a2.v[c]; s3.v[c] += a3.v[c]; }
         }
-        for (; z < splits; z += 16) s0 += src[(size_t)z * st + e];
+        for (; z < splits; z += 16) {
+            V a0 = V::load(slabs + (size_t)z * stride + e);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) s0.v[c] += a0.v[c];
+        }
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) red[threadIdx.x * VEC + c] = (s0.v[c] + s1.v[c]) + (s2.v[c] + s3.v[c]);
     __syncthreads();
     if (q == 0 && e < total) {
-        float t = red[el];
-        for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
-        float *dst = colpart ? col_out + e : out + (size_t)(e / cols) * ld_out + (e % cols);
-        *dst = accumulate ? *dst + t : t;
+        V t;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            float acc = red[el * VEC + c];
+            for (int k = 1; k < 16; ++k) acc += red[(k * 16 + el) * VEC + c];
+            t.v[c] = acc;
+        }
+        float *dst = out + (size_t)(e / cols) * ld_out + (e % cols);
+        if (accumulate) {
+            V o = V::load(dst);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) t.v[c] += o.v[c];
+        }
+        t.store(dst);
     }
 }
 
@@ -377,9 +416,15 @@ static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) &&
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
                         float *out, const float *col_slabs, float *col_out, hipStream_t s) {
     const long long total = (long long)rows * cols;
-    const unsigned mb = (unsigned)((total + 15) / 16), cb = col_out ? (unsigned)((rows + 15) / 16) : 0u;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
-                       accumulate, out, col_slabs, col_out, mb);
+    const bool vec = cols % 4 == 0 && ld_out % 4 == 0 && stride % 4 == 0 && (uintptr_t)slabs % 16 == 0 && (uintptr_t)out % 16 == 0;
+    const unsigned mb = (unsigned)((total + (vec ? 63 : 15)) / (vec ? 64 : 16));
+    const unsigned cb = col_out ? (unsigned)((rows + 15) / 16) : 0u;
+    if (vec)
+        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
+                           accumulate, out, col_slabs, col_out, mb);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
+                           accumulate, out, col_slabs, col_out, mb);
     return check_launch("reduce_slabs");
 }
 
@@ -440,7 +485,8 @@ WgradPlan wgrad_plan(int M, int K, int N) {
     p.bm = N > 64 ? 128 : (N > 32 ? 64 : 32);
     p.bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
     p.tiles = ((N + p.bm - 1) / p.bm) * ((K + p.bn - 1) / p.bn);
-    int want = (1024 + p.tiles - 1) / p.tiles;                  // ~1024 workgroups in flight
+    int want = 1024 / p.tiles;                                  // <= 1024 workgroups = one resident wave (4 per CU): one
+                                                                // more would run alone after all others finish
     if (want > 512) want = 512;
     int max_splits = (M + 16 * kMinBK - 1) / (16 * kMinBK);     // at least 16 reduction slabs per workgroup
     int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
