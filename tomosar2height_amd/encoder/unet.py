@@ -1,14 +1,26 @@
 """Plain convolutional U-Net (reference: tomosar2height/encoder/unet.py:112-187), the image encoder of
-``use_image=true`` configs.  Pure dense convolution: stays on MIOpen through PyTorch-ROCm (SURVEY.md
-section 2 row 10 -- out of hand-written scope); kept here with the reference's parameter names so
-cloud+image checkpoints load."""
+``use_image=true`` configs, kept with the reference's parameter names so cloud+image checkpoints load.  Pure dense
+convolution: plain torch / MIOpen by default; in channels_last mode its 3x3, 2x2-transposed
+and 1x1 convolutions with 16-aligned channel counts run on the same implicit-GEMM kernels as the ALTO grid side
+(grid.py, csrc/conv.hip) -- every layer except the first (3 input channels)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
+from .. import grid
 
-class DownConv(nn.Module):
+
+class _Level(nn.Module):
+    channels_last = False
+
+    def _conv_pair(self, x):
+        if self.channels_last:
+            return grid.conv3x3_chain(x, (self.conv1, self.conv2))
+        return F.relu(self.conv2(F.relu(self.conv1(x))))
+
+
+class DownConv(_Level):
     def __init__(self, in_channels, out_channels, pooling=True):
         super().__init__()
         self.pooling = pooling
@@ -18,11 +30,11 @@ class DownConv(nn.Module):
             self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        x = F.relu(self.conv2(F.relu(self.conv1(x))))
+        x = self._conv_pair(x)
         return (self.pool(x) if self.pooling else x), x
 
 
-class UpConv(nn.Module):
+class UpConv(_Level):
     def __init__(self, in_channels, out_channels, merge_mode="concat", up_mode="transpose"):
         super().__init__()
         if up_mode != "transpose":
@@ -33,9 +45,9 @@ class UpConv(nn.Module):
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
 
     def forward(self, from_down, from_up):
-        up = self.upconv(from_up)
+        up = grid.upconv2x2(from_up, self.upconv) if self.channels_last else self.upconv(from_up)
         x = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
-        return F.relu(self.conv2(F.relu(self.conv1(x))))
+        return self._conv_pair(x)
 
 
 class UNet(nn.Module):
@@ -64,6 +76,11 @@ class UNet(nn.Module):
                 init.xavier_normal_(m.weight)
                 init.constant_(m.bias, 0)
 
+    def set_channels_last(self, flag: bool):
+        for m in self.modules():
+            if isinstance(m, _Level):
+                m.channels_last = bool(flag)
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("tomosar2height_amd: expected device tensors; there is no CPU path")
@@ -73,4 +90,6 @@ class UNet(nn.Module):
             skips.append(before_pool)
         for i, up in enumerate(self.up_convs):
             x = up(skips[-(i + 2)], x)
+        if self.down_convs[0].channels_last:
+            return grid.conv1x1(x, self.conv_final)
         return self.conv_final(x)

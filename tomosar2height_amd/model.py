@@ -42,6 +42,8 @@ class TomoSAR2Height(nn.Module):
         write pixel-major rows natively, so no layout copies remain.  Numerics are unchanged."""
         if self.use_cloud and hasattr(self.point_encoder, "set_channels_last"):
             self.point_encoder.set_channels_last(flag)
+        if self.use_image and hasattr(self.image_encoder, "set_channels_last"):
+            self.image_encoder.set_channels_last(flag)
         if hasattr(self.decoder, "set_channels_last"):
             self.decoder.set_channels_last(flag)
         fmt = torch.channels_last if flag else torch.contiguous_format
