@@ -167,7 +167,7 @@ def main():
         group = dist.group.WORLD
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
-    from tomosar2height_amd import TomoSAR2Height, _lib
+    from tomosar2height_amd import TomoSAR2Height, _lib, grid
     from tomosar2height_amd.config import berlin_config, munich_config
     from tomosar2height_amd.synthetic import berlin_tile
     from tomosar2height_amd.trainer import Trainer, broadcast_parameters
@@ -239,6 +239,7 @@ def main():
                                    f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
                        "parallelism": f"dp{world}", "channels_last": bool(args.channels_last),
+                       "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",
                        "miopen_find": bool(args.miopen_find), "hip_graph": bool(args.hip_graph)},
         }
         if timeline is not None:
@@ -273,6 +274,10 @@ def main():
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 out["roofline_scatter_reduce"] = [roof(named[n]) for n in
                                                   ("t2h_segmean_fwd[C=512,r=32]", "t2h_pool_max_fwd") if n in named]
+                # the largest grid convolutions: implicit-GEMM kernels of csrc/conv.hip
+                out["roofline_grid_conv"] = [roof(named[n]) for n in
+                                             ("t2h_conv3x3_fwd[64->128,512x512]", "t2h_conv3x3_dgrad[128->64,512x512]",
+                                              "t2h_conv3x3_wgrad[64->128,512x512]") if n in named]
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
                 out["kernels"] = kernels
         if world == 1 and not args.skip_cpu_baseline:

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launch of the op
+OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launch of the op ("#k": k-th probe op using it)
     "t2h_linear_fwd[K=512,N=1024]": ["gemm_kernel<128, 128, 2, 2, true, true"],
     "t2h_linear_dgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, true, false"],
     "t2h_linear_wgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, false, false", "reduce_slabs_kernel"],
@@ -20,15 +20,18 @@ OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launc
     "t2h_pool_max_fwd": ["pool_max_fwd_kernel"],
     "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
     "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_kernel", "sample_bwd_gather9_kernel"],
+    "t2h_conv3x3_fwd[64->128,512x512]": ["conv_rows_kernel<128, 2, 2, 0"],
+    "t2h_conv3x3_dgrad[128->64,512x512]": ["conv_rows_kernel<64, 2, 2, 1"],
+    "t2h_conv3x3_wgrad[64->128,512x512]": ["conv_wgrad_kernel<128, 128, 2, 2, 4, false", "reduce_slabs_kernel#3"],
 }
 
 
-REPS = 3      # profiles/pmc_probe.py runs every op this many times
+REPS = 3      # profiles/pmc_probe.py runs every op this many times, one launch of each kernel per run
 
 
 def read_counter(folder, counter):
-    """mean counter value per kernel name; a kernel that serves two probe ops (wgrad: 2 x REPS dispatches) is split by
-    dispatch order into name and name#2."""
+    """mean counter value per kernel name; a kernel that serves several probe ops (REPS dispatches each) is split by
+    dispatch order into name, name#2, name#3 ..."""
     rows = []
     for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
@@ -36,13 +39,16 @@ def read_counter(folder, counter):
     seen, sums, counts = collections.defaultdict(int), collections.defaultdict(float), collections.defaultdict(int)
     for r in rows:
         name = r["Kernel_Name"]
+        group = seen[name] // REPS
         seen[name] += 1
-        key = name if seen[name] <= REPS or "false, false" not in name else name + "#2"
-        if "reduce_slabs" in name:      # 2 launches (dw, db) per wgrad call: first 2*REPS belong to the first wgrad shape
-            key = name if seen[name] <= 2 * REPS else name + "#2"
+        key = name if group == 0 else f"{name}#{group + 1}"
         sums[key] += float(r["Counter_Value"])
         counts[key] += 1
     return {k: sums[k] / counts[k] for k in sums}, counts
+
+
+def _suffix(key):
+    return int(key.rsplit("#", 1)[1]) if "#" in key and key.rsplit("#", 1)[1].isdigit() else 1
 
 
 def main():
@@ -53,17 +59,15 @@ def main():
     for tag, parts in OPS.items():
         total, rows = 0.0, []
         for sub in parts:
-            second = sub.endswith("#2")
-            stem = sub[:-2] if second else sub
-            kf = [k for k in fetch if stem in k and k.endswith("#2") == second]
-            kw = [k for k in write if stem in k and k.endswith("#2") == second]
+            want = _suffix(sub)
+            stem = sub.rsplit("#", 1)[0] if want > 1 else sub
+            kf = [k for k in fetch if stem in k and _suffix(k) == want]
+            kw = [k for k in write if stem in k and _suffix(k) == want]
             if not kf or not kw:
                 total = None
                 break
             f_kib = max(fetch[k] for k in kf)
             w_kib = max(write[k] for k in kw)
-            if "reduce_slabs" in stem:            # dw + db launches: mean per launch x 2
-                f_kib, w_kib = 2 * f_kib, 2 * w_kib
             rows.append({"kernel": sub, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib})
             total += (2.0 * f_kib + w_kib) * 1024.0
         if total is not None:

@@ -14,7 +14,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tomosar2height_amd import mlp, ops                      # noqa: E402
+from tomosar2height_amd import grid, mlp, ops                # noqa: E402
 from tomosar2height_amd.synthetic import berlin_tile          # noqa: E402
 from tomosar2height_amd.tile import TileIndex                 # noqa: E402
 
@@ -52,5 +52,16 @@ plane = rnd(1, 512, 32, 32).contiguous(memory_format=torch.channels_last).requir
 for _ in range(REPS):
     out = ops.sample_plane(tile, plane)                       # sample_fwd_kernel<4>
     out.backward(x512)                                        # sample_bwd_cells_kernel + sample_bwd_gather9_kernel
+# decoder-sized 3x3 convolutions (pixel.py:20-32 at 512 x 512): conv_rows_kernel<128,..,0> / <64,..,1> / conv_wgrad_kernel
+cx, cg = rnd(1, 64, 512, 512).contiguous(memory_format=torch.channels_last), rnd(1, 128, 512, 512).contiguous(memory_format=torch.channels_last)
+cw = (rnd(128, 64, 3, 3) / 24.0).contiguous(memory_format=torch.channels_last)
+cy, cdx = grid._empty_cl(1, 128, 512, 512, dev), grid._empty_cl(1, 64, 512, 512, dev)
+cdw, cdb = torch.empty_like(cw), torch.empty(128, device=dev)
+for _ in range(REPS):
+    grid.conv3x3_fwd_(cx, cw, cdb, cy, relu=True)
+for _ in range(REPS):
+    grid.conv3x3_dgrad_(cg, cw, cdx, mask=cx)
+for _ in range(REPS):
+    grid.conv3x3_wgrad_(cg, cx, cdw, cdb)
 torch.cuda.synchronize()
 print("pmc_probe done")

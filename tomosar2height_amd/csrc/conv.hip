@@ -136,7 +136,10 @@ __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
     }
     float4 ra[2];
     TileLoader<BN, NT, B_KC, BK> lb;
-    int tap = kbeg / p.Ca, c0 = kbeg - tap * p.Ca;     // position of the next slab to load
+    // reduction order: channel slab outer, tap inner -- the 9 (4) taps of one 16-channel slab re-read nearly the same
+    // 64-byte pixel chunks back to back, so they hit L1/L2 instead of coming over the fabric once per tap
+    constexpr int NTAP = IS3X3 ? 9 : (GEOM == G_UP_DGRAD ? 4 : 1);
+    int tap = (kbeg / BK) % NTAP, c0 = (kbeg / BK) / NTAP * BK;     // position of the next slab to load
 
     auto load_slab = [&]() {
         if (IS3X3) {
@@ -162,8 +165,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
             lb.load(p.mat, p.ldmat, n0, p.N, tap * p.Ca + c0, p.K, tid, false);
         else         // B(k, n) = mat[k][tap][n]: direct layout (3x3 dgrad: W[co][tap][ci]; up forward: W[ci][(tap,co)])
             lb.load(p.mat + (size_t)tap * p.N, p.ldmat, n0, p.N, c0, p.Ca, tid, false);
-        c0 += BK;
-        if (c0 >= p.Ca) { c0 = 0; ++tap; }
+        if (++tap == NTAP) { tap = 0; c0 += BK; }
     };
     auto store_slab = [&](float *buf) {
 #pragma unroll
