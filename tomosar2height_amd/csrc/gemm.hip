@@ -162,19 +162,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
                     }
             }
         } else {
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_base[kp * 2 * SA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = b_base[kp * 2 * SB + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+            mfma_slab_f32<TM, TN, SA, SB, BK>(a_base, b_base, acc);     // software-pipelined LDS fragment reads
         }
         if (kt + 1 < nk) {
             la.store(lds + (cur ^ 1) * BUF, tid);

@@ -61,17 +61,28 @@ struct TileLoader {
 // already point at this lane's first element: slab + (lane >> 5) * S + wave offset + (lane & 31).
 template <int TM, int TN, int SA, int SB, int BK>
 __device__ inline void mfma_slab_f32(const float *a_base, const float *b_base, f32x16 (&acc)[TM][TN]) {
+    // software pipelined: the fragments of k-pair kp + 1 are requested from LDS before the MFMAs of kp are issued, so
+    // the LDS latency runs under 4 x 64 MFMA cycles instead of stalling the wave between MFMA groups
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = a_base[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = b_base[j * 32];
 #pragma unroll
     for (int kp = 0; kp < BK / 2; ++kp) {
-        float a[TM], b[TN];
+        const int cur = kp & 1, nxt = cur ^ 1;
+        if (kp + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = a_base[kp * 2 * SA + i * 32];
+            for (int i = 0; i < TM; ++i) a[nxt][i] = a_base[(kp + 1) * 2 * SA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = b_base[kp * 2 * SB + j * 32];
+            for (int j = 0; j < TN; ++j) b[nxt][j] = b_base[(kp + 1) * 2 * SB + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the LDS requests above the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
