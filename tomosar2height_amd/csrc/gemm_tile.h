@@ -34,14 +34,16 @@ struct TileLoader {
                     if (m < rows && kk < kend) v = *reinterpret_cast<const float4 *>(src + (size_t)kk * ld + m);
                 }
             }
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             r[f] = v;
         }
+        relu_pending = relu;        // applied in store(): touching the values here would wait for the loads at once
     }
-    __device__ inline void store(float *__restrict__ lds, int tid) const {   // lds: [BK][ROWS + kPad]
+    bool relu_pending = false;
+    __device__ inline void store(float *__restrict__ lds, int tid) {   // lds: [BK][ROWS + kPad]
 #pragma unroll
         for (int f = 0; f < PER; ++f) {
             int idx = tid + f * NT;
+            if (relu_pending) { r[f].x = fmaxf(r[f].x, 0.f); r[f].y = fmaxf(r[f].y, 0.f); r[f].z = fmaxf(r[f].z, 0.f); r[f].w = fmaxf(r[f].w, 0.f); }
             if (TOTAL % NT == 0 || idx < TOTAL) {
                 if (KC) {
                     int i = idx / (BK / 4), kc = idx % (BK / 4);
