@@ -201,6 +201,7 @@ def test_conv_module_path_uses_hip_and_accumulates_directly():
     layout, and with direct accumulation the gradient lands in the existing .grad buffers (the trainer's bucket)."""
     from tomosar2height_amd import grid, mlp
     g = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
     conv = torch.nn.Conv2d(32, 64, 3, padding=1).to(_dev()).to(memory_format=torch.channels_last)
     x = _cl(torch.randn(1, 32, 64, 64, generator=g)).requires_grad_(True)
     gout = _cl(torch.randn(1, 64, 64, 64, generator=g))
@@ -214,20 +215,25 @@ def test_conv_module_path_uses_hip_and_accumulates_directly():
     yr.backward(gout)
     _close(got[0], yr.detach().cpu(), tol=1e-5)
     _loose_fp64(zip(got[1:], (x.grad.cpu(), conv.weight.grad.cpu(), conv.bias.grad.cpu())))
-    # direct accumulation into pre-existing gradient buffers
+    # direct accumulation into pre-existing gradient buffers (created by the HIP path: channels_last like the parameter;
+    # the layout of a gradient that MIOpen allocates depends on the algorithm it picks)
+    x.grad = None
+    conv.zero_grad()
+    grid.conv_bias_act(x, conv, relu=True).backward(gout)
     wbuf, bbuf = conv.weight.grad, conv.bias.grad
+    assert wbuf.permute(0, 2, 3, 1).is_contiguous()
     w0, b0 = wbuf.clone(), bbuf.clone()
     with mlp.direct_grad_accumulation(True):
         grid.conv_bias_act(x, conv, relu=True).backward(gout)
     assert conv.weight.grad is wbuf and conv.bias.grad is bbuf
-    _close(wbuf - w0, got[2].cpu(), tol=1e-6)
-    _close(bbuf - b0, got[3].cpu(), tol=1e-6)
+    assert torch.equal(wbuf, w0 + w0) and torch.equal(bbuf, b0 + b0)
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(64, 32, 64), (32, 32, 33), (256, 512, 8)])
 def test_conv1x1_on_gemm_kernels(cin, cout, hw):
     from tomosar2height_amd import grid
     g = torch.Generator().manual_seed(cin * cout)
+    torch.manual_seed(cin * cout)
     conv = torch.nn.Conv2d(cin, cout, 1)
     x = torch.randn(2, cin, hw, hw, generator=g)
     gout = torch.randn(2, cout, hw, hw, generator=g)
@@ -252,6 +258,7 @@ def test_upconv2x2_matches_conv_transpose(b, h, w, cin, cout):
     import copy
     from tomosar2height_amd import grid, mlp
     g = torch.Generator().manual_seed(b + h + cin + cout)
+    torch.manual_seed(b + h + cin + cout)
     conv = torch.nn.ConvTranspose2d(cin, cout, 2, stride=2)
     ref = copy.deepcopy(conv).double()
     x = torch.randn(b, cin, h, w, generator=g)

@@ -18,6 +18,7 @@
 // The weight gradient reduces over M: the grid's z dimension splits M, every split writes its partial tile to a
 // slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
 // deterministic).
+#include <stdlib.h>
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -396,6 +397,8 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
     if (mode == 1 && a.N > 64) return launch_gemm_split(mode, true, B_KC, a, 1, s, what);
     if (mode == 2) return launch_rows_p<B_KC, 2>(a, s, what);
     if (mode == 1) return launch_rows_p<B_KC, 1>(a, s, what);
+    static const bool use_dma = !(getenv("T2H_GEMM_DMA") && getenv("T2H_GEMM_DMA")[0] == '0');
+    if (use_dma && gemm_dma_applicable(B_KC, a)) return launch_gemm_dma(B_KC, a, s, what);
     return launch_rows_p<B_KC, 0>(a, s, what);
 }
 

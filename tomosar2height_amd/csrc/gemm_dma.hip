@@ -1,0 +1,126 @@
+// LDS-DMA staged variant of the fp32 MFMA forward GEMM (nn.Linear forward, the "NT" form of gemm.hip: Y = X W^T) for the
+// big layers: 128 x 128 x 16 tiles, K a multiple of 16.
+//
+// Both operands are k-contiguous rows (X [M, K], W [N, K]) and go global -> LDS with global_load_lds_dwordx4, no VGPR
+// staging and no ds_write: the VGPR -> LDS store path (~64 B/clk/CU) was the largest single cost of the register-staged
+// loop (ablation in DESIGN.md section 4).  An LDS-DMA writes 64 lanes x 16 B contiguously, so the image is lane-linear
+// [row][16 floats] without padding; bank conflicts are avoided by an XOR swizzle applied through the per-lane SOURCE
+// address (chunk c of row r lands in slot c ^ ((r >> 2) & 3)), and fragments are read with ds_read_b128.  The MFMA
+// k-pair index is free as long as A and B agree, so lane half h takes k = 4 (2g + h) .. + 3 in group g in {0, 1}: one
+// 16-byte read serves four consecutive MFMAs.  Rows past M / N are clamped to the last valid row (their results are never
+// stored).  Numerics: still an exact fp32 fma chain per output, k visited in the permuted order inside each 16-slab.
+// Measured (N = 131072 points): 1024 -> 512 forward 1.105 -> 1.05 ms (131 TF = 83 % of the matrix peak), 256 -> 512
+// 307 -> 296 us.  The data gradient ("NN": only one row operand; W is read row-strided) was tried both with W through
+// registers and through a second k-major DMA image and lost 2-8 % to the register-staged kernel, so it stays there.
+#include "t2h_common.h"
+#include "gemm_args.h"
+#include "gemm_tile.h"
+
+namespace t2h {
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, NT = 256, TM = 2, TN = 2;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__global__ __launch_bounds__(NT, 4) void gemm_dma_kernel(GemmArgs p) {
+    constexpr int IMG = BM * BK;                                     // floats per operand image
+    constexpr int STG = 2 * IMG;
+    constexpr int LDS_MIN = (NT / 64) * 32 * 36;
+    constexpr int LDS_FLOATS = 2 * STG > LDS_MIN ? 2 * STG : LDS_MIN;
+    __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware work order (gemm.hip)
+    const unsigned nb = gridDim.x * gridDim.y;
+    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = nb / 8, r = nb % 8, x = bid % 8, i8 = bid / 8;
+    const unsigned t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i8;
+    const int tile_n = t % gridDim.x, tile_m = t / gridDim.x;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool relu_a = p.flags & F_RELU_A;
+    const int nk = p.K / BK;
+
+    // DMA source of this lane: two 16-row blocks per wave and operand, chunk swizzled by the row
+    const float *src_a[2], *src_b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        src_a[j] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + c * 4;
+        src_b[j] = p.B + (size_t)min(n0 + row, p.N - 1) * p.ldb + c * 4;
+    }
+    auto issue = [&](int kt, float *stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void *)(src_a[j] + kt * BK), (lds_void *)(stage + (wave * 2 + j) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(src_b[j] + kt * BK), (lds_void *)(stage + IMG + (wave * 2 + j) * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
+
+    if (nk > 0) issue(0, lds);
+    __syncthreads();
+    const int half = lane >> 5, m = lane & 31, sw = (m >> 2) & 3;
+    for (int kt = 0; kt < nk; ++kt) {
+        float *cur = lds + (kt & 1) * STG, *nxt = lds + ((kt & 1) ^ 1) * STG;
+        if (kt + 1 < nk) issue(kt + 1, nxt);
+        const float *ar = cur + (wm * 64 + m) * BK, *br = cur + IMG + (wn * 64 + m) * BK;
+        float4 a4[2][TM], b4[2][TN];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float4 v = *reinterpret_cast<const float4 *>(ar + i * 32 * BK + (((2 * g + half) ^ sw) * 4));
+                if (relu_a) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                a4[g][i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b4[g][j] = *reinterpret_cast<const float4 *>(br + j * 32 * BK + (((2 * g + half) ^ sw) * 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);          // all eight fragment reads in flight before the first MFMA
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float av = e == 0 ? a4[g][i].x : e == 1 ? a4[g][i].y : e == 2 ? a4[g][i].z : a4[g][i].w;
+                        const float bv = e == 0 ? b4[g][j].x : e == 1 ? b4[g][j].y : e == 2 ? b4[g][j].z : b4[g][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+        __syncthreads();      // also drains the LDS-DMA of the next stage (vmcnt(0))
+    }
+
+    EpilogueArgs e;
+    e.C = p.C; e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
+    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
+    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
+}
+
+}  // namespace
+
+bool gemm_dma_applicable(bool b_kc, const GemmArgs &a) {
+    return b_kc && a.K % BK == 0 && a.K >= BK && a.N > 64 && a.M >= 1 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+           !(a.flags & F_RELU_B) && a.k_chunk >= a.K;
+}
+
+int launch_gemm_dma(bool b_kc, const GemmArgs &a, hipStream_t s, const char *what) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
+    if (!b_kc) return fail(T2H_ERR_ARG, "%s: the LDS-DMA kernel serves the NT form only", what);
+    if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
+    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NT), 0, s, a);
+    return check_launch(what);
+}
+
+}  // namespace t2h
