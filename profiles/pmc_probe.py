@@ -35,10 +35,15 @@ b = rnd(1024)
 y = torch.empty(M, 1024, device=dev)
 dw, db = torch.empty(1024, 512, device=dev), torch.empty(1024, device=dev)
 torch.cuda.synchronize()
+w2, b2, y2 = rnd(512, 1024) / 32.0, rnd(512), torch.empty(M, 512, device=dev)
 for _ in range(REPS):
-    mlp.linear_fwd_(x512, w, b, y, relu_out=True)             # gemm_kernel<128,128,2,2,true,true>
+    mlp.linear_fwd_(x512, w, b, y, relu_out=True)             # gemm_dma_kernel (LDS-DMA staged NT), K=512 -> N=1024
 for _ in range(REPS):
-    mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_kernel<128,128,2,2,true,false>
+    mlp.linear_fwd_(x1024, w2, b2, y2)                        # gemm_dma_kernel, K=1024 -> N=512
+for _ in range(REPS):
+    mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_kernel<128,128,2,2,true,false>, dX[M,512]
+for _ in range(REPS):
+    mlp.linear_dgrad_(x512, w2, x1024.clone(), mask=x1024)    # same kernel, dX[M,1024]
 for _ in range(REPS):
     mlp.linear_wgrad_(x1024, x512, dw, db)                    # gemm_kernel<128,128,2,2,false,false> + reduce_slabs
 dw2, db2 = torch.empty(512, 1024, device=dev), torch.empty(512, device=dev)

@@ -17,7 +17,9 @@ def _rel(got, want):
 
 
 SHAPES = [(300, 8, 16), (257, 64, 32), (1000, 32, 32), (4096, 64, 128), (777, 128, 64), (3000, 256, 512),
-          (2048, 512, 1024), (1500, 1024, 512), (129, 3, 64), (5000, 36, 20)]
+          (2048, 512, 1024), (1500, 1024, 512), (129, 3, 64), (5000, 36, 20),
+          # edges of the LDS-DMA staged forward kernel (N > 64, K % 16 == 0): one row, ragged row / column tiles, one slab
+          (1, 16, 128), (129, 48, 96), (500, 16, 200)]
 
 
 @pytest.mark.parametrize("m,k,n", SHAPES)
