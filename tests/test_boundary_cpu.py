@@ -40,6 +40,34 @@ def test_host_side_helpers_need_no_gpu():
     assert b"null pointer" in lib.t2h_last_error_string()
 
 
+def test_grid_conv_dispatch_host_logic():
+    """grid.py's routing (host logic, no launches): which convolutions the implicit-GEMM kernels accept, workspace
+    plans of the C side, and that geometry outside them is left to the stock module."""
+    from tomosar2height_amd import _lib, grid
+    lib = _lib.load()
+    x = torch.rand(1, 32, 16, 16)
+    assert not grid.conv3x3_supported(x, torch.nn.Conv2d(32, 32, 3, padding=1))                 # host tensor
+    assert not grid.upconv2x2_supported(x, torch.nn.ConvTranspose2d(32, 16, 2, stride=2))
+    meta = torch.empty(1, 32, 16, 16, device="meta")
+    for conv, ok in ((torch.nn.Conv2d(32, 64, 3, padding=1), None), (torch.nn.Conv2d(32, 64, 3, padding=0), False),
+                     (torch.nn.Conv2d(32, 64, 3, stride=2, padding=1), False), (torch.nn.Conv2d(24, 64, 3, padding=1), False),
+                     (torch.nn.Conv2d(32, 64, 5, padding=2), False), (torch.nn.Conv2d(32, 64, 3, padding=1, groups=2), False)):
+        if ok is False:
+            assert not grid.conv3x3_supported(meta, conv)
+    # split-reduction plans: small planes with many channels need slabs, large planes do not; weight gradients always do
+    assert lib.t2h_conv3x3_fwd_workspace_bytes(1, 32, 32, 512, 512) % (1024 * 512 * 4) == 0
+    assert lib.t2h_conv3x3_fwd_workspace_bytes(1, 32, 32, 512, 512) > 0
+    assert lib.t2h_conv3x3_dgrad_workspace_bytes(1, 512, 512, 64, 128) == 0
+    assert lib.t2h_conv3x3_wgrad_workspace_bytes(1, 512, 512, 64, 128) >= (128 * 9 * 64 + 128) * 4
+    assert lib.t2h_upconv2x2_wgrad_workspace_bytes(1, 32, 32, 512, 256) >= 512 * 4 * 256 * 4
+    assert lib.t2h_conv3x3_fwd_workspace_bytes(0, 32, 32, 512, 512) == 0
+    # geometry errors come back as codes with a message, never as a launch
+    assert lib.t2h_conv3x3_fwd(1, 1, None, 1, 1, 12, 16, 32, 32, 0, None, 0, None) < 0
+    assert b"powers of two" in lib.t2h_last_error_string()
+    assert lib.t2h_upconv2x2_fwd(1, 1, None, 1, 1, 16, 16, 24, 32, 0, None) < 0
+    assert b"multiples of 16" in lib.t2h_last_error_string()
+
+
 def test_no_cpu_fallback():
     from tomosar2height_amd.tile import TileIndex
     from tomosar2height_amd import ops
