@@ -337,6 +337,36 @@ def test_training_step_is_bit_reproducible():
     assert torch.equal(g1, g3)
 
 
+def test_batched_training_step_equals_mean_of_single_tile_steps():
+    """B = 2 tiles in one forward/backward (cell ids offset per tile, image borders inside the convolution row tiles):
+    the L1(mean) loss gradient equals the average of the two single-tile gradients (channels_last / HIP convolutions)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    model = det_init_(TomoSAR2Height(cfg), seed=31).to(_dev())
+    model.set_channels_last(True)
+    clouds = torch.cat([synth_cloud(6000, seed=810 + i) for i in range(2)], 0).to(_dev())
+    dsm = (torch.rand(2, 512, 512, generator=torch.Generator().manual_seed(8)) * 30).to(_dev())
+
+    def grads(cloud, target):
+        model.zero_grad(set_to_none=True)
+        pa, _ = model(input_cloud=cloud)
+        torch.nn.functional.smooth_l1_loss(pa.squeeze(-1), target).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    both = grads(clouds, dsm)
+    one = [grads(clouds[i:i + 1].contiguous(), dsm[i:i + 1]) for i in range(2)]
+    assert both.keys() == one[0].keys()
+    num = den = 0.0
+    for k in both:
+        want = 0.5 * (one[0][k] + one[1][k])
+        num += (both[k] - want).double().pow(2).sum().item()
+        den += want.double().pow(2).sum().item()
+        assert (both[k] - want).abs().max().item() <= 2e-3 * (want.abs().max().item() + 1e-12), k
+    assert num <= (1e-4 ** 2) * den
+
+
 def test_batched_tiles_equal_single_tiles():
     """BASELINE configs[4] (large-batch inference): B tiles of equal N in one forward (cell ids offset by b*R^2) give the
     same heights as B single-tile forwards, for Munich (depth 6, footprint head, image encoder)."""
