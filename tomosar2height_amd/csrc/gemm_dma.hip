@@ -10,8 +10,9 @@
 // 16-byte read serves four consecutive MFMAs.  Rows past M / N are clamped to the last valid row (their results are never
 // stored).  Numerics: still an exact fp32 fma chain per output, k visited in the permuted order inside each 16-slab.
 // Measured (N = 131072 points): 1024 -> 512 forward 1.105 -> 1.05 ms (131 TF = 83 % of the matrix peak), 256 -> 512
-// 307 -> 296 us.  The data gradient ("NN": only one row operand; W is read row-strided) was tried both with W through
-// registers and through a second k-major DMA image and lost 2-8 % to the register-staged kernel, so it stays there.
+// 307 -> 296 us.  The data gradient ("NN": dY rows as above, W [k][n] as a k-major DMA image read by ds_read_b32 in the
+// same k order) wins only with every fragment read of a slab issued before its MFMAs, and only for long reductions
+// (gemm_dma_applicable); interleaving the W reads with the MFMAs, or W through registers, lost 2-8 %.
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -108,18 +109,99 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_kernel(GemmArgs p) {
     store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
 }
 
+// Data gradient ("NN"): A = dY rows (row image as above), B(k, n) = W[k][n] k-major: DMA image [16][128] (two k rows per
+// wave instruction), fragments by ds_read_b32 in the same permuted k order, all reads of a slab issued before its MFMAs.
+__global__ __launch_bounds__(NT, 4) void gemm_dma_nn_kernel(GemmArgs p) {
+    constexpr int IMG = BM * BK;
+    constexpr int STG = 2 * IMG;
+    constexpr int LDS_MIN = (NT / 64) * 32 * 36;
+    constexpr int LDS_FLOATS = 2 * STG > LDS_MIN ? 2 * STG : LDS_MIN;
+    __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned nb = gridDim.x * gridDim.y;
+    const unsigned bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = nb / 8, r = nb % 8, x = bid % 8, i8 = bid / 8;
+    const unsigned t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i8;
+    const int tile_n = t % gridDim.x, tile_m = t / gridDim.x;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K / BK;
+    const float *src_a[2], *src_b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        src_a[j] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + c * 4;
+        src_b[j] = p.B + (size_t)((wave * 2 + j) * 2 + (lane >> 5)) * p.ldb + min(n0 + (lane & 31) * 4, p.N - 4);
+    }
+    auto issue = [&](int kt, float *stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void *)(src_a[j] + kt * BK), (lds_void *)(stage + (wave * 2 + j) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(src_b[j] + (size_t)kt * BK * p.ldb),
+                                             (lds_void *)(stage + IMG + (wave * 2 + j) * 256), 16, 0, 0);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
+    if (nk > 0) issue(0, lds);
+    __syncthreads();
+    const int half = lane >> 5, m = lane & 31, sw = (m >> 2) & 3;
+    for (int kt = 0; kt < nk; ++kt) {
+        float *cur = lds + (kt & 1) * STG, *nxt = lds + ((kt & 1) ^ 1) * STG;
+        if (kt + 1 < nk) issue(kt + 1, nxt);
+        const float *ar = cur + (wm * 64 + m) * BK;
+        const float *bb = cur + IMG + (4 * half) * BN + wn * 64 + m;
+        float4 a4[2][TM];
+        float b[8][TN];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[g][i] = *reinterpret_cast<const float4 *>(ar + i * 32 * BK + (((2 * g + half) ^ sw) * 4));
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s][j] = bb[(8 * (s >> 2) + (s & 3)) * BN + j * 32];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int g = s >> 2, e = s & 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float av = e == 0 ? a4[g][i].x : e == 1 ? a4[g][i].y : e == 2 ? a4[g][i].z : a4[g][i].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[s][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    EpilogueArgs e;
+    e.C = p.C; e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
+    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
+    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
+}
+
 }  // namespace
 
 bool gemm_dma_applicable(bool b_kc, const GemmArgs &a) {
-    return b_kc && a.K % BK == 0 && a.K >= BK && a.N > 64 && a.M >= 1 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+    // NN (data gradient): measured faster than the register-staged kernel when the reduction is long (>= 512) or at
+    // least as long as the output is wide (1024->512: 1.16 -> 1.08 ms, 512->256: 320 -> 310 us), slower by 2-3 % otherwise
+    if (!b_kc && !(a.N % 4 == 0 && a.N >= 4 && !(a.flags & F_RELU_A) && (a.K >= 512 || a.K >= a.N))) return false;
+    return a.K % BK == 0 && a.K >= BK && a.N > 64 && a.M >= 1 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
            !(a.flags & F_RELU_B) && a.k_chunk >= a.K;
 }
 
 int launch_gemm_dma(bool b_kc, const GemmArgs &a, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
-    if (!b_kc) return fail(T2H_ERR_ARG, "%s: the LDS-DMA kernel serves the NT form only", what);
     if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
-    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NT), 0, s, a);
+    if (b_kc) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL(gemm_dma_nn_kernel, grid, dim3(NT), 0, s, a);
     return check_launch(what);
 }
 
