@@ -14,8 +14,8 @@ import sys
 OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launch of the op ("#k": k-th probe op using it)
     "t2h_linear_fwd[K=512,N=1024]": ["gemm_dma_kernel"],
     "t2h_linear_fwd[K=1024,N=512]": ["gemm_dma_kernel#2"],
-    "t2h_linear_dgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, true, false"],
-    "t2h_linear_dgrad[N=512,K=1024]": ["gemm_kernel<128, 128, 2, 2, true, false#2"],
+    "t2h_linear_dgrad[N=1024,K=512]": ["gemm_dma_nn_kernel"],
+    "t2h_linear_dgrad[N=512,K=1024]": ["gemm_dma_nn_kernel#2"],
     "t2h_linear_wgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, false, false", "reduce_slabs_kernel"],
     "t2h_linear_wgrad[N=512,K=1024]": ["gemm_kernel<128, 128, 2, 2, false, false#2", "reduce_slabs_kernel#2"],
     "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],

@@ -41,7 +41,7 @@ for _ in range(REPS):
 for _ in range(REPS):
     mlp.linear_fwd_(x1024, w2, b2, y2)                        # gemm_dma_kernel, K=1024 -> N=512
 for _ in range(REPS):
-    mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_kernel<128,128,2,2,true,false>, dX[M,512]
+    mlp.linear_dgrad_(x1024, w, x512.clone(), mask=x512)      # gemm_dma_nn_kernel (LDS-DMA staged NN), dX[M,512]
 for _ in range(REPS):
     mlp.linear_dgrad_(x512, w2, x1024.clone(), mask=x1024)    # same kernel, dX[M,1024]
 for _ in range(REPS):
