@@ -526,7 +526,10 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
     (mode == 2 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 2 ? 2 : MW_), 2>(a, p.splits, s, "linear_wgrad") \
      : mode == 1 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 3 ? 3 : MW_), 1>(a, p.splits, s, "linear_wgrad") \
                  : launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, MW_, 0>(a, p.splits, s, "linear_wgrad"))
-        if (p.bm == 128 && p.bn == 128)
+        static const bool tn_dma = !(getenv("T2H_GEMM_DMA") && getenv("T2H_GEMM_DMA")[0] == '0');
+        if (p.bm == 128 && p.bn == 128 && mode == 0 && tn_dma && gemm_dma_tn_applicable(a))
+            rc = launch_gemm_dma_tn(a, p.splits, s, "linear_wgrad");
+        else if (p.bm == 128 && p.bn == 128)
             rc = mode != 0 ? launch_gemm_split(mode, false, false, a, p.splits, s, "linear_wgrad") : T2H_WG(128, 128, 2, 2, 4);
         else if (p.bm == 128 && p.bn == 64) rc = T2H_WG(128, 64, 2, 2, 1);
         else if (p.bm == 128 && p.bn == 32) rc = T2H_WG(128, 32, 4, 1, 1);

@@ -25,5 +25,7 @@ int launch_gemm_split(int mode, bool a_kc, bool b_kc, const GemmArgs &a, int spl
 // gemm_dma.hip: LDS-DMA staged 128x128x16 fp32 kernels for the big row-streaming layers (NT: b_kc, NN: !b_kc)
 bool gemm_dma_applicable(bool b_kc, const GemmArgs &a);
 int launch_gemm_dma(bool b_kc, const GemmArgs &a, hipStream_t s, const char *what);
+bool gemm_dma_tn_applicable(const GemmArgs &a);
+int launch_gemm_dma_tn(const GemmArgs &a, int splits, hipStream_t s, const char *what);
 
 }  // namespace t2h

@@ -187,6 +187,118 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_nn_kernel(GemmArgs p) {
     store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
 }
 
+// Weight gradient ("TN": dW[n, j] = sum_m dY[m, n] X[m, j], reduction over the rows m split across grid.z): both
+// operands are k-major, so both images are [16 k][128] DMA images read by ds_read_b32 in the permuted k order, all 32
+// fragment values of a slab requested before its MFMAs.  Rows past the split's end are clamped to valid memory for the
+// DMA and zeroed in the A fragments (last slab only); the bias gradient (column sums of dY) is read back from the A
+// image by the workgroups of the first column tile.
+__global__ __launch_bounds__(NT, 4) void gemm_dma_tn_kernel(GemmArgs p) {
+    constexpr int IMG = BK * BM;
+    constexpr int STG = 2 * IMG;
+    constexpr int LDS_MIN = (NT / 64) * 32 * 36;
+    constexpr int LDS_FLOATS = 2 * STG > LDS_MIN ? 2 * STG : LDS_MIN;
+    __shared__ __attribute__((aligned(1024))) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned q = nb / 8, r = nb % 8, x = bid % 8, i8 = bid / 8;
+    const unsigned t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i8;
+    const int tile_n = t % gridDim.x, tile_m = (t / gridDim.x) % gridDim.y, split = t / (gridDim.x * gridDim.y);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool relu_b = p.flags & F_RELU_B;
+    const bool do_colsum = p.colsum != nullptr && tile_n == 0;
+
+    // DMA: wave instruction j of wave w covers k rows 2 (2w + j) + (lane >> 5), columns 4 (lane & 31) .. + 3
+    const int col_a = min(m0 + (lane & 31) * 4, p.M - 4), col_b = min(n0 + (lane & 31) * 4, p.N - 4);
+    auto issue = [&](int k0, float *stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int krow = min(k0 + (wave * 2 + j) * 2 + (lane >> 5), p.K - 1);
+            __builtin_amdgcn_global_load_lds((glb_void *)(p.A + (size_t)krow * p.lda + col_a), (lds_void *)(stage + (wave * 2 + j) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(p.B + (size_t)krow * p.ldb + col_b), (lds_void *)(stage + IMG + (wave * 2 + j) * 256),
+                                             16, 0, 0);
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nk > 0) issue(kbeg, lds);
+    __syncthreads();
+    const int half = lane >> 5, m = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        float *cur = lds + (kt & 1) * STG, *nxt = lds + ((kt & 1) ^ 1) * STG;
+        const int k0 = kbeg + kt * BK;
+        if (kt + 1 < nk) issue(k0 + BK, nxt);
+        const float *ab = cur + (4 * half) * BM + wm * 64 + m;
+        const float *bb = cur + IMG + (4 * half) * BN + wn * 64 + m;
+        float a[8][TM], b[8][TN];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[s][i] = ab[(8 * (s >> 2) + (s & 3)) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s][j] = bb[(8 * (s >> 2) + (s & 3)) * BN + j * 32];
+        }
+        if (do_colsum) {     // this thread: column group tid & 31, k rows tid >> 5 and (tid >> 5) + 8 of the A image
+            const int kr = tid >> 5;
+            const float4 v0 = *reinterpret_cast<const float4 *>(cur + kr * BM + (tid & 31) * 4);
+            const float4 v1 = *reinterpret_cast<const float4 *>(cur + (kr + 8) * BM + (tid & 31) * 4);
+            if (k0 + kr < kend) { csum.x += v0.x; csum.y += v0.y; csum.z += v0.z; csum.w += v0.w; }
+            if (k0 + kr + 8 < kend) { csum.x += v1.x; csum.y += v1.y; csum.z += v1.z; csum.w += v1.w; }
+        }
+        if (k0 + BK > kend) {      // partial last slab: rows past the end were clamped for the DMA, drop them here
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (k0 + 8 * (s >> 2) + 4 * half + (s & 3) >= kend) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[s][i] = 0.0f;
+                }
+        }
+        if (relu_b) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[s][j] = fmaxf(b[s][j], 0.0f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    if (do_colsum) {       // fixed-order reduction over the 8 threads that share a column group (as gemm.hip)
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 tt = red[tid];
+            for (int j = tid + 32; j < NT; j += 32) { tt.x += red[j].x; tt.y += red[j].y; tt.z += red[j].z; tt.w += red[j].w; }
+            float *dst = p.colsum + (size_t)split * p.M + m0 + tid * 4;
+            const float tv[4] = {tt.x, tt.y, tt.z, tt.w};
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+                if (m0 + tid * 4 + z < p.M) dst[z] = tv[z];
+        }
+        __syncthreads();
+    }
+    EpilogueArgs e;
+    e.C = p.C + (size_t)split * p.slab_stride;
+    e.bias = nullptr; e.mask = nullptr; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = 0;
+    e.accum = false; e.relu_out = false;
+    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
+}
+
 }  // namespace
 
 bool gemm_dma_applicable(bool b_kc, const GemmArgs &a) {
@@ -202,6 +314,18 @@ int launch_gemm_dma(bool b_kc, const GemmArgs &a, hipStream_t s, const char *wha
     if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
     if (b_kc) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(gemm_dma_nn_kernel, grid, dim3(NT), 0, s, a);
+    return check_launch(what);
+}
+
+// TN (weight gradient), 128 x 128 tiles, reduction rows split over grid.z
+bool gemm_dma_tn_applicable(const GemmArgs &a) {
+    return a.M % 4 == 0 && a.N % 4 == 0 && a.M >= 4 && a.N >= 4 && a.K >= 1 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.k_chunk % BK == 0;
+}
+
+int launch_gemm_dma_tn(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
+    if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
+    hipLaunchKernelGGL(gemm_dma_tn_kernel, grid, dim3(NT), 0, s, a);
     return check_launch(what);
 }
 
