@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void linear_smallk_fwd_kernel(const float *__r
 }
 
 constexpr int kSmallKMax = 8;
-constexpr int kSmallKRows = 512;   // rows per workgroup
+constexpr int kSmallKRows = 128;   // rows per workgroup (1024 workgroups at 131072 points)
 // slab[z][n][k] = sum over the workgroup's rows of dy[m][n] * x[m][k];  colslab[z][n] = sum dy[m][n]
 __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restrict__ dy, int lddy,
                                                           const float *__restrict__ x, int ldx, int M, int K, int N,
@@ -342,16 +342,23 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
 #pragma unroll
         for (int k = 0; k <= kSmallKMax; ++k) acc[k] = 0.0f;
         if (n < N && slot < slots) {
-            for (int m = m_begin + slot; m < m_end; m += slots) {
-                float g = dy[(size_t)m * lddy + n];
-                acc[kSmallKMax] += g;
+            // four rows of dY in flight per lane; accumulation stays in ascending row order
+            for (int m = m_begin + slot; m < m_end; m += 4 * slots) {
+                float g[4];
 #pragma unroll
-                for (int k = 0; k < kSmallKMax; ++k)
-                    if (k < K) {
-                        float v = x[(size_t)m * ldx + k];
-                        if (relu_x) v = fmaxf(v, 0.0f);
-                        acc[k] = fmaf(g, v, acc[k]);
-                    }
+                for (int u = 0; u < 4; ++u) g[u] = m + u * slots < m_end ? dy[(size_t)(m + u * slots) * lddy + n] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (m + u * slots >= m_end) break;
+                    acc[kSmallKMax] += g[u];
+#pragma unroll
+                    for (int k = 0; k < kSmallKMax; ++k)
+                        if (k < K) {
+                            float v = x[(size_t)(m + u * slots) * ldx + k];
+                            if (relu_x) v = fmaxf(v, 0.0f);
+                            acc[k] = fmaf(g[u], v, acc[k]);
+                        }
+                }
             }
         }
         __syncthreads();
