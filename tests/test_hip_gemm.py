@@ -1,6 +1,5 @@
 """GPU parity of the fp32 MFMA linear-layer kernels (t2h_linear_fwd / dgrad / wgrad) against float64 on the CPU.
 Tolerance: fp32 fma-chain rounding, 2e-5 relative to the output scale (K up to 1024)."""
-import numpy as np
 import pytest
 import torch
 
