@@ -107,3 +107,31 @@ def test_full_model_on_degenerate_tiles():
         assert torch.isfinite(got).all()
         scale = want.abs().max().item() + 1e-9
         assert (got.cpu() - want).abs().max().item() <= 1e-4 * scale, name
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_training_step_on_ragged_point_counts(channels_last):
+    """Forward + backward of the whole network at point counts around the tile edges of the GEMM kernels (rows of the
+    per-point GEMMs, reduction length of the weight gradients): heights equal to the oracle's, every gradient finite."""
+    from detinit import det_init_
+    from oracle import torch_ref
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    ref = det_init_(torch_ref.TomoSAR2Height(cfg), seed=32)
+    model = TomoSAR2Height(cfg)
+    model.load_state_dict(ref.state_dict())
+    model.to(_dev())
+    model.set_channels_last(channels_last)
+    for n in (1, 7, 129, 4097):
+        cloud = synth_cloud(n, seed=40 + n)
+        model.zero_grad(set_to_none=True)
+        got, _ = model(input_cloud=cloud.to(_dev()))
+        got.square().mean().backward()
+        with torch.no_grad():
+            want, _ = ref(input_cloud=cloud)
+        scale = want.abs().max().item() + 1e-9
+        assert (got.detach().cpu() - want).abs().max().item() <= 1e-4 * scale, n
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        assert len(grads) > 100 and all(torch.isfinite(g).all() for g in grads), n
