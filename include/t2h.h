@@ -186,6 +186,12 @@ int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *C, int n
                     t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W,
                                    float *out, t2h_stream_t stream);
+/* nn.MaxPool2d(kernel_size=2, stride=2) on NHWC planes (DownConv.pool, alto.py:104-114,132-135): in [B,H,W,C] (H, W even),
+ * out [B,H/2,W/2,C]; which [B,H/2,W/2,C] bytes = 2*dy+dx of the first maximum in scan order (ATen's tie-break); the
+ * backward writes every element of gin [B,H,W,C] exactly once. */
+int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream);
+int t2h_maxpool2x2_nhwc_bwd(const float *gout, const uint8_t *which, int B, int H, int W, int C, float *gin,
+                            t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
                                    t2h_stream_t stream);
 

@@ -82,3 +82,23 @@ def test_upsample_cl_vs_oracle(b, c, h, size):
     np.testing.assert_allclose(xd.grad.cpu().numpy(), c_oracle.upsample_bilinear_bwd(gout.numpy(), h, h), rtol=1e-5, atol=1e-5)
     y2 = grid.upsample_bilinear_cl(xd.detach(), size, _cl(add))
     np.testing.assert_allclose(y2.cpu().numpy(), y.detach().cpu().numpy() + add.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(1, 32, 64, 64), (2, 64, 6, 10), (1, 512, 2, 2), (1, 4, 256, 256)])
+def test_maxpool2x2_matches_aten_including_ties(b, c, h, w):
+    """2x2 max-pool forward / backward on NHWC planes against ATen on the CPU; the planes hold many exact ties (zeros,
+    repeated values) whose gradient routing (first maximum in scan order) must match."""
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(b * c + h)
+    x = torch.randint(-2, 3, (b, c, h, w), generator=g).float()          # few distinct values: ties in most windows
+    x[:, :, : h // 2] *= (torch.rand(b, c, h // 2, w, generator=g) < 0.5)  # and blocks of zeros
+    gout = torch.randn(b, c, h // 2, w // 2, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    yr.backward(gout)
+    xg = _cl(x).requires_grad_(True)
+    y = grid.maxpool2x2(xg, torch.nn.MaxPool2d(2, 2))
+    assert type(y.grad_fn).__name__ == "_MaxPool2x2Backward"
+    y.backward(_cl(gout))
+    assert torch.equal(y.detach().cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)

@@ -276,6 +276,57 @@ __global__ __launch_bounds__(kT) void upsample_nhwc_bwd_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 2x2 max-pool (NHWC)
+// nn.MaxPool2d(kernel_size=2, stride=2) of the ALTO down path (alto.py:104-114,132-135): first maximum in window scan
+// order (0,0),(0,1),(1,0),(1,1) wins, like ATen's strict '>' -- the planes are full of exact ties (empty cells = 0).
+// which[pixel][c] = 2 * dy + dx of the winner, one byte per output element, consumed by the backward.
+__global__ __launch_bounds__(kT) void maxpool2x2_fwd_kernel(const float *__restrict__ in, int B, int H, int W, int C, int lg,
+                                                            float *__restrict__ out, uint8_t *__restrict__ which) {
+    long long t = (long long)blockIdx.x * kT + threadIdx.x;
+    long long pix = t >> lg;
+    const int h = H / 2, w = W / 2;
+    if (pix >= (long long)B * h * w) return;
+    int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((long long)w * h));
+    const float *p00 = in + (((size_t)b * H + 2 * y) * W + 2 * x) * C;
+    const float *p10 = p00 + (size_t)W * C;
+    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
+        const float4 v[4] = {*reinterpret_cast<const float4 *>(p00 + c), *reinterpret_cast<const float4 *>(p00 + C + c),
+                             *reinterpret_cast<const float4 *>(p10 + c), *reinterpret_cast<const float4 *>(p10 + C + c)};
+        float4 best = v[0];
+        uchar4 arg = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (v[k].x > best.x || v[k].x != v[k].x) { best.x = v[k].x; arg.x = k; }     // NaN propagates like ATen
+            if (v[k].y > best.y || v[k].y != v[k].y) { best.y = v[k].y; arg.y = k; }
+            if (v[k].z > best.z || v[k].z != v[k].z) { best.z = v[k].z; arg.z = k; }
+            if (v[k].w > best.w || v[k].w != v[k].w) { best.w = v[k].w; arg.w = k; }
+        }
+        *reinterpret_cast<float4 *>(out + pix * C + c) = best;
+        *reinterpret_cast<uchar4 *>(which + pix * C + c) = arg;
+    }
+}
+
+// gin[2y+dy, 2x+dx, c] = (which == 2 dy + dx) ? g[y, x, c] : 0 -- every input element written exactly once
+__global__ __launch_bounds__(kT) void maxpool2x2_bwd_kernel(const float *__restrict__ g, const uint8_t *__restrict__ which, int B,
+                                                            int H, int W, int C, int lg, float *__restrict__ gin) {
+    long long t = (long long)blockIdx.x * kT + threadIdx.x;
+    long long pix = t >> lg;
+    const int h = H / 2, w = W / 2;
+    if (pix >= (long long)B * h * w) return;
+    int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((long long)w * h));
+    float *p00 = gin + (((size_t)b * H + 2 * y) * W + 2 * x) * C;
+    float *p10 = p00 + (size_t)W * C;
+    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
+        const float4 gv = *reinterpret_cast<const float4 *>(g + pix * C + c);
+        const uchar4 a = *reinterpret_cast<const uchar4 *>(which + pix * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o = make_float4(a.x == k ? gv.x : 0.f, a.y == k ? gv.y : 0.f, a.z == k ? gv.z : 0.f, a.w == k ? gv.w : 0.f);
+            *reinterpret_cast<float4 *>((k & 2 ? p10 : p00) + (k & 1) * C + c) = o;
+        }
+    }
+}
+
 static int lg_for(int C) { return group_log2(C, 4); }
 
 }  // namespace t2h
@@ -376,6 +427,27 @@ T2H_API int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *
     if (dbias && hipMemcpyAsync(dbias, tail + a.Ctot, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return check_launch("head1x1_bwd/copy db");
     return T2H_OK;
+}
+
+T2H_API int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream) {
+    if (!in || !out || !which || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || C % 4)
+        return fail(T2H_ERR_ARG, "maxpool2x2_nhwc_fwd: bad argument (even H, W and C %% 4 == 0 required)");
+    int lg = lg_for(C);
+    long long threads = ((long long)B * (H / 2) * (W / 2)) << lg;
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), in, B, H, W,
+                       C, lg, out, which);
+    return check_launch("maxpool2x2_nhwc_fwd");
+}
+
+T2H_API int t2h_maxpool2x2_nhwc_bwd(const float *gout, const uint8_t *which, int B, int H, int W, int C, float *gin,
+                                    t2h_stream_t stream) {
+    if (!gout || !gin || !which || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || C % 4)
+        return fail(T2H_ERR_ARG, "maxpool2x2_nhwc_bwd: bad argument (even H, W and C %% 4 == 0 required)");
+    int lg = lg_for(C);
+    long long threads = ((long long)B * (H / 2) * (W / 2)) << lg;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), gout, which,
+                       B, H, W, C, lg, gin);
+    return check_launch("maxpool2x2_nhwc_bwd");
 }
 
 T2H_API int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W,

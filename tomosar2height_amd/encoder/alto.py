@@ -50,6 +50,9 @@ class _PointGridLevel(nn.Module):
             return grid.conv3x3_chain(x, (self.conv1, self.conv2))
         return F.relu(self.conv2(F.relu(self.conv1(x))))
 
+    def _pool(self, x):
+        return grid.maxpool2x2(x, self.pool) if self.channels_last else self.pool(x)
+
     def _conv1x1(self, conv, x):
         """1x1 convs and 2x2 transposed convs (UpConv.conv1x1 is either, alto.py:172-175)."""
         if not self.channels_last:
@@ -86,10 +89,10 @@ class DownConv(_PointGridLevel):
         g = self._conv_pair(grid_in)
         if prev_conv is not None:
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
-            res_in = self.pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
+            res_in = self._pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
             g = g + self._conv1x1(self.conv1x1, res_in)
         raster, c = self._exchange(tile, g, c_last)
-        pooled = self.pool(raster) if self.pooling else raster
+        pooled = self._pool(raster) if self.pooling else raster
         return pooled, raster, g, c
 
 

@@ -31,7 +31,9 @@ class DownConv(_Level):
 
     def forward(self, x):
         x = self._conv_pair(x)
-        return (self.pool(x) if self.pooling else x), x
+        if not self.pooling:
+            return x, x
+        return (grid.maxpool2x2(x, self.pool) if self.channels_last else self.pool(x)), x
 
 
 class UpConv(_Level):

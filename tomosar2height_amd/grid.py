@@ -444,6 +444,44 @@ def head1x1(xs, conv: torch.nn.Conv2d) -> torch.Tensor:
     return _Head1x1.apply(conv.weight, conv.bias, *xs)
 
 
+# ------------------------------------------------------------------------------------------------ 2x2 max-pool
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _as_cl(x)
+        b, c, h, w = x.shape
+        y = _empty_cl(b, c, h // 2, w // 2, x.device)
+        which = torch.empty(b * (h // 2) * (w // 2) * c, dtype=torch.uint8, device=x.device)
+        _lib.call("t2h_maxpool2x2_nhwc_fwd", _lib.ptr(x), b, h, w, c, _lib.ptr(y), _lib.ptr(which), _lib.stream(),
+                  nbytes=4 * x.numel() + 5 * y.numel(), tag="t2h_maxpool2x2_fwd")
+        ctx.save_for_backward(which)
+        ctx.shape = (b, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (which,) = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        g = _as_cl(g)
+        gin = _empty_cl(b, c, h, w, g.device)
+        _lib.call("t2h_maxpool2x2_nhwc_bwd", _lib.ptr(g), _lib.ptr(which), b, h, w, c, _lib.ptr(gin), _lib.stream(),
+                  nbytes=5 * g.numel() + 4 * gin.numel(), tag="t2h_maxpool2x2_bwd")
+        return gin
+
+
+def maxpool2x2(x: torch.Tensor, pool: torch.nn.MaxPool2d = None) -> torch.Tensor:
+    """``nn.MaxPool2d(kernel_size=2, stride=2)(x)`` on channels_last planes (same winners on ties as ATen)."""
+    ok = (USE_HIP_CONV and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+          and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2)
+    if pool is not None:
+        k, st = pool.kernel_size, pool.stride
+        ok = ok and (k in (2, (2, 2))) and (st in (2, (2, 2))) and pool.padding in (0, (0, 0)) and not pool.ceil_mode \
+            and pool.dilation in (1, (1, 1)) and not pool.return_indices
+    if not ok:
+        return pool(x) if pool is not None else F.max_pool2d(x, 2, 2)
+    return _MaxPool2x2.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ NHWC upsample
 class _UpsampleCL(torch.autograd.Function):
     @staticmethod
