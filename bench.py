@@ -179,8 +179,7 @@ def main():
     torch.manual_seed(0)
     model = TomoSAR2Height(cfg).to(dev)
     model.set_mlp_precision(args.mlp_precision)
-    if args.channels_last:
-        model.set_channels_last(True)
+    model.set_channels_last(bool(args.channels_last))
     if world > 1:
         broadcast_parameters(model, group)
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate)     # train.py:97

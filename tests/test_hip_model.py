@@ -92,8 +92,7 @@ def test_full_model_golden(tag, channels_last):
     model, cfg = _full_model(tag)
     assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
     assert list(model.state_dict()) == g["state_keys"].tolist()
-    if channels_last:
-        model.set_channels_last(True)
+    model.set_channels_last(channels_last)
     cloud = torch.from_numpy(g["cloud"]).to(_dev())
     image = None
     if tag == "munich":

@@ -27,6 +27,7 @@ class TomoSAR2Height(nn.Module):
         z_bound = cfg["dataset"]["normalize"]["z_bound"]
         self.z_scale = z_bound[1] - z_bound[0]
         self._initialize_weights()
+        self.set_channels_last(True)      # default: grid side in NHWC on the implicit-GEMM convolution kernels
 
     def _initialize_weights(self):
         """model.py:46-52: Xavier-uniform weights / zero biases on every Conv2d and Linear (ConvTranspose2d is
@@ -38,8 +39,9 @@ class TomoSAR2Height(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def set_channels_last(self, flag: bool = True):
-        """Run the grid side (planes + convs) in channels_last memory: the point<->grid HIP kernels read and
-        write pixel-major rows natively, so no layout copies remain.  Numerics are unchanged."""
+        """Run the grid side (planes + convs) in channels_last memory (the default): the point<->grid HIP kernels read
+        and write pixel-major rows natively, so no layout copies remain, and the convolutions run on csrc/conv.hip.
+        ``set_channels_last(False)`` restores the NCHW / MIOpen grid side; results agree to rounding."""
         if self.use_cloud and hasattr(self.point_encoder, "set_channels_last"):
             self.point_encoder.set_channels_last(flag)
         if self.use_image and hasattr(self.image_encoder, "set_channels_last"):
