@@ -301,3 +301,44 @@ def test_conv3x3_argument_errors():
     assert grid.conv_bias_act(x8, conv).shape == (1, 32, 16, 16)
     assert _lib.load().t2h_conv3x3_fwd_workspace_bytes(1, 32, 32, 512, 512) > 0
     assert _lib.load().t2h_conv3x3_fwd_workspace_bytes(1, 512, 512, 32, 64) == 0
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 128, 512), (128, 64, 512), (32, 64, 512), (512, 512, 32), (512, 256, 64)])
+def test_conv3x3_at_bench_sizes(cin, cout, hw):
+    """The layer shapes of the Berlin step at full size (decoder at 512 x 512, ALTO bottom levels): forward, data and
+    weight gradient against torch's convolution on the same device (fp32, another summation order: 2e-5 of the max-norm;
+    the weight gradient sums 2^18 pixels: 1e-4), plus linearity of the forward in its input."""
+    from tomosar2height_amd import grid
+    g = torch.Generator(device=_dev()).manual_seed(cin + cout + hw)
+
+    def rnd(*shape):
+        return torch.randn(*shape, device=_dev(), generator=g)
+
+    x = rnd(1, cin, hw, hw).contiguous(memory_format=torch.channels_last)
+    gy = rnd(1, cout, hw, hw).contiguous(memory_format=torch.channels_last)
+    w = (rnd(cout, cin, 3, 3) / (9 * cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    bias = rnd(cout)
+    y = grid._empty_cl(1, cout, hw, hw, _dev())
+    grid.conv3x3_fwd_(x, w, bias, y)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(gy)
+
+    def close(a, b, tol):
+        assert (a - b).abs().max().item() <= tol * b.abs().max().item()
+
+    close(y, yr.detach(), 2e-5)
+    dx = grid._empty_cl(1, cin, hw, hw, _dev())
+    grid.conv3x3_dgrad_(gy, w, dx)
+    close(dx, xr.grad, 2e-5)
+    dw, db = torch.empty_like(w), torch.empty(cout, device=_dev())
+    grid.conv3x3_wgrad_(gy, x, dw, db)
+    close(dw, wr.grad, 1e-4)
+    close(db, br.grad, 1e-4)
+    # linearity: conv(2 x + x') - bias = 2 (conv(x) - bias) + (conv(x') - bias)
+    x2 = rnd(1, cin, hw, hw).contiguous(memory_format=torch.channels_last)
+    y2, y3 = torch.empty_like(y), torch.empty_like(y)
+    grid.conv3x3_fwd_(x2, w, None, y2)
+    grid.conv3x3_fwd_((2 * x + x2).contiguous(memory_format=torch.channels_last), w, None, y3)
+    close(y3, 2 * (y - bias.view(1, -1, 1, 1)) + y2, 2e-5)
