@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
+    ap.add_argument("--uniform-xy", action="store_true", help="no-skew control: all points uniform in the tile (SURVEY 8d)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (gloo smoke test only)")
     return ap.parse_args()
 
@@ -188,7 +189,7 @@ def main():
 
     tiles = []
     for i in range(args.tile_pool):
-        t = berlin_tile(seed=1000 * rank + i, n_points=args.points)
+        t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy)
         tiles.append({"inputs": t["inputs"].to(dev), "dsm": t["dsm"].to(dev)})
 
     def run(n_steps, offset=0, timeline=None, every=8):
@@ -238,6 +239,7 @@ def main():
                                    f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
                        "parallelism": f"dp{world}", "channels_last": bool(args.channels_last),
+                       "point_distribution": "uniform (no-skew control)" if args.uniform_xy else "70 % in 160 buildings + 30 % uniform",
                        "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",
                        "miopen_find": bool(args.miopen_find), "hip_graph": bool(args.hip_graph)},
         }
