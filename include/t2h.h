@@ -166,7 +166,7 @@ int t2h_upsample_bilinear_bwd(const float *gout, int B, int C, int h, int w, int
 /* ---------------------------------------------------------------------------------------------
  * Grid-side fusions around the (MIOpen) convolutions -- SURVEY 8f-1, first step.  NHWC tensors ([B,H,W,C],
  * channels_last), P = B*H*W pixels, C % 4 == 0.
- *   t2h_bias_relu_fwd   y = act(y + bias[c]) in place           conv bias + F.relu (alto.py:98-99,229-230; pixel.py:27-30)
+ *   t2h_bias_relu_fwd   y = act(y + bias[c]) in place           conv bias + F.relu (alto.py:98-99,226-227; pixel.py:27-30)
  *   t2h_bias_relu_bwd   g_masked = g * (y > 0) (if relu; else untouched, may be NULL); dbias = [dbias +] sum_p g_masked
  *   t2h_head1x1_fwd/bwd out[p] = bias + sum_i <w_i, x_i[p,:]> over up to 4 inputs: torch.cat([x,x1,x2,x3]) + the 1x1
  *                       conv4 of ConvDecoder (pixel.py:31) without materialising the 288-channel concat; backward gives
@@ -186,7 +186,7 @@ int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *C, int n
                     t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W,
                                    float *out, t2h_stream_t stream);
-/* nn.MaxPool2d(kernel_size=2, stride=2) on NHWC planes (DownConv.pool, alto.py:104-114,132-135): in [B,H,W,C] (H, W even),
+/* nn.MaxPool2d(kernel_size=2, stride=2) on NHWC planes (DownConv.pool, alto.py:61,110,136): in [B,H,W,C] (H, W even),
  * out [B,H/2,W/2,C]; which [B,H/2,W/2,C] bytes = 2*dy+dx of the first maximum in scan order (ATen's tie-break); the
  * backward writes every element of gin [B,H,W,C] exactly once. */
 int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream);
@@ -198,7 +198,7 @@ int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w
 /* ---------------------------------------------------------------------------------------------
  * 3x3 grid convolutions as implicit GEMMs on the matrix cores (exact fp32) -- SURVEY 8f-1, second step.
  * Replaces nn.Conv2d(kernel_size=3, stride=1, padding=1) forward and its autograd: conv3x3 of alto.py:59-61 used at
- * alto.py:98-99,229-230 (with F.relu) and ConvDecoder.conv1..3 of pixel.py:20-30.
+ * alto.py:98-99,226-227 (with F.relu) and ConvDecoder.conv1..3 of pixel.py:20-30.
  *   x  [B,H,W,Cin]  NHWC (torch channels_last), y / dy [B,H,W,Cout]; H, W powers of two
  *   w  [Cout][3][3][Cin] = the channels_last memory of torch's [Cout,Cin,3,3] weight; dw has the same layout
  *   fwd    y  = act(conv(x, w) + bias)             flags: T2H_RELU_OUT, T2H_ACCUM;   Cin % 16 == 0, Cout % 4 == 0

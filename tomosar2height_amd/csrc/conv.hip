@@ -1,6 +1,6 @@
 // 3x3 grid convolutions (stride 1, zero padding 1) of the ALTO U-Net and the pixel decoder as implicit GEMMs in exact
 // fp32 on the matrix cores -- the planes the point<->grid kernels exchange with the grid side
-// (reference: conv3x3 of alto.py:59-61,157-182 with F.relu at alto.py:98-99,229-230; ConvDecoder pixel.py:20-32).
+// (reference: conv3x3 of alto.py:59-61,157-182 with F.relu at alto.py:98-99,226-227; ConvDecoder pixel.py:20-32).
 //
 // Layout: activations NHWC [B,H,W,C] (torch channels_last), weights [Cout][3][3][Cin] (= the channels_last memory of
 // torch's [Cout,Cin,3,3] parameter), so every reduction slab of 16 input channels is one contiguous 64-byte run per

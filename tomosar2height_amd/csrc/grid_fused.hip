@@ -1,7 +1,7 @@
 // Grid-side fusions around the (MIOpen) convolutions of the ALTO U-Net and the pixel decoder -- SURVEY 8f-1, first
 // step: remove the elementwise passes between the convs.  All tensors are pixel-major NHWC ([B,H,W,C], channels_last).
 //
-//   bias_relu_fwd      y = relu(y + bias[c])  in place            conv bias + F.relu   (alto.py:98-99,229-230; pixel.py:27-30)
+//   bias_relu_fwd      y = relu(y + bias[c])  in place            conv bias + F.relu   (alto.py:98-99,226-227; pixel.py:27-30)
 //   bias_relu_bwd      gm = g * (y > 0); db[c] = sum_p gm           relu backward + conv bias gradient in one pass
 //   head1x1_*          out[p] = b + sum_i <w_i, x_i[p,:]>          torch.cat([x,x1,x2,x3]) + conv4 1x1 (pixel.py:31):
 //                                                                  the 288-channel concat never materialises
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kT) void upsample_nhwc_bwd_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------------------------- 2x2 max-pool (NHWC)
-// nn.MaxPool2d(kernel_size=2, stride=2) of the ALTO down path (alto.py:104-114,132-135): first maximum in window scan
+// nn.MaxPool2d(kernel_size=2, stride=2) of the ALTO down path (alto.py:61,110,136): first maximum in window scan
 // order (0,0),(0,1),(1,0),(1,1) wins, like ATen's strict '>' -- the planes are full of exact ties (empty cells = 0).
 // which[pixel][c] = 2 * dy + dx of the winner, one byte per output element, consumed by the backward.
 __global__ __launch_bounds__(kT) void maxpool2x2_fwd_kernel(const float *__restrict__ in, int B, int H, int W, int C, int lg,

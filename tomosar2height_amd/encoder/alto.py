@@ -44,7 +44,7 @@ class _PointGridLevel(nn.Module):
     channels_last = False
 
     def _conv_pair(self, x):
-        """``F.relu(conv2(F.relu(conv1(x))))`` (alto.py:98-99, 229-230); in channels_last mode on the implicit-GEMM
+        """``F.relu(conv2(F.relu(conv1(x))))`` (alto.py:98-99, 226-227); in channels_last mode on the implicit-GEMM
         kernels with fused bias / ReLU / ReLU-backward (grid.py, csrc/conv.hip)."""
         if self.channels_last:
             return grid.conv3x3_chain(x, (self.conv1, self.conv2))

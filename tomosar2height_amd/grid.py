@@ -193,7 +193,7 @@ def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True, mas
 
 def conv3x3_chain(x: torch.Tensor, convs, relu_last: bool = True) -> torch.Tensor:
     """``relu(conv_n(... relu(conv_1(x))))`` where every intermediate activation feeds the next conv only (the
-    conv1 -> conv2 pairs of alto.py:98-99,229-230): each data gradient applies the previous ReLU's mask in its
+    conv1 -> conv2 pairs of alto.py:98-99,226-227): each data gradient applies the previous ReLU's mask in its
     epilogue, so only the last ReLU needs a backward pass of its own."""
     convs = list(convs)
     fused = all(conv3x3_supported(x, c) for c in convs)
