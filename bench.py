@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--channels-last", type=int, default=1, help="grid side in NHWC (same numerics, no layout copies)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-every", type=int, default=8, help="record per-kernel HIP events on every n-th timed step")
+    ap.add_argument("--timing-every", type=int, default=16, help="record per-kernel HIP events on every n-th timed step")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
