@@ -90,7 +90,10 @@ def test_two_rank_step_equals_single_process(tmp_path):
     worst = 0.0
     for k, v in want.items():
         worst = max(worst, (got["params"][k] - v).abs().max().item())
-        np.testing.assert_allclose(got["params"][k].numpy(), v.numpy(), rtol=1e-5, atol=2e-6, err_msg=k)
+        # AdamW (lr 1e-3) turns the fp32 rounding of a near-zero gradient sum (rank-wise vs sequential order, host-dependent
+        # thread counts) into update differences of a few 1e-6; a lost or doubled rank contribution would move whole tensors
+        # by ~1e-3
+        np.testing.assert_allclose(got["params"][k].numpy(), v.numpy(), rtol=1e-5, atol=2e-5, err_msg=k)
     # the 8 never-used tensors of up_convs[depth-2] (alto.py:241-242) are outside the bucket on every rank
     assert len(got["none_grad"]) == 8 and all("up_convs.1." in k for k in got["none_grad"])
     n_live = sum(v.numel() for k, v in want.items() if k not in got["none_grad"])
