@@ -147,6 +147,10 @@ int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, i
                          (error <= ~2^-23 relative per product, fp32 accumulate); opt-in, never the default */
 int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
                    int N, int flags, t2h_stream_t stream);
+/* t2h_linear_fwd + addend [M, ldadd] added to the finished result (fp32 kernels only; NULL = t2h_linear_fwd): the 1x1-conv
+ * residuals `x + conv1x1(prev)` of alto.py:110,114,236 without a separate elementwise add */
+int t2h_linear_fwd_add(const float *x, int ldx, const float *w, const float *bias, const float *addend, int ldadd, float *y,
+                       int ldy, int M, int K, int N, int flags, t2h_stream_t stream);
 int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,
                      const float *mask, int ldmask, int flags, t2h_stream_t stream);
 size_t t2h_linear_wgrad_workspace_bytes(int M, int K, int N);
@@ -224,6 +228,9 @@ int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int
  * weight (dw likewise); Cin, Cout multiples of 16.  The bias gradient is sum_p dy[p] = t2h_bias_relu_bwd with relu = 0. */
 int t2h_upconv2x2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
                       int flags, t2h_stream_t stream);
+/* ... + addend [B,2H,2W,Cout] (may be NULL): the residual `x + upconv(prev)` of alto.py:236 without a separate add */
+int t2h_upconv2x2_fwd_add(const float *x, const float *w, const float *bias, const float *addend, float *y, int B, int H,
+                          int W, int Cin, int Cout, int flags, t2h_stream_t stream);
 size_t t2h_upconv2x2_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_upconv2x2_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
                         void *workspace, size_t workspace_bytes, t2h_stream_t stream);

@@ -109,6 +109,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_sample_bwd": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n),
         "t2h_sample_bwd_atomic": (n, n, 3, 1, 10, 32, 32, n, n),
         "t2h_linear_fwd": (n, 32, n, n, n, 32, 10, 32, 32, 0, n),
+        "t2h_linear_fwd_add": (n, 32, n, n, n, 32, n, 32, 10, 32, 32, 0, n),
         "t2h_linear_dgrad": (n, 32, n, n, 32, 10, 32, 32, n, 0, 0, n),
         "t2h_linear_wgrad": (n, 32, n, 32, 10, 32, 32, 0, n, n, n, 0, n),
         "t2h_upsample_bilinear_fwd": (n, n, 1, 32, 16, 16, 32, 32, n, n),
@@ -124,6 +125,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_conv3x3_dgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_conv3x3_wgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_upconv2x2_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
+        "t2h_upconv2x2_fwd_add": (n, n, n, n, n, 1, 32, 32, 32, 32, 0, n),
         "t2h_upconv2x2_dgrad": (n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_upconv2x2_wgrad": (n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_maxpool2x2_nhwc_fwd": (n, 1, 64, 64, 32, n, n, n),

@@ -342,3 +342,34 @@ def test_conv3x3_at_bench_sizes(cin, cout, hw):
     grid.conv3x3_fwd_(x2, w, None, y2)
     grid.conv3x3_fwd_((2 * x + x2).contiguous(memory_format=torch.channels_last), w, None, y3)
     close(y3, 2 * (y - bias.view(1, -1, 1, 1)) + y2, 2e-5)
+
+
+@pytest.mark.parametrize("kind,cin,cout,hw", [("conv1x1", 64, 128, 32), ("conv1x1", 32, 64, 16), ("conv1x1", 64, 32, 16),
+                                              ("upconv", 128, 64, 16), ("upconv", 512, 256, 8)])
+def test_residual_addend_rides_the_epilogue(kind, cin, cout, hw):
+    """``addend + conv(x)`` (the residual connections of alto.py:110,114,236) fused into the 1x1-conv / transposed-conv
+    epilogue: forward and all gradients (including the pass-through gradient of the addend) against torch in float64; the
+    addend tensor itself is left untouched."""
+    import copy
+    from tomosar2height_amd import grid
+    torch.manual_seed(cin + cout + hw)
+    conv = torch.nn.Conv2d(cin, cout, 1) if kind == "conv1x1" else torch.nn.ConvTranspose2d(cin, cout, 2, stride=2)
+    ref = copy.deepcopy(conv).double()
+    out_hw = hw if kind == "conv1x1" else 2 * hw
+    x, res = torch.randn(2, cin, hw, hw), torch.randn(2, cout, out_hw, out_hw)
+    gout = torch.randn(2, cout, out_hw, out_hw)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    yr = rr + ref(xr)
+    yr.backward(gout.double())
+    conv = conv.to(_dev()).to(memory_format=torch.channels_last)
+    xg, rg = _cl(x).requires_grad_(True), _cl(res).requires_grad_(True)
+    keep = rg.detach().clone()
+    y = grid.conv1x1(xg, conv, rg) if kind == "conv1x1" else grid.upconv2x2(xg, conv, rg)
+    assert "Backward" in type(y.grad_fn).__name__ and "Add" not in type(y.grad_fn).__name__
+    y.backward(_cl(gout))
+    assert torch.equal(rg.detach(), keep)
+    _close(y, yr.detach())
+    _close(xg.grad, xr.grad)
+    _close(rg.grad, rr.grad)
+    _close(conv.weight.grad, ref.weight.grad)
+    _close(conv.bias.grad, ref.bias.grad)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_linear_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "t2h_linear_fwd_add": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_linear_dgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "t2h_linear_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "t2h_linear_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "t2h_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "t2h_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2h_upconv2x2_fwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_dgrad_workspace_bytes": (_sz, [_i] * 5),
     "t2h_upconv2x2_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_wgrad_workspace_bytes": (_sz, [_i] * 5),

@@ -37,6 +37,7 @@ struct ConvArgs {
     const float *mat;        // dense operand: weights [Cout][9][Cin] (fwd/dgrad) or dY rows [P, Cout] (wgrad)
     float *C;                // output rows or slab base
     const float *bias, *mask;
+    const float *addend;     // transposed-conv forward: tensor of the output's shape added to the result, or null
     float *colsum;           // wgrad: per-split column sums of dY, [splits][Cout] or null
     int H, W, logW, Ca;
     int M, N, K;             // GEMM extents (rows, columns, reduction)
@@ -87,6 +88,10 @@ __device__ inline void store_tiles_up2x2(f32x16 (&acc)[TM][TN], float *patch, in
                     const long long opix = (long long)(row >> logW) * 4 * W + 2 * (row & (W - 1)) + tap_off;
                     float4 *dst = reinterpret_cast<float4 *>(e.C + opix * Cout + co);
                     if (e.accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (e.addend) {
+                        float4 o = *reinterpret_cast<const float4 *>(e.addend + opix * Cout + co);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
                     *dst = v;
                 }
             }
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(NT, MINW) void conv_rows_kernel(ConvArgs p) {
     e.C = p.C + (size_t)split * p.slab_stride;
     e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
     e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
+    e.addend = GEOM == G_UP_FWD ? p.addend : nullptr;
     if (GEOM == G_UP_FWD)
         store_tiles_up2x2<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e, p.logW, p.W,
                                   p.N / 4);
@@ -419,13 +425,14 @@ RowsPlan rows_plan_for(long long M, int Cin, int Cout) {
 // shared body of the row-streaming entry points
 template <int GEOM>
 int conv_rows(const float *act, const float *w, const float *bias, const float *mask, float *out, int B, int H, int W,
-              int Cin, int Cout, int flags, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
+              int Cin, int Cout, int flags, void *ws, size_t ws_bytes, hipStream_t s, const char *what,
+              const float *addend = nullptr) {
     const RowsShape sh = rows_shape<GEOM>(Cin, Cout);
     const int Ca = sh.Ca, N = sh.N;
     const long long M = (long long)B * H * W;
     RowsPlan r = rows_plan_for<GEOM>(M, Cin, Cout);
     ConvArgs a{};
-    a.act = act; a.mat = w; a.H = H; a.W = W; a.logW = ilog2_exact(W); a.Ca = Ca;
+    a.act = act; a.mat = w; a.H = H; a.W = W; a.logW = ilog2_exact(W); a.Ca = Ca; a.addend = addend;
     a.M = (int)M; a.N = N; a.K = sh.K; a.ldmat = sh.ldmat; a.k_chunk = r.k_chunk;
     EpilogueArgs e{};
     e.C = out; e.bias = bias; e.mask = mask; e.M = (int)M; e.N = N; e.ldc = N; e.ldm = N;
@@ -559,13 +566,19 @@ static int check_up(const char *what, int B, int H, int W, int Cin, int Cout) {
     return T2H_OK;
 }
 
-T2H_API int t2h_upconv2x2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
-                              int Cout, int flags, t2h_stream_t stream) {
+T2H_API int t2h_upconv2x2_fwd_add(const float *x, const float *w, const float *bias, const float *addend, float *y, int B,
+                                  int H, int W, int Cin, int Cout, int flags, t2h_stream_t stream) {
     if (!x || !w || !y) return fail(T2H_ERR_ARG, "upconv2x2_fwd: null pointer");
     if (int rc = check_up("upconv2x2_fwd", B, H, W, Cin, Cout)) return rc;
-    if (!al16(x) || !al16(w) || !al16(y) || (bias && !al16(bias))) return fail(T2H_ERR_ARG, "upconv2x2_fwd: pointers must be 16-byte aligned");
+    if (!al16(x) || !al16(w) || !al16(y) || (bias && !al16(bias)) || (addend && !al16(addend)))
+        return fail(T2H_ERR_ARG, "upconv2x2_fwd: pointers must be 16-byte aligned");
     return conv_rows<G_UP_FWD>(x, w, bias, nullptr, y, B, H, W, Cin, Cout, flags & T2H_ACCUM, nullptr, 0, as_stream(stream),
-                               "upconv2x2_fwd");
+                               "upconv2x2_fwd", addend);
+}
+
+T2H_API int t2h_upconv2x2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                              int Cout, int flags, t2h_stream_t stream) {
+    return t2h_upconv2x2_fwd_add(x, w, bias, nullptr, y, B, H, W, Cin, Cout, flags, stream);
 }
 
 T2H_API size_t t2h_upconv2x2_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

@@ -223,6 +223,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
                     if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     float4 *dst = reinterpret_cast<float4 *>(C + (size_t)row * p.ldc + col);
                     if (accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (p.addend) {
+                        float4 o = *reinterpret_cast<const float4 *>(p.addend + (size_t)row * p.ldadd + col);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
                     *dst = v;
                 }
             }
@@ -438,14 +442,16 @@ static int map_flags(int f) {
     return o;
 }
 
-T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
-                           int N, int flags, t2h_stream_t stream) {
+T2H_API int t2h_linear_fwd_add(const float *x, int ldx, const float *w, const float *bias, const float *addend, int ldadd,
+                               float *y, int ldy, int M, int K, int N, int flags, t2h_stream_t stream) {
     if (!x || !w || !y) return fail(T2H_ERR_ARG, "linear_fwd: null pointer");
     if (M < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return fail(T2H_ERR_ARG, "linear_fwd: bad shape");
     if (M == 0) return T2H_OK;
     hipStream_t s = as_stream(stream);
     const bool vec_ok = K % 4 == 0 && N % 4 == 0 && aligned4(x, ldx) && aligned4(w, K) && aligned4(y, ldy) &&
                         (!bias || (uintptr_t)bias % 16 == 0);
+    if (addend && (!vec_ok || !aligned4(addend, ldadd) || ldadd < N || mode_of(flags) != 0))
+        return fail(T2H_ERR_ARG, "linear_fwd_add: the addend needs 16-byte rows (multiples of 4) and the fp32 kernels");
     if (!vec_ok) {   // fc_pos (K = 3) and 1-channel heads: plain VALU kernel
         if (K > 64) return fail(T2H_ERR_ARG, "linear_fwd: K=%d, N=%d need 16-byte rows (multiples of 4) beyond K=64", K, N);
         long long total = (long long)M * N;
@@ -454,9 +460,14 @@ T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float 
         return check_launch("linear_fwd(small K)");
     }
     GemmArgs a{};
-    a.A = x; a.lda = ldx; a.B = w; a.ldb = K; a.C = y; a.ldc = ldy; a.bias = bias;
+    a.A = x; a.lda = ldx; a.B = w; a.ldb = K; a.C = y; a.ldc = ldy; a.bias = bias; a.addend = addend; a.ldadd = ldadd;
     a.M = M; a.N = N; a.K = K; a.flags = map_flags(flags); a.k_chunk = K; a.slab_stride = 0;
     return launch_rows<true>(a, mode_of(flags), s, "linear_fwd");
+}
+
+T2H_API int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
+                           int N, int flags, t2h_stream_t stream) {
+    return t2h_linear_fwd_add(x, ldx, w, bias, nullptr, 0, y, ldy, M, K, N, flags, stream);
 }
 
 T2H_API int t2h_linear_dgrad(const float *dy, int lddy, const float *w, float *dx, int lddx, int M, int K, int N,

@@ -11,6 +11,8 @@ struct GemmArgs {
     float *C;
     const float *bias;     // [N] or null
     const float *mask;     // [M, ldm] or null: result *= (mask > 0)
+    const float *addend;   // [M, ldadd] or null: added to the finished result (after ReLU / mask), fp32 kernels only
+    int ldadd;
     float *colsum;         // TN only: per-split column sums of A (i.e. sum over k of A(m,k)), [splits][M] or null
     int M, N, K;
     int lda, ldb, ldc, ldm;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_kernel(GemmArgs p) {
 
     EpilogueArgs e;
     e.C = p.C; e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
-    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
+    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT; e.addend = p.addend; e.ldadd = p.ldadd;
     store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
 }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_nn_kernel(GemmArgs p) {
     }
     EpilogueArgs e;
     e.C = p.C; e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
-    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT;
+    e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT; e.addend = p.addend; e.ldadd = p.ldadd;
     store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
 }
 

@@ -93,6 +93,8 @@ struct EpilogueArgs {
     const float *bias, *mask;
     int M, N, ldc, ldm;
     bool accum, relu_out;
+    const float *addend = nullptr;     // [M, ldadd] or null: added last (residual connections)
+    int ldadd = 0;
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
@@ -128,6 +130,10 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
                     if (e.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     float4 *dst = reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col);
                     if (e.accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (e.addend) {
+                        float4 o = *reinterpret_cast<const float4 *>(e.addend + (size_t)row * e.ldadd + col);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
                     *dst = v;
                 }
             }

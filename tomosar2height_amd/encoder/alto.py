@@ -53,11 +53,14 @@ class _PointGridLevel(nn.Module):
     def _pool(self, x):
         return grid.maxpool2x2(x, self.pool) if self.channels_last else self.pool(x)
 
-    def _conv1x1(self, conv, x):
-        """1x1 convs and 2x2 transposed convs (UpConv.conv1x1 is either, alto.py:172-175)."""
+    def _conv1x1(self, conv, x, addend=None):
+        """``[addend +] conv(x)`` for 1x1 convs and 2x2 transposed convs (UpConv.conv1x1 is either, alto.py:172-175); in
+        channels_last mode the residual add rides the kernel's epilogue."""
         if not self.channels_last:
-            return conv(x)
-        return grid.upconv2x2(x, conv) if isinstance(conv, nn.ConvTranspose2d) else grid.conv1x1(x, conv)
+            return conv(x) if addend is None else addend + conv(x)
+        if isinstance(conv, nn.ConvTranspose2d):
+            return grid.upconv2x2(x, conv, addend)
+        return grid.conv1x1(x, conv, addend)
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
         sampled = ops.sample_plane(tile, plane)                                   # alto.py:121-122 / 245-246
@@ -90,7 +93,7 @@ class DownConv(_PointGridLevel):
         if prev_conv is not None:
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
             res_in = self._pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
-            g = g + self._conv1x1(self.conv1x1, res_in)
+            g = self._conv1x1(self.conv1x1, res_in, addend=g)
         raster, c = self._exchange(tile, g, c_last)
         pooled = self._pool(raster) if self.pooling else raster
         return pooled, raster, g, c
@@ -121,7 +124,7 @@ class UpConv(_PointGridLevel):
         g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
         g = self._conv_pair(g)
         if prev_conv is not None:
-            g = g + self._conv1x1(self.conv1x1, prev_conv)                          # alto.py:233-236
+            g = self._conv1x1(self.conv1x1, prev_conv, addend=g)                    # alto.py:233-236
         if self.is_last:                                                            # alto.py:241-242
             return g, g, c_last
         raster, c = self._exchange(tile, g, c_last)

@@ -210,15 +210,21 @@ class _Conv1x1(torch.autograd.Function):
     """1x1 convolution = the per-point GEMM kernels (always exact fp32 here) on the [pixels, C] rows of the NHWC plane."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, addend):
         x = _as_cl(x)
         b, cin, h, wd = x.shape
         cout, m = weight.shape[0], b * h * wd
         w2 = weight.reshape(cout, cin).contiguous()
         y = _empty_cl(b, cout, h, wd, x.device)
-        _lib.call("t2h_linear_fwd", _lib.ptr(x), cin, _lib.ptr(w2), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
-                  cout, m, cin, cout, 0, _lib.stream(), nbytes=4 * (m * cin + m * cout + cin * cout),
+        if addend is not None:
+            addend = _as_cl(addend)
+            if addend.shape != y.shape:
+                raise ValueError("conv1x1: addend must have the output's shape")
+        _lib.call("t2h_linear_fwd_add", _lib.ptr(x), cin, _lib.ptr(w2), _lib.ptr(bias) if bias is not None else None,
+                  _lib.ptr(addend) if addend is not None else None, cout, _lib.ptr(y), cout, m, cin, cout, 0, _lib.stream(),
+                  nbytes=4 * (m * cin + m * cout * (2 if addend is not None else 1) + cin * cout),
                   flops=2 * m * cin * cout, tag=f"t2h_linear_fwd[K={cin},N={cout}]")
+        ctx.has_addend = addend is not None
         ctx.save_for_backward(x, weight, bias)
         return y
 
@@ -247,17 +253,19 @@ class _Conv1x1(torch.autograd.Function):
                   _lib.ptr(dw), _lib.ptr(db) if db is not None else None, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
                   tag=f"t2h_linear_wgrad[N={cout},K={cin}]")
-        return (dx, None, None) if direct else (dx, dw, db)
+        ga = g if ctx.has_addend else None
+        return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
 
-def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d) -> torch.Tensor:
-    """1x1 convolution (alto.py conv1x1 residuals, upconv_noup, conv_final) on the per-point GEMM kernels."""
+def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, addend: torch.Tensor = None) -> torch.Tensor:
+    """``conv(x)`` or ``addend + conv(x)`` for a 1x1 convolution (alto.py conv1x1 residuals, upconv_noup, conv_final) on the
+    per-point GEMM kernels; the addend rides the GEMM epilogue."""
     ok = (USE_HIP_CONV and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
           and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and x.is_cuda
           and x.dtype == torch.float32)
     if not ok:
-        return conv(x)
-    return _Conv1x1.apply(x, conv.weight, conv.bias)
+        return conv(x) if addend is None else addend + conv(x)
+    return _Conv1x1.apply(x, conv.weight, conv.bias, addend)
 
 
 # ------------------------------------------------------------------------------------------------ upconv2x2 (HIP)
@@ -272,14 +280,21 @@ class _UpConv2x2(torch.autograd.Function):
     """nn.ConvTranspose2d(kernel_size=2, stride=2) (upconv2x2, alto.py:175,215-218,236) on csrc/conv.hip."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, addend):
         x = _as_cl(x)
         w = _w_cl(weight)                                   # [Cin][2][2][Cout] in memory
         b, cin, h, wd = x.shape
         cout = weight.shape[1]
         y = _empty_cl(b, cout, 2 * h, 2 * wd, x.device)
-        _lib.call("t2h_upconv2x2_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
-                  b, h, wd, cin, cout, 0, _lib.stream(), nbytes=4 * (x.numel() + y.numel() + w.numel()),
+        if addend is not None:
+            addend = _as_cl(addend)
+            if addend.shape != y.shape:
+                raise ValueError("upconv2x2: addend must have the output's shape")
+        ctx.has_addend = addend is not None
+        _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None,
+                  _lib.ptr(addend) if addend is not None else None, _lib.ptr(y),
+                  b, h, wd, cin, cout, 0, _lib.stream(),
+                  nbytes=4 * (x.numel() + y.numel() * (2 if addend is not None else 1) + w.numel()),
                   flops=2 * 4 * cin * cout * b * h * wd, tag=f"t2h_upconv2x2_fwd[{cin}->{cout},{h}x{wd}]")
         ctx.save_for_backward(x, weight, bias)
         return y
@@ -318,14 +333,15 @@ class _UpConv2x2(torch.autograd.Function):
             ws = _lib.workspace(nws, g.device)
             _lib.call("t2h_bias_relu_bwd", _lib.ptr(g), None, None, pix, cout, 0, 1 if direct else 0, _lib.ptr(db),
                       _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * g.numel())
-        return (dx, None, None) if direct else (dx, dw, db)
+        ga = g if ctx.has_addend else None
+        return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
 
-def upconv2x2(x: torch.Tensor, conv) -> torch.Tensor:
-    """``conv(x)`` for the 2x2 stride-2 transposed convolutions of the ALTO up path."""
+def upconv2x2(x: torch.Tensor, conv, addend: torch.Tensor = None) -> torch.Tensor:
+    """``conv(x)`` or ``addend + conv(x)`` for the 2x2 stride-2 transposed convolutions of the ALTO up path."""
     if not upconv2x2_supported(x, conv):
-        return conv(x)
-    return _UpConv2x2.apply(x, conv.weight, conv.bias)
+        return conv(x) if addend is None else addend + conv(x)
+    return _UpConv2x2.apply(x, conv.weight, conv.bias, addend)
 
 
 # ------------------------------------------------------------------------------------------------ concat-free 1x1 head
