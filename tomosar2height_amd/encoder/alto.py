@@ -1,7 +1,8 @@
 """ALTO U-Net (reference: tomosar2height/encoder/alto.py) on the MI355X path.
 
-Every level alternates topology: grid convs (MIOpen through PyTorch-ROCm, out of hand-written scope:
-SURVEY.md 8a-9) -> bilinear sample to the points -> per-point MLP -> mean-rasterise back to the grid.
+Every level alternates topology: grid convs (implicit-GEMM HIP kernels of csrc/conv.hip in channels_last mode, the
+default; MIOpen through PyTorch-ROCm otherwise) -> bilinear sample to the points -> per-point MLP -> mean-rasterise back
+to the grid.
 The three point<->grid steps run as HIP kernels on the tile's cell-sorted order
 (``ops.sample_plane`` / ``mlp.comm_mlp`` / ``ops.rasterise_mean``); the reference recomputes cell indices
 and clones the coordinates at every level (alto.py:79-80, 92-94, 189-190), here the ``TileIndex`` built

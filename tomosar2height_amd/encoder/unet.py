@@ -1,6 +1,6 @@
 """Plain convolutional U-Net (reference: tomosar2height/encoder/unet.py:112-187), the image encoder of
 ``use_image=true`` configs, kept with the reference's parameter names so cloud+image checkpoints load.  Pure dense
-convolution: plain torch / MIOpen by default; in channels_last mode its 3x3, 2x2-transposed
+convolution: in channels_last mode (the model's default) its 3x3, 2x2-transposed
 and 1x1 convolutions with 16-aligned channel counts run on the same implicit-GEMM kernels as the ALTO grid side
 (grid.py, csrc/conv.hip) -- every layer except the first (3 input channels)."""
 import torch

@@ -1,5 +1,5 @@
-"""Grid-side fused operators (first step): the elementwise passes around the MIOpen convolutions of the
-ALTO U-Net and the pixel decoder as HIP kernels on channels_last (NHWC) tensors.
+"""Grid side of the hot path on channels_last (NHWC) tensors: the convolutions of the ALTO U-Net, the image
+U-Net and the pixel decoder on the implicit-GEMM HIP kernels, and the elementwise work around them fused away.
 
     conv_bias_act(x, conv, relu)   3x3 stride-1 convs: implicit-GEMM MFMA kernels of csrc/conv.hip (forward with fused
                                    bias/ReLU, data gradient, deterministic weight + bias gradient); any other conv:

@@ -110,8 +110,8 @@ class direct_grad_accumulation:
 
     def __init__(self, enabled: bool = True, side_stream=None):
         """``side_stream``: issue the accumulating weight-gradient GEMMs there.  They are off the backward's critical
-        path (nothing reads the bucket before the optimizer step), so they fill the GPU while MIOpen's small-grid conv
-        kernels run on the main stream.  The caller joins the stream before touching the gradients."""
+        path (nothing reads the bucket before the optimizer step), so they fill the GPU while small-grid conv kernels
+        run on the main stream.  The caller joins the stream before touching the gradients."""
         self.enabled = enabled
         self.side_stream = side_stream if enabled else None
 

@@ -113,9 +113,10 @@ class Trainer:
     def capture_graph(self, example):
         """Capture forward + loss + backward of one tile into a hipGraph (``torch.cuda.CUDAGraph``) for tiles of
         ``example``'s shapes.  Later ``train_step`` calls with the same shapes copy the tile into static buffers and
-        replay the ~800 launches with one host call; other shapes (real tiles have varying N) run eagerly.  Needs the
-        gradient bucket, i.e. at least one eager ``train_step`` first.  Results equal eager execution up to MIOpen's own
-        run-to-run conv-wgrad rounding.  At N = 131072 the step is GPU-bound (measured: no gain); it pays for small tiles."""
+        replay the ~470 launches with one host call; other shapes (real tiles have varying N) run eagerly.  Needs the
+        gradient bucket, i.e. at least one eager ``train_step`` first.  In channels_last mode the replay is bit-identical to
+        eager execution (with the NCHW / MIOpen grid side: up to MIOpen's run-to-run conv-wgrad rounding).  At N = 131072
+        the step is GPU-bound (measured: no gain); it pays for small tiles."""
         if self.bucket is None:
             raise RuntimeError("capture_graph: run one eager train_step first (the gradient bucket must exist)")
         dev = self.device
