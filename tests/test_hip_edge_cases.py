@@ -135,3 +135,42 @@ def test_training_step_on_ragged_point_counts(channels_last):
         assert (got.detach().cpu() - want).abs().max().item() <= 1e-4 * scale, n
         grads = [p.grad for p in model.parameters() if p.grad is not None]
         assert len(grads) > 100 and all(torch.isfinite(g).all() for g in grads), n
+
+
+@pytest.mark.parametrize("name", ["uniform_1", "uniform_65", "uniform_2049", "one_cell", "line", "corners", "uneven_batch"])
+@pytest.mark.parametrize("c", [4, 32, 64])
+def test_row_balanced_pooling_equals_cell_parallel_pooling(name, c):
+    """t2h_pool_rows_fwd/bwd (a workgroup per 128 sorted rows, cells crossing chunk borders reduced cooperatively) against
+    t2h_pool_max_fwd/bwd (a lane group per cell): identical pooled values and winner bits on every edge cloud (dense cells
+    spanning many chunks, single points, two tiles), gradients equal to summation-order rounding."""
+    from tomosar2height_amd import _lib
+    from tomosar2height_amd.tile import TileIndex
+    if name not in CLOUDS:
+        pytest.skip("cloud not in this build of the edge set")
+    cloud = CLOUDS[name].to(_dev())
+    tile = TileIndex(cloud, 16)
+    n = tile.n_points
+    g = torch.Generator().manual_seed(n + c)
+    feat = torch.randint(-3, 4, (n, c), generator=g).float().to(_dev())       # many exact ties
+    gp = torch.randn(n, c, generator=g).to(_dev())
+    ws = _lib.load().t2h_pool_winner_stride(c)
+    outs = []
+    for rows in (False, True):
+        pooled = torch.empty_like(feat)
+        winner = torch.zeros(n, ws, dtype=torch.uint8, device=_dev())
+        gfeat = torch.full_like(feat, 0.5)
+        if rows:
+            _lib.call("t2h_pool_rows_fwd", _lib.ptr(feat), c, _lib.ptr(tile.cell), _lib.ptr(tile.off0), n, c, _lib.ptr(pooled), c,
+                      _lib.ptr(winner), _lib.stream())
+            _lib.call("t2h_pool_rows_bwd", _lib.ptr(gp), c, _lib.ptr(winner), _lib.ptr(tile.cell), _lib.ptr(tile.off0), n, c, 1,
+                      _lib.ptr(gfeat), c, _lib.stream())
+        else:
+            _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled), c,
+                      _lib.ptr(winner), _lib.stream())
+            _lib.call("t2h_pool_max_bwd", _lib.ptr(gp), c, _lib.ptr(winner), _lib.ptr(tile.off0), tile.B, tile.nbits, c, 1,
+                      _lib.ptr(gfeat), c, _lib.stream())
+        outs.append((pooled, winner, gfeat))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    scale = outs[0][2].abs().max().item() + 1e-12
+    assert (outs[0][2] - outs[1][2]).abs().max().item() <= 2e-6 * scale
