@@ -366,6 +366,32 @@ def test_batched_training_step_equals_mean_of_single_tile_steps():
     assert num <= (1e-4 ** 2) * den
 
 
+def test_hipgraph_captured_inference_forward_is_bit_identical():
+    """BASELINE configs[4]: the Munich forward captured once into a hipGraph and replayed on other tiles (copied into the
+    static inputs) returns exactly the eager heights and footprint logits."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import munich_config
+    model = det_init_(TomoSAR2Height(munich_config(use_image=True)), seed=6).to(_dev()).eval()
+    clouds = [synth_cloud(6000, seed=90 + i).to(_dev()) for i in range(3)]
+    images = [torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(i)).to(_dev()) for i in range(3)]
+    static_cloud, static_image = clouds[0].clone(), images[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        model(input_cloud=static_cloud, input_image=static_image)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        pa_s, pb_s = model(input_cloud=static_cloud, input_image=static_image)
+    for cloud, image in zip(clouds, images):
+        static_cloud.copy_(cloud)
+        static_image.copy_(image)
+        graph.replay()
+        with torch.no_grad():
+            pa, pb = model(input_cloud=cloud, input_image=image)
+        assert torch.equal(pa, pa_s) and torch.equal(pb, pb_s)
+
+
 def test_batched_tiles_equal_single_tiles():
     """BASELINE configs[4] (large-batch inference): B tiles of equal N in one forward (cell ids offset by b*R^2) give the
     same heights as B single-tile forwards, for Munich (depth 6, footprint head, image encoder)."""
