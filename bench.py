@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
+    ap.add_argument("--use-image", action="store_true",
+                    help="train the cloud+image network (BASELINE configs[2] with --mlp-precision bf16): image U-Net encoder on")
     ap.add_argument("--uniform-xy", action="store_true", help="no-skew control: all points uniform in the tile (SURVEY 8d)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (gloo smoke test only)")
     return ap.parse_args()
@@ -198,7 +200,7 @@ def main():
     if args.mode == "infer":
         return infer_bench(args, world, rank, dev, group)
 
-    cfg = berlin_config()
+    cfg = berlin_config(use_image=args.use_image)
     torch.manual_seed(0)
     model = TomoSAR2Height(cfg).to(dev)
     model.set_mlp_precision(args.mlp_precision)
@@ -206,13 +208,13 @@ def main():
     if world > 1:
         broadcast_parameters(model, group)
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate)     # train.py:97
-    trainer = Trainer(model, opt, device=dev, optimize_every=args.optimize_every, use_cloud=True,
+    trainer = Trainer(model, opt, device=dev, optimize_every=args.optimize_every, use_cloud=True, use_image=args.use_image,
                       process_group=group)
 
     tiles = []
     for i in range(args.tile_pool):
-        t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy)
-        tiles.append({"inputs": t["inputs"].to(dev), "dsm": t["dsm"].to(dev)})
+        t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy, with_image=args.use_image)
+        tiles.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
 
     def run(n_steps, offset=0, timeline=None, every=8):
         """`timeline`: record per-launch HIP events on every `every`-th tile-step only -- recording two events around
@@ -250,7 +252,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.steps / elapsed
         out = {
-            "metric": "training tiles/sec (Berlin crop, cloud-only)", "value": round(value, 4), "unit": "tiles/s",
+            "metric": "training tiles/sec (Berlin crop, cloud+image)" if args.use_image else "training tiles/sec (Berlin crop, cloud-only)",
+            "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "f32 tensors, bf16-operand MFMA in the per-point GEMMs",
