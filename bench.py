@@ -11,11 +11,21 @@ A "step" is one tile through ``Trainer.train_step``: forward, L1 loss, backward,
 (reference: trainer.py:47-89, optimize_every = 64).  Tiles are resident in HBM before the timed region.
 Weak scaling: every rank runs K tiles; value = world * K / max-over-ranks(time).
 
-Rank 0 prints ONE JSON line (contract fields + `roofline` + `cpu_baseline` + a per-kernel table).
+Legs, in this order (rank 0 prints ONE compact JSON line at the very end, nothing after it):
+  1. warm-up (W tiles), then the TIMED region: exactly K tile-steps, no per-launch instrumentation.  The accumulation
+     phase is aligned so that the K-th tile ends an optimizer step: the region holds ceil(K / (optimize_every/world))
+     all-reduce + AdamW steps -- never fewer per tile than the reference's one per 64 tiles.
+  2. profile leg (untimed): ``--profile-steps`` more tile-steps with two HIP events around every C-ABI launch, on the
+     stream the kernels run on -> per-kernel table (written to ``--kernel-table``, not printed) and the ``roofline``
+     objects: launches are aggregated per DEVICE KERNEL SYMBOL (t2h_last_kernel_name), the way
+     ``rocprofv3 --kernel-trace --stats`` aggregates, so the two can be compared directly.
+  3. ``--check-dp`` (optional): the data-parallel equivalence check of SURVEY.md 8e.
+  4. cpu_baseline (rank 0, N = 1 only): the oracle torch restatement on the host cores, SURVEY.md 8d protocol.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,6 +37,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
+SCATTER_REDUCE_TAGS = ("t2h_segmean_fwd[C=512,r=32]", "t2h_pool_max_fwd", "t2h_pool_max_bwd", "t2h_trunk_block_fwd",
+                       "t2h_trunk_block_bwd")
 
 
 def parse():
@@ -39,10 +51,18 @@ def parse():
     ap.add_argument("--tile-pool", type=int, default=4, help="distinct resident tiles cycled per rank")
     ap.add_argument("--channels-last", type=int, default=1, help="grid side in NHWC (same numerics, no layout copies)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--timing-every", type=int, default=16, help="record per-kernel HIP events on every n-th timed step")
+    ap.add_argument("--profile-steps", type=int, default=16,
+                    help="untimed tile-steps with per-launch HIP events after the timed region (0 = no kernel table)")
+    ap.add_argument("--kernel-table", default=os.path.join("gpurun_out", "bench_kernels.json"),
+                    help="where rank 0 writes the full per-kernel table (never printed: the stdout line stays compact)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="intra-op threads of the headline CPU baseline "
+                                                                "(reference default: conf/config.yaml:20-21, train.py:77-78)")
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0,
+                    help="stop adding timed CPU repetitions once the whole CPU leg has taken this long (>= 1 timed step "
+                         "per thread setting is always taken)")
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = native fp32 MFMA, BASELINE configs[1] (the headline); bf16 = bf16-operand MFMA "
                          "(configs[2]); bf16x3 = fp32-grade products from 3-way bf16 splitting (opt-in experiment)")
@@ -58,6 +78,10 @@ def parse():
                     help="train the cloud+image network (BASELINE configs[2] with --mlp-precision bf16): image U-Net encoder on")
     ap.add_argument("--uniform-xy", action="store_true", help="no-skew control: all points uniform in the tile (SURVEY 8d)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (gloo smoke test only)")
+    ap.add_argument("--check-dp", action="store_true",
+                    help="SURVEY 8e equivalence check: the W-rank accumulated + all-reduced gradient of 2W fixed tiles vs "
+                         "the same tiles accumulated by one rank alone; reports max_rel_diff, allreduce_ms, rccl_ranks")
+    ap.add_argument("--fused-optimizer", type=int, default=1, help="1 = t2h flat-bucket AdamW kernel, 0 = torch.optim.AdamW")
     return ap.parse_args()
 
 
@@ -72,25 +96,48 @@ def pmc_traffic():
         return {}
 
 
-def cpu_baseline(points: int, threads: int):
-    """The oracle's torch restatement of the reference model ("port"), one tile-step (fwd + bwd) of the SAME
-    workload on the host cores.  This is the only place bench.py touches oracle/."""
+def cpu_baseline(args):
+    """The oracle's torch restatement of the reference model ("port"), fwd + bwd tile-steps of the SAME workload on the
+    host cores: ``--cpu-warmup`` + ``--cpu-steps`` timed repetitions, median, at the reference's 8 intra-op threads
+    (the headline `value`) and at all host cores (`all_cores`).  This is the only place bench.py touches oracle/."""
     from oracle import torch_ref
     from tomosar2height_amd.config import berlin_config
     from tomosar2height_amd.synthetic import berlin_tile
-    if threads > 0:
-        torch.set_num_threads(threads)
-    cores = torch.get_num_threads()
+    t_leg = time.perf_counter()
+    host_cores = os.cpu_count() or 1
     torch.manual_seed(0)
     model = torch_ref.TomoSAR2Height(berlin_config())
-    warm = berlin_tile(1, n_points=2048)
-    torch_ref.train_loss(model, warm["inputs"], None, warm["dsm"]).backward()
-    tile = berlin_tile(0, n_points=points)
-    t0 = time.perf_counter()
-    torch_ref.train_loss(model, tile["inputs"], None, tile["dsm"]).backward()
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"1 tile-step (fwd+bwd, N={points}, fp32) of the oracle torch restatement, {dt:.1f} s"}
+    tile = berlin_tile(0, n_points=args.points)
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        t0 = time.perf_counter()
+        torch_ref.train_loss(model, tile["inputs"], None, tile["dsm"]).backward()
+        return time.perf_counter() - t0
+
+    def leg(threads, warm, reps):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            one()
+        times = [one()]
+        while len(times) < reps and time.perf_counter() - t_leg < args.cpu_budget_s:
+            times.append(one())
+        med = statistics.median(times)
+        return {"value": round(1.0 / med, 5), "cores": torch.get_num_threads(), "median_s": round(med, 2),
+                "timed_steps": len(times), "warmup_steps": warm}
+
+    small = berlin_tile(1, n_points=2048)      # first-touch allocations / lazy initialisation, not a measurement
+    torch_ref.train_loss(model, small["inputs"], None, small["dsm"]).backward()
+    main = leg(min(args.cpu_threads, host_cores), args.cpu_warmup, args.cpu_steps)
+    out = {"value": main["value"], "unit": "tiles/s", "cores": main["cores"], "kind": "port",
+           "sample": f"median of {main['timed_steps']} tile-steps (fwd+bwd, N={args.points}, fp32) after {main['warmup_steps']} "
+                     f"warm-up, oracle torch restatement, {main['median_s']} s/step, {main['cores']} threads "
+                     f"(reference default) on a {host_cores}-core host"}
+    if host_cores > main["cores"]:
+        allc = leg(host_cores, 1, max(1, min(3, args.cpu_steps)))
+        out["all_cores"] = {k: allc[k] for k in ("value", "cores", "median_s", "timed_steps")}
+    out["leg_s"] = round(time.perf_counter() - t_leg, 1)
+    return out
 
 
 def infer_bench(args, world, rank, dev, group):
@@ -123,7 +170,7 @@ def infer_bench(args, world, rank, dev, group):
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            static_out = model(input_cloud=static_cloud, input_image=static_image)
+            static_out = model(input_cloud=static_cloud, input_image=static_image)  # noqa: F841 (kept alive by the graph)
 
     def run(n, off=0):
         with torch.no_grad():
@@ -167,6 +214,90 @@ def infer_bench(args, world, rank, dev, group):
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------- kernel table
+def kernel_tables(timeline, n_steps):
+    """(per-tag rows, per-symbol rows) from a KernelTimeline over ``n_steps`` tile-steps, both sorted by time."""
+    def row(name, d):
+        avg_us = 1e3 * d["ms"] / d["calls"]
+        per_b, per_f = d["bytes"] / d["calls"], d["flops"] / d["calls"]
+        gbs = per_b / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        tfs = per_f / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+        # the roofline that bounds the launch: arithmetic intensity against the machine balance (157.3 TF / 8 TB/s)
+        mfma = per_f > 0 and per_f / max(per_b, 1) > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+        return {"kernel": name, "launches_per_step": round(d["calls"] / n_steps, 2), "avg_us": round(avg_us, 2),
+                "bytes_per_launch": int(per_b), "flops_per_launch": int(per_f), "GBps": round(gbs, 1),
+                "TFLOPs": round(tfs, 2), "bound": "mfma" if mfma else "hbm",
+                "frac": round(tfs / MFMA_F32_PEAK_TFLOPS if mfma else gbs / HBM_PEAK_GBS, 4),
+                "ms_per_step": round(d["ms"] / n_steps, 4)}
+
+    per_tag = timeline.summary()
+    per_symbol = {}
+    for name, d in per_tag.items():
+        s = per_symbol.setdefault(d["symbol"], {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0, "entry_points": set()})
+        for k in ("calls", "ms", "bytes", "flops"):
+            s[k] += d[k]
+        s["entry_points"].add(name.split("[")[0])
+    tags = sorted((dict(row(n, d), symbol=d["symbol"]) for n, d in per_tag.items()), key=lambda r: -r["ms_per_step"])
+    syms = sorted((dict(row(n, d), entry_points=sorted(d["entry_points"])) for n, d in per_symbol.items()),
+                  key=lambda r: -r["ms_per_step"])
+    return tags, syms
+
+
+def roof(k, traffic=None):
+    mfma = k["bound"] == "mfma"
+    return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["TFLOPs"] if mfma else k["GBps"],
+            "peak": MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s",
+            "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"]}
+
+
+# ---------------------------------------------------------------------------------------------- DP equivalence
+def check_dp(args, world, rank, dev, group, model, make_trainer):
+    """W ranks x 2 fixed-seed tiles each, accumulated + all-reduced (SUM), against the same 2W tiles
+    accumulated by this rank alone, in fp32 (difference = re-association only).  Also times the all-reduce of the flat
+    bucket and checks that the replicas' parameters are still bit-identical."""
+    from tomosar2height_amd.synthetic import berlin_tile
+    n_pts = min(args.points, 32768)
+    tiles = [berlin_tile(seed=7000 + i, n_points=n_pts) for i in range(2 * world)]
+    tiles = [{k: t[k].to(dev) for k in ("inputs", "dsm")} for t in tiles]
+    grabbed = {}
+
+    def grab(key):
+        def hook(flat):
+            grabbed[key] = flat.clone()
+        return hook
+
+    null_opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    dp = make_trainer(null_opt, 2 * world, group)
+    dp.on_reduced = grab("dp")
+    for i in range(2):
+        dp.train_step(tiles[rank + i * world])           # rank r: tiles r, r + W  (i mod W == r)
+    single = make_trainer(null_opt, 2 * world, None)
+    single.on_reduced = grab("single")
+    for t in tiles:
+        single.train_step(t)
+    torch.cuda.synchronize()
+    ref = grabbed["single"]
+    rel = float(((grabbed["dp"] - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item())
+    out = {"tiles": 2 * world, "points_per_tile": n_pts, "max_rel_diff": rel, "bucket_floats": int(ref.numel())}
+    if world > 1:
+        flat = dp.bucket.flat
+        for _ in range(2):
+            dist.all_reduce(flat, group=group)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(flat, group=group)
+        torch.cuda.synchronize()
+        out["allreduce_ms"] = round(1e3 * (time.perf_counter() - t0) / 5, 3)
+        flat.zero_()
+        psum = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        both = torch.cat([psum, -psum])
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)      # max(x) == -max(-x) on every rank <=> identical
+        out["replicas_identical"] = bool((both[0] + both[1]).item() == 0.0)
+    out["rccl_ranks"] = world if (world > 1 and dist.get_backend(group) == "nccl") else 0
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,7 +324,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     from tomosar2height_amd import TomoSAR2Height, _lib, grid
-    from tomosar2height_amd.config import berlin_config, munich_config
+    from tomosar2height_amd.config import berlin_config
     from tomosar2height_amd.synthetic import berlin_tile
     from tomosar2height_amd.trainer import Trainer, broadcast_parameters
 
@@ -207,25 +338,35 @@ def main():
     model.set_channels_last(bool(args.channels_last))
     if world > 1:
         broadcast_parameters(model, group)
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate)     # train.py:97
-    trainer = Trainer(model, opt, device=dev, optimize_every=args.optimize_every, use_cloud=True, use_image=args.use_image,
-                      process_group=group)
+
+    def make_optimizer():
+        if args.fused_optimizer:
+            try:
+                from tomosar2height_amd.optim import FlatAdamW
+                return FlatAdamW(model.parameters(), lr=cfg.training.learning_rate), "t2h FlatAdamW (one kernel over the flat bucket)"
+            except ImportError:
+                pass
+        return torch.optim.AdamW(model.parameters(), lr=cfg.training.learning_rate), "torch.optim.AdamW"     # train.py:97
+
+    def make_trainer(opt, every, grp):
+        return Trainer(model, opt, device=dev, optimize_every=every, use_cloud=True, use_image=args.use_image,
+                       process_group=grp)
+
+    opt, opt_name = make_optimizer()
+    trainer = make_trainer(opt, args.optimize_every, group)
 
     tiles = []
     for i in range(args.tile_pool):
         t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy, with_image=args.use_image)
         tiles.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
 
-    def run(n_steps, offset=0, timeline=None, every=8):
-        """`timeline`: record per-launch HIP events on every `every`-th tile-step only -- recording two events around
-        each of the ~370 t2h launches of a step costs ~5 ms of host time per step, so instrumenting all K steps would
-        distort the headline number by ~15 %."""
-        for s in range(n_steps):
-            if timeline is not None and (s % every == every - 1 or (n_steps < every and s == n_steps - 1)):
-                with timeline:
-                    trainer.train_step(tiles[(offset + s) % len(tiles)])
-            else:
-                trainer.train_step(tiles[(offset + s) % len(tiles)])
+    state = {"i": 0, "optimizer_steps": 0}
+
+    def run(n_steps):
+        for _ in range(n_steps):
+            if trainer.train_step(tiles[state["i"] % len(tiles)]):
+                state["optimizer_steps"] += 1
+            state["i"] += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -237,16 +378,37 @@ def main():
     if args.hip_graph:
         trainer.capture_graph(tiles[0])
         run(2)
+    # phase-align: the K-th timed tile must end an optimizer step, so the timed region contains the all-reduce + AdamW
+    # work of ceil(K / local_every) optimizer steps (the driver's K = 20 would otherwise never reach the 64th tile)
+    le = trainer.local_every
+    trainer.accumulated_steps = (le - args.steps % le) % le
     fence()
-    timeline = None if (args.no_kernel_timing or args.hip_graph) else _lib.KernelTimeline()
+    steps_before = state["optimizer_steps"]
     t0 = time.perf_counter()
-    run(args.steps, args.warmup, timeline, args.timing_every)
+    run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    timed_optimizer_steps = state["optimizer_steps"] - steps_before
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
+    timeline = None
+    if args.profile_steps > 0 and not args.hip_graph:
+        timeline = _lib.KernelTimeline()
+        with timeline:
+            run(args.profile_steps)
+        fence()
+    # one optimizer boundary on its own (all-reduce + AdamW + bucket zero), host-timed between fences
+    fence()
+    tb = time.perf_counter()
+    trainer.optimizer_boundary()
+    fence()
+    boundary_ms = 1e3 * (time.perf_counter() - tb)
+
+    dp = check_dp(args, world, rank, dev, group, model, make_trainer) if args.check_dp else None
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -261,55 +423,47 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: Berlin cloud-only, fp32, B=1 tile, "
                                    f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
-                                   f"optimize_every={args.optimize_every} (AdamW + grad all-reduce amortised)",
+                                   f"optimize_every={args.optimize_every}",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
-                       "parallelism": f"dp{world}", "channels_last": bool(args.channels_last),
+                       "optimizer_steps_in_timed_region": timed_optimizer_steps, "optimizer": opt_name,
+                       "optimizer_boundary_ms": round(boundary_ms, 3),
+                       "parallelism": f"dp{world}", "collective": (dist.get_backend(group) if world > 1 else None),
+                       "channels_last": bool(args.channels_last),
                        "point_distribution": "uniform (no-skew control)" if args.uniform_xy else "70 % in 160 buildings + 30 % uniform",
                        "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",
-                       "miopen_find": bool(args.miopen_find), "hip_graph": bool(args.hip_graph)},
+                       "library_fallbacks": getattr(grid, "fallback_count", lambda: None)(),
+                       "hip_graph": bool(args.hip_graph)},
         }
         if timeline is not None:
-            timed_steps = max(1, len([i for i in range(args.steps) if i % args.timing_every == args.timing_every - 1]))   # >= 1: see run()
-            out["config"]["kernel_timing"] = f"HIP events on {timed_steps} of the {args.steps} timed steps"
-            kernels = []
-            for name, d in sorted(timeline.summary().items(), key=lambda kv: -kv[1]["ms"]):
-                avg_us = 1e3 * d["ms"] / d["calls"]
-                per_launch_b, per_launch_f = d["bytes"] / d["calls"], d["flops"] / d["calls"]
-                gbs = per_launch_b / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-                tfs = per_launch_f / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
-                # roofline that bounds the launch: arithmetic intensity vs the machine balance (157.3 TF / 8 TB/s)
-                mfma_bound = per_launch_f > 0 and per_launch_f / max(per_launch_b, 1) > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
-                kernels.append({"kernel": name, "launches_per_step": round(d["calls"] / timed_steps, 2),
-                                "avg_us": round(avg_us, 2), "bytes_per_launch": int(per_launch_b),
-                                "flops_per_launch": int(per_launch_f), "GBps": round(gbs, 1), "TFLOPs": round(tfs, 2),
-                                "bound": "mfma" if mfma_bound else "hbm",
-                                "frac": round(tfs / MFMA_F32_PEAK_TFLOPS if mfma_bound else gbs / HBM_PEAK_GBS, 4),
-                                "ms_per_step": round(d["ms"] / timed_steps, 4)})
-
-            def roof(k):
-                traffic = pmc_traffic().get(k["kernel"]) if args.points == 131072 else None
-                if k["bound"] == "mfma":
-                    return {"kernel": k["kernel"], "bound": "mfma", "achieved": k["TFLOPs"], "peak": MFMA_F32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"]}
-                return {"kernel": k["kernel"], "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"]}
-
-            if kernels:
-                out["roofline"] = roof(kernels[0])                       # the launch with the largest time share
-                named = {k["kernel"]: k for k in kernels}
+            tags, syms = kernel_tables(timeline, args.profile_steps)
+            traffic = pmc_traffic() if args.points == 131072 else {}
+            named = {k["kernel"]: k for k in tags}
+            if syms:
+                out["roofline"] = roof(syms[0], traffic.get(syms[0]["kernel"]))       # the kernel symbol with the largest time share
+                out["roofline"]["entry_points"] = syms[0]["entry_points"]
+                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps; "
+                                          "class totals: sum(algorithmic flops or bytes) / sum(duration)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
-                out["roofline_scatter_reduce"] = [roof(named[n]) for n in
-                                                  ("t2h_segmean_fwd[C=512,r=32]", "t2h_pool_max_fwd") if n in named]
-                # the largest grid convolutions: implicit-GEMM kernels of csrc/conv.hip
-                out["roofline_grid_conv"] = [roof(named[n]) for n in
-                                             ("t2h_conv3x3_fwd[64->128,512x512]", "t2h_conv3x3_dgrad[128->64,512x512]",
-                                              "t2h_conv3x3_wgrad[64->128,512x512]") if n in named]
-                out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in kernels), 3)
-                out["kernels"] = kernels
+                out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n)) for n in SCATTER_REDUCE_TAGS if n in named]
+                out["roofline_top_symbols"] = [{"kernel": s["kernel"][:60], "ms_per_step": s["ms_per_step"], "frac": s["frac"],
+                                                "bound": s["bound"]} for s in syms[:6]]
+                out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in tags), 3)
+                out["t2h_launches_per_step"] = round(sum(k["launches_per_step"] for k in tags), 1)
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
+                with open(args.kernel_table, "w") as f:
+                    json.dump({"workload": out["config"]["workload"], "profile_steps": args.profile_steps,
+                               "by_entry_point": tags, "by_kernel_symbol": syms}, f, indent=1)
+                out["config"]["kernel_table"] = args.kernel_table
+            except OSError as e:
+                out["config"]["kernel_table"] = f"not written: {e}"
+        if dp is not None:
+            out["check_dp"] = dp
         if world == 1 and not args.skip_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.points, args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(args)          # last: the GPU legs above run back to back
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

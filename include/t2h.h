@@ -40,13 +40,18 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 3
+#define T2H_ABI_VERSION 4
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
 
 int t2h_abi_version(void);
 const char *t2h_last_error_string(void);
+/* Profiling aid (no reference counterpart): the name of the main device kernel the last entry point on this
+ * thread launched ("" if it does not record one), so that a host-side timeline can aggregate per kernel symbol
+ * exactly like `rocprofv3 --kernel-trace --stats` does.  t2h_clear_kernel_name() resets it. */
+const char *t2h_last_kernel_name(void);
+void t2h_clear_kernel_name(void);
 
 /* ---------------------------------------------------------------------------------------------
  * coordinate2index(x, reso)                                     utils/coordinate.py:12-28
@@ -65,8 +70,11 @@ int t2h_coordinate2index(const float *pts, int stride, int64_t total, int reso, 
  *   perm        [B*N]       index (within its tile, 0..N-1) of the original point at each sorted slot
  *   cell        [B*N]       b * 4^nbits + morton(ix, iy) of each sorted point (finest level)
  *   off0        [B * 4^nbits + 1]  CSR offsets into the sorted order (global, i.e. including b*N)
- *   status      [1]         number of points with x or y outside [0,1) (clamped into the border
- *                           cell; the reference would index out of range) -- caller checks it
+ *   status      [2]         [0]: number of points of THIS call with x or y outside [0,1) or NaN (clamped into
+ *                           the border cell; the reference would index out of range) -- zeroed by every call;
+ *                           [1]: the same count, ADDED to whatever the caller left there (never zeroed by the
+ *                           library), so that a caller can keep one running total across many tiles and read
+ *                           it once, without a synchronisation per tile
  * The sort is stable (original order inside a cell), so results are run-to-run deterministic. */
 size_t t2h_tile_workspace_bytes(int B, int N, int nbits);
 int t2h_tile_build(const float *cloud, int dim, int B, int N, int nbits, float *pts_sorted, int32_t *perm,
@@ -277,6 +285,19 @@ int t2h_tile_crop_finish(double *z_shift, t2h_stream_t stream);
  * Layout glue between the conv side (NCHW) and the point side (NHWC): [B, C, P] <-> [B, P, C]. */
 int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * AdamW step over all parameters in one launch                       train.py:97, trainer.py:78-79
+ * (torch.optim.AdamW arithmetic: decoupled weight decay, bias corrections in double on the host, amsgrad off).
+ *   table   [n_tensors] device records {float *p; const float *g; float *m; float *v; int64 n}  (5 x 8 bytes each):
+ *           parameter, its gradient (a view of the trainer's flat bucket), first / second moment, element count;
+ *           p, g, m, v of one tensor share one dense memory layout, so the update runs in storage order
+ *   chunks  [n_chunks] device records {int32 tensor, int32 first_element}, t2h_adamw_chunk_elems() elements each
+ *   step    1-based step count (the bias corrections 1 - beta^step)
+ *   zero_grad != 0: the gradient is set to zero in the same pass (trainer.py:80 optimizer.zero_grad()). */
+int t2h_adamw_chunk_elems(void);
+int t2h_adamw_flat_step(const void *table, const int32_t *chunks, int n_chunks, double lr, double beta1, double beta2,
+                        double eps, double weight_decay, int64_t step, int zero_grad, t2h_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,74 @@
+"""-m gpu: the HIP model + GradBucket + direct weight-gradient accumulation under torch.distributed on the hardware
+(last row; reference trainer.py:69-89).  The box has ONE MI355X, so: (a) two ranks share cuda:0 and reduce
+over gloo -- everything but the transport is the 8-GPU code path; (b) a 1-rank RCCL ("nccl") group runs the real
+collective library on the flat bucket; (c) bench.py's own N > 1 path with --check-dp; (d) the multi-rank mosaic.
+Ranks are fresh child processes (torch.distributed.run), started before they touch the GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(nproc, script_args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n--- stdout\n{r.stdout[-4000:]}\n--- stderr\n{r.stderr[-6000:]}"
+    return r
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_model_equals_single_process(tmp_path):
+    out = str(tmp_path / "dp.json")
+    _launch(2, [WORKER, "dp", out])
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["identical_replicas"]
+    # 2 + 2 tiles summed per rank then across ranks vs 4 tiles summed in order: fp32 re-association only
+    assert res["grad_max_rel"] <= 2e-5, res
+    assert res["param_max_abs"] <= 2e-5, res            # AdamW, lr 1e-3: a lost rank contribution would move weights by ~1e-3
+    assert abs(res["loss_dp"] - res["loss_single"]) <= 1e-5 * abs(res["loss_single"])
+    assert len(res["none_grad"]) == 8 and all("up_convs.3." in k for k in res["none_grad"])     # alto.py:241-242
+    assert res["bucket"] == res["bucket_single"] >= res["live"] and res["bucket_views_aligned"]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_is_bit_identical(tmp_path):
+    out = str(tmp_path / "rccl1.json")
+    _launch(1, [WORKER, "rccl1", out])
+    res = json.load(open(out))
+    assert res == {"backend": "nccl", "grad_equal": True, "param_equal": True, "loss_equal": True, "f64_ok": True}
+
+
+@pytest.mark.gpu
+def test_multi_rank_mosaic_equals_single(tmp_path):
+    out = str(tmp_path / "mosaic.json")
+    _launch(2, [WORKER, "mosaic", out])
+    res = json.load(open(out))
+    assert not res["nan"] and res["max_abs"] <= 1e-12 * max(res["scale"], 1.0), res
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_check_dp_line_is_compact():
+    r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4",
+                    "--warmup", "1", "--points", "8192", "--optimize-every", "4", "--profile-steps", "2", "--check-dp",
+                    "--kernel-table", os.path.join(ROOT, "gpurun_out", "bench_kernels_test.json")])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), "the JSON line must be the last thing on stdout"
+    assert len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["optimizer_steps_in_timed_region"] == 2
+    assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]
+    assert "roofline" in d and d["roofline"]["frac"] > 0

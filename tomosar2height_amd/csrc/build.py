@@ -27,19 +27,35 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile(args):
+    src, verbose, hipcc = args
+    obj = src[:-4] + ".o"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+    if verbose:
+        cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Objects are rebuilt only when their source (or any shared header) is newer; sources compile in parallel."""
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    headers = glob.glob(os.path.join(HERE, "*.h")) + \
+        [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "t2h.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    todo, objs = [], []
     for src in sources():
         obj = src[:-4] + ".o"
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-               "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
-        if verbose:
-            cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.run(cmd, check=True)
         objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            todo.append((src, verbose, hipcc))
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(todo), int(os.environ.get("T2H_BUILD_JOBS", "6")))) as pool:
+            list(pool.map(_compile, todo))
     subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT] + objs, check=True)
     return OUT
 

@@ -22,6 +22,7 @@
 // coordinates kept in registers, out-of-image taps read as zero).  Small planes with many channels (32^2 x 512: 32
 // output tiles) split the reduction over grid.z into slabs in caller workspace, summed in a fixed order by the
 // epilogue kernel (bias / ReLU / mask / accumulate applied there) -- deterministic, no atomics.
+#include <string>
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -402,6 +403,10 @@ int launch_rows(const ConvArgs &a, const RowsPlan &r, hipStream_t s, const char 
     if (r.bn == 128) hipLaunchKernelGGL((conv_rows_kernel<128, 2, 2, GEOM, 4>), grid, dim3(NT), 0, s, a);
     else if (r.bn == 64) hipLaunchKernelGGL((conv_rows_kernel<64, 2, 2, GEOM, 4>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((conv_rows_kernel<32, 4, 1, GEOM, 4>), grid, dim3(NT), 0, s, a);
+    static const std::string names[3] = {"conv_rows_kernel<128,2,2," + std::to_string(GEOM) + ",4>",
+                                         "conv_rows_kernel<64,2,2," + std::to_string(GEOM) + ",4>",
+                                         "conv_rows_kernel<32,4,1," + std::to_string(GEOM) + ",4>"};
+    note_kernel(names[r.bn == 128 ? 0 : (r.bn == 64 ? 1 : 2)].c_str());
     return check_launch(what);
 }
 
@@ -553,6 +558,7 @@ T2H_API int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float 
     if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, false>), grid, dim3(NT), 0, s, a);
     else if (p.bm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 4, false>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4, false>), grid, dim3(NT), 0, s, a);
+    note_kernel(p.bm == 128 ? "conv_wgrad_kernel<128,128,2,2,4,false>" : (p.bm == 64 ? "conv_wgrad_kernel<64,128,2,2,4,false>" : "conv_wgrad_kernel<32,128,1,4,4,false>"));
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
     const int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, colslab, db, s);
@@ -626,6 +632,7 @@ T2H_API int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int 
     if (p.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, 4, true>), grid, dim3(NT), 0, s, a);
     else if (p.bm == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2, 4, true>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(NT), 0, s, a);
+    note_kernel(p.bm == 128 ? "conv_wgrad_kernel<128,128,2,2,4,true>" : (p.bm == 64 ? "conv_wgrad_kernel<64,128,2,2,4,true>" : "conv_wgrad_kernel<32,128,1,4,4,true>"));
     if (int rc = check_launch("upconv2x2_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw,
                                nullptr, nullptr, s);

@@ -19,6 +19,7 @@
 // slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
 // deterministic).
 #include <stdlib.h>
+#include <string>
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -388,6 +389,11 @@ static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char 
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, A_KC, B_KC, BK, XCD, MINW, MODE>), grid, dim3(64 * WM * WN), 0, s, a);
+    static const std::string name = "gemm_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + "," + std::to_string(WM) + "," +
+                                    std::to_string(WN) + "," + (A_KC ? "true" : "false") + "," + (B_KC ? "true" : "false") + "," +
+                                    std::to_string(BK) + "," + (XCD ? "true" : "false") + "," + std::to_string(MINW) + "," +
+                                    std::to_string(MODE) + ">";
+    note_kernel(name.c_str());
     return check_launch(what);
 }
 

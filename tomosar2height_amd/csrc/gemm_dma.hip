@@ -314,6 +314,7 @@ int launch_gemm_dma(bool b_kc, const GemmArgs &a, hipStream_t s, const char *wha
     if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
     if (b_kc) hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(gemm_dma_nn_kernel, grid, dim3(NT), 0, s, a);
+    note_kernel(b_kc ? "gemm_dma_kernel" : "gemm_dma_nn_kernel");
     return check_launch(what);
 }
 
@@ -326,6 +327,7 @@ int launch_gemm_dma_tn(const GemmArgs &a, int splits, hipStream_t s, const char 
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
     hipLaunchKernelGGL(gemm_dma_tn_kernel, grid, dim3(NT), 0, s, a);
+    note_kernel("gemm_dma_tn_kernel");
     return check_launch(what);
 }
 

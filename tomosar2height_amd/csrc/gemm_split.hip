@@ -265,6 +265,7 @@ int launch_gemm_split(int mode, bool a_kc, bool b_kc, const SplitArgs &a, int sp
         else T2H_SPLIT_LAUNCH(false, false, 1, 3);
     }
 #undef T2H_SPLIT_LAUNCH
+    note_kernel(mode == 2 ? "gemm_split_kernel<bf16x3>" : "gemm_split_kernel<bf16>");
     return check_launch(what);
 }
 

@@ -17,6 +17,10 @@ constexpr int kWave = 64;
 char *err_buf();
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+// name of the device kernel an entry point just launched (its main kernel, not helper reductions): thread local,
+// read back through t2h_last_kernel_name() by profilers that aggregate per kernel symbol like rocprofv3 does
+void note_kernel(const char *name);
+const char *noted_kernel();
 
 inline hipStream_t as_stream(t2h_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -22,6 +22,9 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+static thread_local const char *g_noted_kernel = "";
+void note_kernel(const char *name) { g_noted_kernel = name; }
+const char *noted_kernel() { return g_noted_kernel; }
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(T2H_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -56,7 +59,7 @@ __global__ void tile_keys_kernel(const float *__restrict__ cloud, int dim, int N
     bool ok = (x >= 0.0f) && (x < 1.0f) && (y >= 0.0f) && (y < 1.0f);  // false for NaN too
     int ix = ok ? (int)__fmul_rn(x, (float)R) : (int)fminf(fmaxf(x * (float)R, 0.0f), (float)(R - 1));
     int iy = ok ? (int)__fmul_rn(y, (float)R) : (int)fminf(fmaxf(y * (float)R, 0.0f), (float)(R - 1));
-    if (!ok) atomicAdd(status, 1);
+    if (!ok) { atomicAdd(status, 1); atomicAdd(status + 1, 1); }
     keys[(size_t)b * N + i] = morton2((uint32_t)ix, (uint32_t)iy);
 }
 
@@ -190,6 +193,8 @@ using namespace t2h;
 
 T2H_API int t2h_abi_version(void) { return T2H_ABI_VERSION; }
 T2H_API const char *t2h_last_error_string(void) { return err_buf(); }
+T2H_API const char *t2h_last_kernel_name(void) { return noted_kernel(); }
+T2H_API void t2h_clear_kernel_name(void) { note_kernel(""); }
 
 T2H_API int t2h_coordinate2index(const float *pts, int stride, int64_t total, int reso, int64_t *index,
                                  t2h_stream_t stream) {

@@ -42,7 +42,10 @@ class LocalPoolPointnet(nn.Module):
         else:
             raise ValueError("Invalid scatter type")
         self.channels_last = False
+        # check_domain=True: synchronise and raise on every forward.  Default: count on the device only; the running
+        # total (out_of_domain_total) is read by Trainer at optimizer-step boundaries and by DSMGenerator per mosaic
         self.check_domain = False
+        self.register_buffer("domain_status", torch.zeros(2, dtype=torch.int32), persistent=False)
 
     def set_channels_last(self, flag: bool):
         """Keep the grid side in channels_last memory so planes need no NCHW<->NHWC copies."""
@@ -50,13 +53,21 @@ class LocalPoolPointnet(nn.Module):
         if hasattr(self.unet, "set_channels_last"):
             self.unet.set_channels_last(flag)
 
+    def out_of_domain_total(self, reset: bool = True) -> int:
+        """Points with x or y outside [0, 1) (or NaN) over all forwards since the last reset (synchronises).  Such
+        points were clamped into the border cells; the reference would index out of range (coordinate.py:12-28)."""
+        n = int(self.domain_status[1].item())
+        if reset and n:
+            self.domain_status.zero_()
+        return n
+
     def point_features(self, tile: TileIndex) -> torch.Tensor:
         """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max-pools, fc_c."""
         return mlp.point_trunk(tile, tile.pts, self.fc_pos, self.blocks, self.fc_c)
 
     def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
         """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``."""
-        tile = TileIndex(inputs, self.reso_plane)
+        tile = TileIndex(inputs, self.reso_plane, status=self.domain_status)
         if self.check_domain:
             tile.check_domain()
         net = self.point_features(tile)

@@ -13,6 +13,7 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import _lib
 
@@ -23,8 +24,14 @@ class DSMGenerator:
     NODATA_VALUE = np.nan
 
     def __init__(self, model, device, tiles, bounds, dsm_pixel_size=(1.0, 1.0), patch_size=(512.0, 512.0),
-                 half_blend_percent=None, use_cloud=True, use_image=False):
+                 half_blend_percent=None, use_cloud=True, use_image=False, process_group=None):
+        """``process_group`` (an addition): with W ranks, rank r runs the tiles ``i % W == r`` and the
+        float64 ``dsm / weight`` pair is summed over ranks with ONE all-reduce before the normalisation
+        (generator.py:149-157 -- the blend is a sum over tiles, so it shards without any other exchange)."""
         self.model, self.device, self.tiles = model, device, tiles
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if process_group is not None else 1
+        self.rank = dist.get_rank(process_group) if process_group is not None else 0
         self.pixel_size = [float(dsm_pixel_size[0]), float(dsm_pixel_size[1])]
         self.half_blend_percent = half_blend_percent or [0.5, 0.5]
         self.use_cloud, self.use_image = use_cloud, use_image
@@ -65,6 +72,13 @@ class DSMGenerator:
         h = height.reshape(height.shape[-3], height.shape[-2]) if height.dim() == 4 else height
         h = h.contiguous()
         _lib.require_device(h, dsm, weight, what="mosaic_accumulate")
+        if tuple(h.shape) != tuple(self.patch_weight.shape):
+            raise ValueError(f"height map {tuple(h.shape)} does not have the blend-weight shape "
+                             f"{tuple(self.patch_weight.shape)} (patch_size / dsm_pixel_size)")
+        if t_row < 0 or l_col < 0 or t_row + h.shape[0] > dsm.shape[0] or l_col + h.shape[1] > dsm.shape[1]:
+            # the reference's slice `+=` (generator.py:152-154) raises a shape error here
+            raise ValueError(f"tile rows [{t_row}, {t_row + h.shape[0]}) x cols [{l_col}, {l_col + h.shape[1]}) is not "
+                             f"inside the {tuple(dsm.shape)} mosaic")
         _lib.call("t2h_mosaic_accumulate", _lib.ptr(h), h.shape[0], h.shape[1], _lib.ptr(self.patch_weight), _lib.ptr(dsm),
                   _lib.ptr(weight), dsm.shape[0], dsm.shape[1], int(t_row), int(l_col), 1, _lib.stream(),
                   nbytes=h.numel() * (4 + 8 + 4 * 8))
@@ -74,7 +88,9 @@ class DSMGenerator:
         dsm = torch.zeros(self.dsm_shape, dtype=torch.float64, device=dev)
         weight = torch.zeros(self.dsm_shape, dtype=torch.float64, device=dev)
         self.model.eval()
-        for data in self.tiles:
+        for i, data in enumerate(self.tiles):
+            if i % self.world != self.rank:
+                continue
             if not bool(data["is_valid"][0]):
                 continue
             min_b = data["min_bound"].squeeze().double()
@@ -86,5 +102,13 @@ class DSMGenerator:
                 image = data.get("image").to(dev) if self.use_image else None
                 height = self.model(input_cloud=cloud, input_image=image)[0]
             self.accumulate(dsm, weight, height, t_row, l_col)
+        if self.world > 1:
+            pair = torch.stack((dsm, weight))
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=self.group)      # one collective per mosaic
+            dsm, weight = pair[0].contiguous(), pair[1].contiguous()
+        if hasattr(self.model, "out_of_domain_total"):
+            bad = self.model.out_of_domain_total()
+            if bad:
+                raise ValueError(f"{bad} input point(s) had x or y outside [0, 1) (or NaN): un-normalised tile")
         _lib.call("t2h_mosaic_finalize", _lib.ptr(dsm), _lib.ptr(weight), dsm.numel(), _lib.stream(), nbytes=24 * dsm.numel())
         return dsm

@@ -54,6 +54,11 @@ class TomoSAR2Height(nn.Module):
                 m.weight.data = m.weight.data.contiguous(memory_format=fmt)
         return self
 
+    def out_of_domain_total(self, reset: bool = True) -> int:
+        """Running count of input points outside [0, 1)^2 seen by the point encoder (one device sync)."""
+        enc = getattr(self, "point_encoder", None)
+        return enc.out_of_domain_total(reset) if hasattr(enc, "out_of_domain_total") else 0
+
     @staticmethod
     def set_mlp_precision(name: str):
         """'fp32' (default) or 'bf16' for the per-point MLP GEMMs (process-wide; see ``mlp.set_precision``)."""

@@ -20,7 +20,9 @@ class TileIndex:
     inside a cell differs from the reference (stable sort: original order is kept inside a finest cell).
     """
 
-    def __init__(self, cloud: torch.Tensor, plane_resolution: int):
+    def __init__(self, cloud: torch.Tensor, plane_resolution: int, status: torch.Tensor = None):
+        """``status``: optional persistent int32 ``[2]`` device tensor; ``status[1]`` keeps a running total of
+        out-of-domain points over all tiles built with it (read it with one sync whenever convenient)."""
         if cloud.dim() != 3 or cloud.shape[-1] < 2:
             raise ValueError(f"expected a [B, N, dim>=2] point tensor, got {tuple(cloud.shape)}")
         if cloud.dtype != torch.float32:
@@ -40,7 +42,11 @@ class TileIndex:
         self.perm = torch.empty(bn, dtype=torch.int32, device=dev)
         self.cell = torch.empty(bn, dtype=torch.int32, device=dev)
         self.off0 = torch.empty(cells + 1, dtype=torch.int32, device=dev)
-        self.status = torch.empty(1, dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+        elif status.dtype != torch.int32 or status.numel() != 2 or status.device != dev:
+            raise ValueError("status must be an int32 [2] tensor on the points' device")
+        self.status = status
         ws_bytes = lib.t2h_tile_workspace_bytes(self.B, self.N, self.nbits)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         _lib.call("t2h_tile_build", _lib.ptr(cloud), self.dim, self.B, self.N, self.nbits, _lib.ptr(self.pts),
@@ -62,7 +68,7 @@ class TileIndex:
     def out_of_domain(self) -> int:
         """Number of points with x or y outside [0,1) (synchronises).  The reference would raise an index
         error inside torch_scatter for these; here they were clamped into the border cells."""
-        return int(self.status.item())
+        return int(self.status[0].item())
 
     def check_domain(self):
         bad = self.out_of_domain()

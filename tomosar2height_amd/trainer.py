@@ -38,7 +38,9 @@ class GradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.grad is not None]
-        total = sum(p.numel() for p in self.params)
+        # every view starts on a 16-byte boundary (4 floats): the accumulating reductions of the weight-gradient
+        # kernels then always take their float4 path, whatever odd-sized parameter (conv4.bias has 1 element) precedes
+        total = sum(-(-p.numel() // 4) * 4 for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.grad.dtype, device=ref.grad.device)
         off = 0
@@ -53,7 +55,7 @@ class GradBucket:
                 view = torch.as_strided(self.flat, g.size(), g.stride(), storage_offset=off)
             view.copy_(g)
             p.grad = view
-            off += n
+            off += -(-n // 4) * 4
 
     def all_reduce(self, group):
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -64,7 +66,9 @@ class GradBucket:
 
 class Trainer:
     def __init__(self, model: nn.Module, optimizer, device=None, optimize_every=1, use_cloud=False, use_image=False,
-                 use_footprint=False, weight_ce=10., process_group=None):
+                 use_footprint=False, weight_ce=10., process_group=None, check_domain=True, scheduler=None):
+        """``check_domain``: at every optimizer step (one device read per ``optimize_every`` tiles) raise if any input
+        point was outside [0, 1)^2 -- the reference's scatter would index out of range for such a point."""
         self.model = model
         self.optimizer = optimizer
         self.device = device
@@ -73,6 +77,9 @@ class Trainer:
         self.weight_ce = weight_ce
         self.optimizer.zero_grad()
 
+        self.check_domain = check_domain
+        self.scheduler = scheduler        # stepped once per optimizer step, as train.py:188-190 does with CyclicLR
+        self.on_reduced = None
         self.group = process_group
         self.world = dist.get_world_size(process_group) if process_group is not None else 1
         if optimize_every % self.world:
@@ -185,9 +192,25 @@ class Trainer:
         if self.accumulated_steps < self.local_every:
             return False
 
+        self.optimizer_boundary()
+        return True
+
+    def optimizer_boundary(self):
+        """End of an optimizer step (trainer.py:78-89): [all-reduce(SUM) of the flat gradient bucket over the ranks,]
+        ``optimizer.step()``, loss averaging, gradients to zero.  ``on_reduced(flat_grad)``, if set, sees the complete
+        accumulated (and reduced) gradient just before the optimizer consumes it (tests, ``bench.py --check-dp``)."""
         if self.world > 1:
             self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
+        if self.on_reduced is not None:
+            self.on_reduced(self.bucket.flat)
         self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()                                         # train.py:188-190: once per iteration
+        if self.check_domain and hasattr(self.model, "out_of_domain_total"):
+            bad = self.model.out_of_domain_total()
+            if bad:
+                raise ValueError(f"{bad} input point(s) of the last {self.local_every} tile(s) had x or y outside [0, 1) "
+                                 "(or NaN): normalise / crop the tiles as dataset.py:270-278 does")
         with torch.no_grad():
             denom = self.optimize_every
             acc = self.accumulated_loss
@@ -204,7 +227,6 @@ class Trainer:
         self.accumulated_steps = 0
         self.accumulated_loss_dict = {k: 0.0 for k in self.accumulated_loss_dict}
         self.bucket.zero_()     # == optimizer.zero_grad() for every parameter that has a gradient
-        return True
 
     # ------------------------------------------------------------------------------------------ eval
     def eval_step(self, data):
