@@ -136,10 +136,11 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_mosaic_finalize": (n, n, 100, n),
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),
         "t2h_tile_crop_finish": (n, n),
+        "t2h_adamw_flat_step": (n, n, 4, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, 0, n),
         "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }
-    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride")]
+    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems")]
     assert sorted(cases) == sorted(launching), set(launching) ^ set(cases)
     for name, args in cases.items():
         rc = getattr(lib, name)(*args)
