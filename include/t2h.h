@@ -287,6 +287,24 @@ int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_strea
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused PointNet trunk block, hidden_dim = 32               pointnet.py:72-82, 92-99; resnet.py:36-54
+ * One launch per ResnetBlockFC(64 -> 32) over the cell-sorted rows:
+ *     X   = [net_prev | pool_local(net_prev)]       (pts != NULL: X = fc_pos(pts) instead, pointnet.py:72)
+ *     hr  = relu(fc_0(relu(X)))                     [M, 32]  (kept for the backward)
+ *     out = shortcut(X) + (fc_1(hr) + b1)           [M, ld_out >= 32]
+ *     c   = fc_c(relu(out))                         [M, 32]  (wc != NULL: the last block, pointnet.py:81-82)
+ * scatter_max + gather + torch.cat (pointnet.py:76-78) run inside the block's loader: the pooled half of X is never
+ * written to memory.  winner [M, 8] receives the arg-max bits of net_prev's pooling (bit j of byte l: the row holds the
+ * first maximum of its cell for channel 4l + j -- torch_scatter's CPU tie-break), as t2h_pool_max_fwd would.
+ * x_full (optional, [M, 64]): the block input X materialised (tests; the unfused backward).
+ * w0, ws [32, 64]; w1, wc [32, 32]; w_pos [64, 3]: nn.Linear layouts.  cell / off0: from t2h_tile_build. */
+int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *net_prev,
+                        int ld_prev, const int32_t *cell, const int32_t *off0, const float *w0, const float *b0,
+                        const float *w1, const float *b1, const float *ws, const float *wc, const float *bc, int64_t M,
+                        float *x_full, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
+                        t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * AdamW step over all parameters in one launch                       train.py:97, trainer.py:78-79
  * (torch.optim.AdamW arithmetic: decoupled weight decay, bias corrections in double on the host, amsgrad off).
  *   table   [n_tensors] device records {float *p; const float *g; float *m; float *v; int64 n}  (5 x 8 bytes each):

@@ -8,6 +8,7 @@ and the reference's ``torch.cat([net, pooled], dim=2)`` (pointnet.py:78) never m
 writes its output into the left half of the next block's [M, 2h] input buffer and ``pool_max`` writes the right
 half in place.  There is no CPU path here: all tensors must live on the device.
 """
+import os
 from typing import Optional
 
 import torch
@@ -304,6 +305,56 @@ def comm_mlp(sampled, w_a, b_a, w_b, b_b, c_last, w_c, b_c) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ PointNet trunk
+FUSED_TRUNK = os.environ.get("T2H_FUSED_TRUNK", "1") != "0"      # A/B switch: 0 = one GEMM launch per Linear + pool kernels
+
+
+def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
+    """The fused block kernel (csrc/trunk.hip) is built for the reference's trunk widths: hidden_dim = 32, i.e.
+    fc_pos 3 -> 64, blocks 64 -> 32 with a shortcut, fc_c 32 -> 32 (tomosar2height.yaml:7-8, pointnet.py:36-40)."""
+    if not FUSED_TRUNK or n_blocks < 2 or pts.shape[1] < 3 or tuple(params[0].shape) != (64, 3):
+        return False
+    for i in range(n_blocks):
+        w0, b0, w1, b1, ws = params[2 + 5 * i: 7 + 5 * i]
+        if ws is None or tuple(w0.shape) != (32, 64) or tuple(w1.shape) != (32, 32) or tuple(ws.shape) != (32, 64):
+            return False
+    return tuple(params[-2].shape) == (32, 32)
+
+
+def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_x=True):
+    """pointnet.py:72-82 as one launch per block: (cats, hrs, winners) in the layout the backward expects -- cats[i] is
+    block i's [M, 64] input (= [net | pooled]; cats[0] = fc_pos output), cats[-1] the last block's [M, 32] output."""
+    m, nb, dev = pts.shape[0], len(blocks), pts.device
+    cats, hrs, winners = [], [], []
+    net_prev, c_out = None, None
+    for i, (w0, b0, w1, b1, ws) in enumerate(blocks):
+        first, last = i == 0, i == nb - 1
+        x_full = _empty(m, 64, pts) if materialise_x else None
+        hr, out = _empty(m, 32, pts), _empty(m, 32, pts)
+        win = None if first else torch.empty(m, 8, dtype=torch.uint8, device=dev)
+        if last:
+            c_out = _empty(m, 32, pts)
+        wts = [t.contiguous() for t in (w0, b0, w1, b1, ws)]
+        nbytes = m * ((4 * pts.shape[1] if first else 4 * 32 + 4) + 2 * 128 + (0 if first else 8) + (128 if last else 0)
+                      + (256 if materialise_x else 0))
+        flops = 2 * m * (2 * 64 * 32 + 32 * 32 + (32 * 32 if last else 0) + (3 * 64 if first else 0))
+        _lib.call("t2h_trunk_block_fwd",
+                  _lib.ptr(pts) if first else None, pts.shape[1], _lib.ptr(w_pos.contiguous()) if first else None,
+                  _lib.ptr(b_pos) if first else None,
+                  None if first else _lib.ptr(net_prev), 32, None if first else _lib.ptr(tile.cell),
+                  None if first else _lib.ptr(tile.off0),
+                  *[_lib.ptr(t) for t in wts], _lib.ptr(w_c.contiguous()) if last else None, _lib.ptr(b_c) if last else None,
+                  m, None if x_full is None else _lib.ptr(x_full), _lib.ptr(hr), _lib.ptr(out), 32,
+                  None if win is None else _lib.ptr(win), None if c_out is None else _lib.ptr(c_out), _lib.stream(),
+                  nbytes=nbytes, flops=flops, tag="t2h_trunk_block_fwd")
+        cats.append(x_full)
+        hrs.append(hr)
+        if win is not None:
+            winners.append(win)
+        net_prev = out
+    cats.append(net_prev)
+    return c_out, cats, hrs, winners
+
+
 class _PointTrunk(torch.autograd.Function):
     """pointnet.py:72-82 on sorted rows: fc_pos -> block0 -> 4 x {pool_max, block} -> relu -> fc_c.
 
@@ -319,6 +370,11 @@ class _PointTrunk(torch.autograd.Function):
         w_c, b_c = params[-2], params[-1]
         m = pts.shape[0]
         h = blocks[0][2].shape[0]
+        ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
+        if _fused_trunk_applicable(pts, params, n_blocks):
+            out, cats, hrs, winners = _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
+            ctx.save_for_backward(pts, *params, *cats, *hrs, *winners)
+            return out
         cats, hrs, winners = [], [], []
         cat0 = _empty(m, w_pos.shape[0], pts)
         linear_fwd_(pts, w_pos, b_pos, cat0)                                   # pointnet.py:72
@@ -334,7 +390,6 @@ class _PointTrunk(torch.autograd.Function):
             cats.append(nxt)
         out = _empty(m, w_c.shape[0], pts)
         linear_fwd_(cats[-1], w_c, b_c, out, relu_in=True)                          # pointnet.py:81-82
-        ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
         ctx.save_for_backward(pts, *params, *cats, *hrs, *winners)
         return out
 
