@@ -304,6 +304,24 @@ int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const flo
                         float *x_full, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
                         t2h_stream_t stream);
 
+/* Backward of t2h_trunk_block_fwd, one launch per block (+ one small reduction):
+ *     g   = g_net + route(sum over each row's cell of g_pool)     (g_pool != NULL: the backward of the pooling that
+ *                                                                  consumed this block's output: gather -> scatter-add,
+ *                                                                  scatter_max -> the arg-max row, pointnet.py:95-98)
+ *           (gc != NULL, last block: g = (gc wc) * (out_last > 0), and dWc / dbc of fc_c, pointnet.py:81-82)
+ *     dhr = (g w1) * (hr > 0);   dX = g ws + (dhr w0) * (X > 0)  -> dx [M, 64] = [d net_prev | d pooled_prev]
+ *     slabs of dW0, dWs, dW1, db0, db1 (and dWc, dbc / dWpos, dbpos) per workgroup in `workspace`
+ * pts != NULL (first block): X is recomputed from the points, dx is not written, fc_pos's gradients are produced.
+ * t2h_trunk_block_reduce adds the slabs in a fixed order into the gradients ([dst +=] when accumulate != 0). */
+size_t t2h_trunk_block_bwd_workspace_bytes(int64_t M);
+int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_pool, int ld_gp, const uint8_t *winner,
+                        const int32_t *cell, const int32_t *off0, const float *gc, const float *wc,
+                        const float *out_last, const float *hr, const float *x_full, const float *pts, int dim,
+                        const float *w_pos, const float *b_pos, const float *w0, const float *w1, const float *ws,
+                        int64_t M, float *dx, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+int t2h_trunk_block_reduce(const void *workspace, int64_t M, int first, int last, float *dw0, float *db0, float *dw1,
+                           float *db1, float *dws, float *dwx, float *dbx, int accumulate, t2h_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * AdamW step over all parameters in one launch                       train.py:97, trainer.py:78-79
  * (torch.optim.AdamW arithmetic: decoupled weight decay, bias corrections in double on the host, amsgrad off).

@@ -50,7 +50,8 @@ def test_fused_forward_vs_unfused_and_pool_exact(name):
     params = [p.detach() for p in _params(enc)]
     nb = len(enc.blocks)
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
-    c, cats, hrs, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+    c, cats, hrs, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1],
+                                                     materialise_x0=True)
     # (1) the pooling inside the loader == t2h_pool_max_fwd on the same block output: values and arg-max bits exact
     for i in range(1, nb):
         net = cats[i][:, :32].contiguous()
@@ -148,3 +149,49 @@ def test_resblock_golden(tag):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"gx_{tag}"], rtol=1e-4, atol=1e-6)
     for n, w in zip(names, ws):
         np.testing.assert_allclose(w.grad.cpu().numpy(), g[f"g_{tag}.{n}"], rtol=1e-4, atol=2e-6, err_msg=n)
+
+
+@pytest.mark.parametrize("name", ["ragged", "one_cell", "ties", "tiny", "big"])
+def test_fused_backward_vs_float64_with_the_same_masks(name):
+    """Every gradient of the fused backward against float64 arithmetic that uses the SAME ReLU masks and arg-max bits (so
+    no mask can flip): isolates the kernel's own arithmetic -- GEMMs, the pooling backward folded into the loader, the
+    slab reduction, the fc_pos / fc_c ends -- at 1e-5."""
+    from tomosar2height_amd import mlp
+    from tomosar2height_amd.tile import TileIndex
+    enc = _trunk_modules(seed=21)
+    cloud = _clouds()[name].to(_dev())
+    tile = TileIndex(cloud, 256)
+    params = [p.detach() for p in _params(enc)]
+    nb = len(enc.blocks)
+    blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
+    c, cats, hrs, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1],
+                                                     materialise_x0=True)
+    g_out = torch.randn(c.shape, generator=torch.Generator().manual_seed(5)).to(_dev())
+    got = mlp._trunk_backward_fused(tile, tile.pts, params, cats, hrs, winners, g_out)
+    assert all(g is not None for g in got)
+
+    d = torch.float64
+    w = [p.to(d) for p in params]
+    want = [None] * len(params)
+    go = g_out.to(d)
+    out_last = cats[-1].to(d)
+    want[-2], want[-1] = go.t() @ torch.relu(out_last), go.sum(0)
+    g = (go @ w[-2]) * (out_last > 0)
+    cell = tile.cell.long()
+    uniq, inv = torch.unique_consecutive(cell, return_inverse=True)
+    for i in range(nb - 1, -1, -1):
+        w0, b0, w1, b1, ws = w[2 + 5 * i: 7 + 5 * i]
+        x, hr = cats[i].to(d), hrs[i].to(d)
+        dhr = (g @ w1) * (hr > 0)
+        want[2 + 5 * i: 7 + 5 * i] = [dhr.t() @ torch.relu(x), dhr.sum(0), g.t() @ hr, g.sum(0), g.t() @ x]
+        dx = g @ ws + (dhr @ w0) * (x > 0)
+        if i > 0:
+            sums = torch.zeros(len(uniq), 32, dtype=d, device=dx.device).index_add_(0, inv, dx[:, 32:])
+            bits = winners[i - 1]
+            mask = torch.stack([(bits[:, ch // 4] >> (ch % 4)) & 1 for ch in range(32)], 1).to(d)
+            g = dx[:, :32] + mask * sums[inv]
+        else:
+            want[0], want[1] = dx.t() @ tile.pts.to(d), dx.sum(0)
+    for k, (a, b) in enumerate(zip(got, want)):
+        scale = b.abs().max().item() + 1e-30
+        assert (a.to(d) - b).abs().max().item() <= 1e-5 * scale, f"param {k}: {(a.to(d) - b).abs().max().item() / scale:.2e}"

@@ -305,6 +305,393 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     }
 }
 
+
+// =====================================================================================================================
+// Backward of one block (resnet.py:36-54 + the gather / scatter_max backward of pointnet.py:92-99), one launch:
+//
+//     g    = g_net + route(sum over the cell of g_pool)       (the pooling's backward, folded into this loader;
+//                                                               last block: g = (gc Wc) * (out > 0), the fc_c backward)
+//     dhr  = (g W1) * (hr > 0)
+//     dX   = g Ws + (dhr W0) * (X > 0)                        -> [d net_prev | d pooled_prev]  (first block: fc_pos wgrad)
+//     dW1 += g^T hr, dW0 += dhr^T relu(X), dWs += g^T X, db1 += colsum g, db0 += colsum dhr
+//
+// Everything a weight gradient or a ReLU mask needs is held in the MFMA C/D register layout (lane = column, registers =
+// rows): hr, X and out are loaded from global memory straight into that layout (each load instruction reads two 128-byte
+// row segments), dhr leaves its MFMA in it, and the reduction index of a weight gradient (the row) may be enumerated in
+// any order as long as both operands agree -- so those products need no LDS at all.  LDS holds only what the two data
+// gradients read row-wise (g and dhr, 128 x 32 each) and the transposed weights (23 KB): 60 KB, two workgroups per CU.
+// A workgroup walks `tiles_per_wg` consecutive tiles with the weight-gradient accumulators in registers, then writes one
+// slab; t2h_reduce_segments adds the slabs in a fixed order (deterministic, no atomics).
+struct TrunkBwdArgs {
+    const float *g_net; int ld_gn;
+    const float *g_pool; int ld_gp; const uint8_t *winner; const int32_t *cell, *off0;
+    const float *gc, *wc, *out_last;                                        // last block
+    const float *hr, *x_full;
+    const float *pts; int dim; const float *wpos, *bpos;                    // first block
+    const float *w0, *w1, *ws;
+    int M, tiles_per_wg;
+    float *dx;                                                              // [M, 64] (not for the first block)
+    float *slab; int slab_floats;
+};
+
+// slab layout (floats): dW0 [32][64] | dWs [32][64] | dW1 [32][32] | db0 [32] | db1 [32] | LAST: dWc [32][32] | dbc [32]
+//                                                                              | FIRST: dWpos [64][3] | dbpos [64]
+constexpr int SL_W0 = 0, SL_WS = 2048, SL_W1 = 4096, SL_B0 = 5120, SL_B1 = 5152, SL_X = 5184;
+
+// the tile's g rows -> Gs (row-major, stride HS): g_net + (winner bit ? sum over the row's cell of g_pool : 0)
+__device__ inline void load_g_tile(const TrunkBwdArgs &a, float *Gs, float *scratch, int r0, int r1, int tid) {
+    const int lane = tid & (G - 1), grp = tid >> 3;
+    if (!a.g_pool) {
+#pragma unroll
+        for (int p = 0; p < TR / NG; ++p) {
+            const int row = r0 + p * NG + grp;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r1) v = *reinterpret_cast<const float4 *>(a.g_net + (size_t)row * a.ld_gn + lane * 4);
+            *reinterpret_cast<float4 *>(Gs + (p * NG + grp) * HS + lane * 4) = v;
+        }
+        __syncthreads();
+        return;
+    }
+    float4 *val = reinterpret_cast<float4 *>(scratch);                      // [TR * G]: g_pool rows, then cell sums at head rows
+    float4 *pval = reinterpret_cast<float4 *>(Gs);                          // [NG * G]   (Gs is written last)
+    float4 *oval = reinterpret_cast<float4 *>(Gs + 4 * NG * G);             // [2 * G]
+    int *bounds = reinterpret_cast<int *>(Gs + 4 * NG * G + 8 * G);         // [4]
+    int segs[TR / NG], sege[TR / NG];
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int row = r0 + p * NG + grp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        segs[p] = sege[p] = -1;
+        if (row < r1) {
+            const int cid = a.cell[row];
+            segs[p] = a.off0[cid]; sege[p] = a.off0[cid + 1];
+            v = *reinterpret_cast<const float4 *>(a.g_pool + (size_t)row * a.ld_gp + lane * 4);
+        }
+        val[(p * NG + grp) * G + lane] = v;
+    }
+    if (tid == 0) {
+        const int ch = a.cell[r0], ct = a.cell[r1 - 1];
+        bounds[0] = a.off0[ch]; bounds[1] = a.off0[ch + 1]; bounds[2] = a.off0[ct]; bounds[3] = a.off0[ct + 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int lo = side == 0 ? bounds[0] : r1, hi = side == 0 ? r0 : bounds[3];
+        if (hi <= lo) continue;                                             // uniform over the workgroup
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = lo + grp; n < hi; n += NG) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.g_pool + (size_t)n * a.ld_gp + lane * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        pval[grp * G + lane] = acc;
+        __syncthreads();
+        if (grp == 0) {
+            float4 t = pval[lane];
+            for (int g = 1; g < NG; ++g) { const float4 v = pval[g * G + lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            oval[side * G + lane] = t;
+        }
+        __syncthreads();
+    }
+    float4 headsum[TR / NG];
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int row = r0 + p * NG + grp;
+        headsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row >= r1 || row != max(segs[p], r0)) continue;
+        float4 acc = segs[p] < r0 ? oval[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int end = min(sege[p], r1);
+        for (int n = row; n < end; ++n) { const float4 v = val[(n - r0) * G + lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        if (sege[p] > r1) { const float4 v = oval[G + lane]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        headsum[p] = acc;
+    }
+    __syncthreads();                                                        // every head has read its rows: now overwrite
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int row = r0 + p * NG + grp;
+        if (row < r1 && row == max(segs[p], r0)) val[(row - r0) * G + lane] = headsum[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int row = r0 + p * NG + grp;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < r1) {
+            const float4 sum = val[(max(segs[p], r0) - r0) * G + lane];
+            const uint8_t bits = a.winner[(size_t)row * G + lane];
+            const float4 gn = *reinterpret_cast<const float4 *>(a.g_net + (size_t)row * a.ld_gn + lane * 4);
+            o = make_float4(gn.x + ((bits & 1) ? sum.x : 0.f), gn.y + ((bits & 2) ? sum.y : 0.f),
+                            gn.z + ((bits & 4) ? sum.z : 0.f), gn.w + ((bits & 8) ? sum.w : 0.f));
+        }
+        *reinterpret_cast<float4 *>(Gs + (p * NG + grp) * HS + lane * 4) = o;
+    }
+    __syncthreads();
+}
+
+// weight gradient tile: acc[n][k] += sum over the 32 rows of a[row][n] * b[row][k], operands in the C/D register layout
+__device__ inline void mfma_outer(const float (&av)[16], const float (&bv)[16], f32x16 &acc) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float Gs[TR * HS];
+    __shared__ __attribute__((aligned(16))) float Ds[TR * HS];
+    __shared__ __attribute__((aligned(16))) float W1t[32 * HS];              // [k][n] = W1[n][k]
+    __shared__ __attribute__((aligned(16))) float W0t[64 * HS];              // [k][n] = W0[n][k]
+    __shared__ __attribute__((aligned(16))) float Wst[64 * HS];
+    __shared__ __attribute__((aligned(16))) float Wct[LAST ? 32 * HS : 4];
+    __shared__ float Pts[FIRST ? TR * 3 + 256 : 4];                          // tile points, then Wpos [64][3] + bpos [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- transposed weights -> LDS
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int idx = tid + f * 256, n = idx >> 4, k4 = (idx & 15) * 4;    // W [32][64]: n row, 4 consecutive k
+        const float4 v0 = *reinterpret_cast<const float4 *>(a.w0 + n * 64 + k4);
+        const float4 vs = *reinterpret_cast<const float4 *>(a.ws + n * 64 + k4);
+        W0t[(k4 + 0) * HS + n] = v0.x; W0t[(k4 + 1) * HS + n] = v0.y; W0t[(k4 + 2) * HS + n] = v0.z; W0t[(k4 + 3) * HS + n] = v0.w;
+        Wst[(k4 + 0) * HS + n] = vs.x; Wst[(k4 + 1) * HS + n] = vs.y; Wst[(k4 + 2) * HS + n] = vs.z; Wst[(k4 + 3) * HS + n] = vs.w;
+    }
+    {
+        const int n = tid >> 3, k4 = (tid & 7) * 4;
+        const float4 v1 = *reinterpret_cast<const float4 *>(a.w1 + n * 32 + k4);
+        W1t[(k4 + 0) * HS + n] = v1.x; W1t[(k4 + 1) * HS + n] = v1.y; W1t[(k4 + 2) * HS + n] = v1.z; W1t[(k4 + 3) * HS + n] = v1.w;
+        if (LAST) {
+            const float4 vc = *reinterpret_cast<const float4 *>(a.wc + n * 32 + k4);
+            Wct[(k4 + 0) * HS + n] = vc.x; Wct[(k4 + 1) * HS + n] = vc.y; Wct[(k4 + 2) * HS + n] = vc.z; Wct[(k4 + 3) * HS + n] = vc.w;
+        }
+    }
+    if (FIRST) {
+        if (tid < 192) Pts[TR * 3 + tid] = a.wpos[tid];
+        if (tid < 64) Pts[TR * 3 + 192 + tid] = a.bpos[tid];
+    }
+
+    f32x16 acc_w0[2], acc_ws[2], acc_w1, acc_wc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc_w0[0][q] = acc_w0[1][q] = acc_ws[0][q] = acc_ws[1][q] = acc_w1[q] = acc_wc[q] = 0.f; }
+    float db0 = 0.f, db1 = 0.f, dbc = 0.f;
+    float dwp[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, dbp[2] = {0.f, 0.f};
+
+    const int n_tiles = (a.M + TR - 1) / TR;
+    const int t_begin = blockIdx.x * a.tiles_per_wg, t_end = min(t_begin + a.tiles_per_wg, n_tiles);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int r0 = tile * TR, r1 = min(r0 + TR, a.M);
+        const int wrow0 = r0 + wave * 32;                                    // first global row of this wave
+        float g_cd[16];
+        // register q of the C/D layout holds row rb + ro(q), ro(q) = (q & 3) + 8 (q >> 2): one base, constant offsets
+        const int rb = wrow0 + 4 * h;
+#define T2H_RO(q) (((q) & 3) + 8 * ((q) >> 2))
+#define T2H_ROW_OK(q) (rb + T2H_RO(q) < r1)
+
+        // ---------------------------------------------------------------- g -> Gs (row-major) and g_cd (registers)
+        if constexpr (LAST) {
+#pragma unroll
+            for (int p = 0; p < TR / NG; ++p) {                              // gc tile -> Ds
+                const int row = r0 + p * NG + (tid >> 3);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < r1) v = *reinterpret_cast<const float4 *>(a.gc + (size_t)row * 32 + (tid & 7) * 4);
+                *reinterpret_cast<float4 *>(Ds + (p * NG + (tid >> 3)) * HS + (tid & 7) * 4) = v;
+            }
+            __syncthreads();
+            f32x16 acc_g;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc_g[q] = 0.f;
+            mfma_rows<32, false>(Ds + (wave * 32 + r) * HS + 4 * h, Wct + r * HS + 4 * h, acc_g);     // gc Wc
+            float gc_cd[16], o_cd[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                gc_cd[q] = Ds[(wave * 32 + acc_row(q, lane)) * HS + r];
+                o_cd[q] = T2H_ROW_OK(q) ? (a.out_last + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                g_cd[q] = o_cd[q] > 0.f ? acc_g[q] : 0.f;                    // through relu(net) of pointnet.py:81
+                dbc += gc_cd[q];
+                o_cd[q] = fmaxf(o_cd[q], 0.f);
+            }
+            mfma_outer(gc_cd, o_cd, acc_wc);                                 // dWc += gc^T relu(out)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) Gs[(wave * 32 + acc_row(q, lane)) * HS + r] = g_cd[q];
+            __syncthreads();
+        } else {
+            load_g_tile(a, Gs, Ds, r0, r1, tid);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) g_cd[q] = Gs[(wave * 32 + acc_row(q, lane)) * HS + r];
+        }
+
+        // ---------------------------------------------------------------- dhr = (g W1) * (hr > 0); dW1, db1, db0
+        float d_cd[16];
+        {
+            float hr_cd[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hr_cd[q] = T2H_ROW_OK(q) ? (a.hr + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
+            f32x16 acc_d;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc_d[q] = 0.f;
+            mfma_rows<32, false>(Gs + (wave * 32 + r) * HS + 4 * h, W1t + r * HS + 4 * h, acc_d);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                d_cd[q] = hr_cd[q] > 0.f ? acc_d[q] : 0.f;
+                db1 += g_cd[q];
+                db0 += d_cd[q];
+            }
+            mfma_outer(g_cd, hr_cd, acc_w1);                                 // dW1 += g^T hr   (hr is already relu'ed)
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ds[(wave * 32 + acc_row(q, lane)) * HS + r] = d_cd[q];      // own rows only
+
+        // ---------------------------------------------------------------- per 32-column half of X: dW0, dWs, dX
+        if constexpr (FIRST) {
+            for (int i = tid; i < TR * 3; i += 256) {                        // (the previous tile ended with a barrier)
+                const int row = r0 + i / 3;
+                Pts[i] = row < r1 ? a.pts[(size_t)row * a.dim + i % 3] : 0.f;
+            }
+        }
+        __syncthreads();                                                     // Ds rows (and Pts) are complete
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float x_cd[16];                                                  // X[row(q)][32 t + r], the C/D register layout
+            if constexpr (FIRST) {
+                // the tile's points are re-read from LDS at every use (broadcast reads): keeping them in registers across
+                // the MFMA phases costs 48 VGPRs and spills
+                asm volatile("" ::: "memory");
+                const float *wp = Pts + TR * 3;
+                const int n = 32 * t + r;
+                const float w_0 = wp[n * 3 + 0], w_1 = wp[n * 3 + 1], w_2 = wp[n * 3 + 2], b_n = wp[192 + n];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float *pp = Pts + (wave * 32 + acc_row(q, lane)) * 3;
+                    float acc = b_n;                                         // the forward's fc_pos arithmetic, bit for bit
+                    acc = fmaf(pp[0], w_0, acc);
+                    acc = fmaf(pp[1], w_1, acc);
+                    acc = fmaf(pp[2], w_2, acc);
+                    x_cd[q] = T2H_ROW_OK(q) ? acc : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) x_cd[q] = T2H_ROW_OK(q) ? (a.x_full + (size_t)rb * 64 + 32 * t + r)[T2H_RO(q) * 64] : 0.f;
+            }
+            {
+                float xr[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) xr[q] = fmaxf(x_cd[q], 0.f);
+                mfma_outer(d_cd, xr, acc_w0[t]);                             // dW0 += dhr^T relu(X)
+                mfma_outer(g_cd, x_cd, acc_ws[t]);                           // dWs += g^T X
+            }
+            // dX = (dhr W0) * (X > 0) + g Ws
+            f32x16 acc_x;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc_x[q] = 0.f;
+            mfma_rows<32, false>(Ds + (wave * 32 + r) * HS + 4 * h, W0t + (32 * t + r) * HS + 4 * h, acc_x);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc_x[q] = x_cd[q] > 0.f ? acc_x[q] : 0.f;
+            mfma_rows<32, false>(Gs + (wave * 32 + r) * HS + 4 * h, Wst + (32 * t + r) * HS + 4 * h, acc_x);
+            if constexpr (FIRST) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {                               // fc_pos: dWpos += dX^T pts, dbpos += colsum dX
+                    const float *pp = Pts + (wave * 32 + acc_row(q, lane)) * 3;
+                    const float v = T2H_ROW_OK(q) ? acc_x[q] : 0.f;
+                    dbp[t] += v;
+                    dwp[t][0] = fmaf(v, pp[0], dwp[t][0]);
+                    dwp[t][1] = fmaf(v, pp[1], dwp[t][1]);
+                    dwp[t][2] = fmaf(v, pp[2], dwp[t][2]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (T2H_ROW_OK(q)) (a.dx + (size_t)rb * 64 + 32 * t + r)[T2H_RO(q) * 64] = acc_x[q];
+            }
+        }
+        __syncthreads();                                                     // Gs / Ds free for the next tile
+#undef T2H_RO
+#undef T2H_ROW_OK
+    }
+
+    // ---- accumulators of the 4 waves -> one slab per workgroup, summed in wave order
+    float *slab = a.slab + (size_t)blockIdx.x * a.slab_floats;
+    float *scr = Gs;                                                         // Gs and Ds are adjacent: 2 * TR * HS floats
+    static_assert(2 * TR * HS >= 4 * 1024, "scratch too small");
+    auto flush = [&](const f32x16 &acc, float *dst, int ld, int col0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scr[wave * 1024 + acc_row(q, lane) * 32 + r] = acc[q];
+        __syncthreads();
+        const int e = tid * 4, n = e >> 5, k = e & 31;
+        float4 s0 = *reinterpret_cast<const float4 *>(scr + e);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 v = *reinterpret_cast<const float4 *>(scr + w * 1024 + e);
+            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dst + n * ld + col0 + k) = s0;
+        __syncthreads();
+    };
+    flush(acc_w0[0], slab + SL_W0, 64, 0);
+    flush(acc_w0[1], slab + SL_W0, 64, 32);
+    flush(acc_ws[0], slab + SL_WS, 64, 0);
+    flush(acc_ws[1], slab + SL_WS, 64, 32);
+    flush(acc_w1, slab + SL_W1, 32, 0);
+    if (LAST) flush(acc_wc, slab + SL_X, 32, 0);
+    // column sums: every lane holds the partial of column r over its rows; 8 partials (wave, h) per column
+    auto flush_col = [&](float v, float *dst) {
+        scr[(wave * 2 + h) * 32 + r] = v;
+        __syncthreads();
+        if (tid < 32) {
+            float t = scr[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) t += scr[j * 32 + tid];
+            dst[tid] = t;
+        }
+        __syncthreads();
+    };
+    flush_col(db0, slab + SL_B0);
+    flush_col(db1, slab + SL_B1);
+    if (LAST) flush_col(dbc, slab + SL_X + 1024);
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {                                    // dWpos [64][3]: column n = 32 t + r
+                scr[(wave * 2 + h) * 32 + r] = dwp[t][d];
+                __syncthreads();
+                if (tid < 32) {
+                    float v = scr[tid];
+#pragma unroll
+                    for (int j = 1; j < 8; ++j) v += scr[j * 32 + tid];
+                    slab[SL_X + (32 * t + tid) * 3 + d] = v;
+                }
+                __syncthreads();
+            }
+            flush_col(dbp[t], slab + SL_X + 192 + 32 * t);
+        }
+    }
+}
+
+// out[i] = [out[i] +] sum over slabs z (ascending) of src[z * stride + i], several independent segments per launch
+struct ReduceSeg { const float *src; float *dst; int n, accumulate; };
+constexpr int kMaxSegs = 48;
+struct ReduceArgs { ReduceSeg seg[kMaxSegs]; int n_segs, n_slabs; long long stride; };
+
+__global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceArgs a) {
+    const ReduceSeg sg = a.seg[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < sg.n; i += gridDim.x * 256) {
+        // four partial sums over interleaved slabs keep loads in flight; combined in a fixed order
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = 0;
+        for (; z + 3 < a.n_slabs; z += 4) {
+            s0 += sg.src[(size_t)z * a.stride + i];
+            s1 += sg.src[(size_t)(z + 1) * a.stride + i];
+            s2 += sg.src[(size_t)(z + 2) * a.stride + i];
+            s3 += sg.src[(size_t)(z + 3) * a.stride + i];
+        }
+        for (; z < a.n_slabs; ++z) s0 += sg.src[(size_t)z * a.stride + i];
+        const float t = (s0 + s1) + (s2 + s3);
+        sg.dst[i] = sg.accumulate ? sg.dst[i] + t : t;
+    }
+}
+
 }  // namespace
 }  // namespace t2h
 
@@ -341,4 +728,75 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     else hipLaunchKernelGGL((trunk_block_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
     note_kernel(first ? "trunk_block_fwd_kernel<true,false>" : (last ? "trunk_block_fwd_kernel<false,true>" : "trunk_block_fwd_kernel<false,false>"));
     return check_launch("trunk_block_fwd");
+}
+
+constexpr int kTrunkSlabFloats = 6240;      // 5184 shared + max(last: 1024 + 32, first: 192 + 64), multiple of 4
+static int trunk_bwd_tiles_per_wg(int64_t M) {
+    const int64_t n_tiles = (M + TR - 1) / TR;
+    int64_t t = (n_tiles + 511) / 512;       // <= 512 workgroups: two resident per CU, each keeps its weight-gradient
+    return (int)(t < 1 ? 1 : t);             // accumulators in registers over its tiles
+}
+static int trunk_bwd_slabs(int64_t M) {
+    const int64_t n_tiles = (M + TR - 1) / TR;
+    const int tpw = trunk_bwd_tiles_per_wg(M);
+    return (int)((n_tiles + tpw - 1) / tpw);
+}
+
+T2H_API size_t t2h_trunk_block_bwd_workspace_bytes(int64_t M) {
+    if (M < 1) return 0;
+    return (size_t)trunk_bwd_slabs(M) * kTrunkSlabFloats * sizeof(float);
+}
+
+T2H_API int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_pool, int ld_gp, const uint8_t *winner,
+                                const int32_t *cell, const int32_t *off0, const float *gc, const float *wc,
+                                const float *out_last, const float *hr, const float *x_full, const float *pts, int dim,
+                                const float *w_pos, const float *b_pos, const float *w0, const float *w1, const float *ws,
+                                int64_t M, float *dx, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    const bool first = pts != nullptr, last = gc != nullptr;
+    if (!hr || !w0 || !w1 || !ws || !workspace) return fail(T2H_ERR_ARG, "trunk_block_bwd: null pointer");
+    if (first && last) return fail(T2H_ERR_ARG, "trunk_block_bwd: a block is either the first or the last");
+    if (last ? (!wc || !out_last) : (!g_net || ld_gn < 32 || ld_gn % 4))
+        return fail(T2H_ERR_ARG, "trunk_block_bwd: bad output-gradient description");
+    if (g_pool && (last || !winner || !cell || !off0 || ld_gp < 32 || ld_gp % 4))
+        return fail(T2H_ERR_ARG, "trunk_block_bwd: bad pooled-gradient description");
+    if (first ? (!w_pos || !b_pos || dim < 3) : (!x_full || !dx)) return fail(T2H_ERR_ARG, "trunk_block_bwd: bad input description");
+    if (M < 0 || M >= ((int64_t)1 << 31) - TR) return fail(T2H_ERR_ARG, "trunk_block_bwd: bad shape");
+    if (!al16(w0) || !al16(w1) || !al16(ws) || !al16(hr) || (g_net && !al16(g_net)) || (g_pool && !al16(g_pool)) ||
+        (gc && (!al16(gc) || !al16(wc))) || !al16(workspace))
+        return fail(T2H_ERR_ARG, "trunk_block_bwd: pointers must be 16-byte aligned");
+    if (M == 0) return T2H_OK;
+    if (workspace_bytes < t2h_trunk_block_bwd_workspace_bytes(M))
+        return fail(T2H_ERR_WORKSPACE, "trunk_block_bwd: workspace %zu < %zu bytes", workspace_bytes, t2h_trunk_block_bwd_workspace_bytes(M));
+    TrunkBwdArgs a{};
+    a.g_net = g_net; a.ld_gn = ld_gn; a.g_pool = g_pool; a.ld_gp = ld_gp; a.winner = winner; a.cell = cell; a.off0 = off0;
+    a.gc = gc; a.wc = wc; a.out_last = out_last; a.hr = hr; a.x_full = x_full;
+    a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos; a.w0 = w0; a.w1 = w1; a.ws = ws;
+    a.M = (int)M; a.tiles_per_wg = trunk_bwd_tiles_per_wg(M); a.dx = dx;
+    a.slab = static_cast<float *>(workspace); a.slab_floats = kTrunkSlabFloats;
+    const dim3 grid((unsigned)trunk_bwd_slabs(M));
+    hipStream_t s = as_stream(stream);
+    if (first) hipLaunchKernelGGL((trunk_block_bwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (last) hipLaunchKernelGGL((trunk_block_bwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((trunk_block_bwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+    note_kernel(first ? "trunk_block_bwd_kernel<true,false>" : (last ? "trunk_block_bwd_kernel<false,true>" : "trunk_block_bwd_kernel<false,false>"));
+    return check_launch("trunk_block_bwd");
+}
+
+// Sum the per-workgroup slabs of t2h_trunk_block_bwd (ascending slab order) into the parameter gradients.
+// dwx / dbx: fc_c's (last block) or fc_pos's (first block) weight / bias gradient, or NULL for a middle block.
+T2H_API int t2h_trunk_block_reduce(const void *workspace, int64_t M, int first, int last, float *dw0, float *db0, float *dw1,
+                                   float *db1, float *dws, float *dwx, float *dbx, int accumulate, t2h_stream_t stream) {
+    if (!workspace || !dw0 || !db0 || !dw1 || !db1 || !dws) return fail(T2H_ERR_ARG, "trunk_block_reduce: null pointer");
+    if ((first || last) && (!dwx || !dbx)) return fail(T2H_ERR_ARG, "trunk_block_reduce: missing fc_pos / fc_c gradient");
+    if (M < 1) return fail(T2H_ERR_ARG, "trunk_block_reduce: bad shape");
+    const float *base = static_cast<const float *>(workspace);
+    ReduceArgs r{};
+    int n = 0;
+    auto add = [&](int off, float *dst, int len) { r.seg[n].src = base + off; r.seg[n].dst = dst; r.seg[n].n = len; r.seg[n].accumulate = accumulate; ++n; };
+    add(SL_W0, dw0, 2048); add(SL_WS, dws, 2048); add(SL_W1, dw1, 1024); add(SL_B0, db0, 32); add(SL_B1, db1, 32);
+    if (last) { add(SL_X, dwx, 1024); add(SL_X + 1024, dbx, 32); }
+    if (first) { add(SL_X, dwx, 192); add(SL_X + 192, dbx, 64); }
+    r.n_segs = n; r.n_slabs = trunk_bwd_slabs(M); r.stride = kTrunkSlabFloats;
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(8, n), dim3(256), 0, as_stream(stream), r);
+    return check_launch("trunk_block_reduce");
 }

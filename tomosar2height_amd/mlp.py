@@ -320,7 +320,7 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
-def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_x=True):
+def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_x=True, materialise_x0=False):
     """pointnet.py:72-82 as one launch per block: (cats, hrs, winners) in the layout the backward expects -- cats[i] is
     block i's [M, 64] input (= [net | pooled]; cats[0] = fc_pos output), cats[-1] the last block's [M, 32] output."""
     m, nb, dev = pts.shape[0], len(blocks), pts.device
@@ -328,14 +328,14 @@ def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_
     net_prev, c_out = None, None
     for i, (w0, b0, w1, b1, ws) in enumerate(blocks):
         first, last = i == 0, i == nb - 1
-        x_full = _empty(m, 64, pts) if materialise_x else None
+        x_full = _empty(m, 64, pts) if (materialise_x and (not first or materialise_x0)) else None
         hr, out = _empty(m, 32, pts), _empty(m, 32, pts)
         win = None if first else torch.empty(m, 8, dtype=torch.uint8, device=dev)
         if last:
             c_out = _empty(m, 32, pts)
         wts = [t.contiguous() for t in (w0, b0, w1, b1, ws)]
         nbytes = m * ((4 * pts.shape[1] if first else 4 * 32 + 4) + 2 * 128 + (0 if first else 8) + (128 if last else 0)
-                      + (256 if materialise_x else 0))
+                      + (256 if x_full is not None else 0))
         flops = 2 * m * (2 * 64 * 32 + 32 * 32 + (32 * 32 if last else 0) + (3 * 64 if first else 0))
         _lib.call("t2h_trunk_block_fwd",
                   _lib.ptr(pts) if first else None, pts.shape[1], _lib.ptr(w_pos.contiguous()) if first else None,
@@ -353,6 +353,56 @@ def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_
         net_prev = out
     cats.append(net_prev)
     return c_out, cats, hrs, winners
+
+
+def _trunk_backward_fused(tile, pts, params, cats, hrs, winners, g_out):
+    """Backward of ``_trunk_forward_fused``: one t2h_trunk_block_bwd + one slab reduction per block, last block first.
+    Block i's kernel folds the backward of the pooling that consumed its output (gather -> scatter-add over the cell,
+    scatter_max -> its arg-max row, pointnet.py:95-98) into its loader, the last block's the backward of
+    ``fc_c(relu(.))``, the first block's the fc_pos weight gradient.  Returns the gradients in ``params`` order
+    (``None`` where they were accumulated straight into ``param.grad``)."""
+    lib = _lib.load()
+    nb = (len(params) - 4) // 5
+    m = pts.shape[0]
+    w_pos, b_pos, w_c, b_c = params[0], params[1], params[-2], params[-1]
+    direct = _DIRECT_ACCUM and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+    grads = [None] * len(params)
+    ws_bytes = lib.t2h_trunk_block_bwd_workspace_bytes(m)
+    ws = _lib.workspace(ws_bytes, pts.device)            # reused by every block: launches are stream ordered
+    dx_next = None
+    for i in range(nb - 1, -1, -1):
+        first, last = i == 0, i == nb - 1
+        w0, b0, w1, b1, wsc = params[2 + 5 * i: 7 + 5 * i]
+        dx = None if first else _empty(m, 64, pts)
+        nbytes = m * ((128 if last else 256 + 8 + 4) + 128 + (4 * pts.shape[1] if first else 256) + (128 if last else 0)
+                      + (0 if first else 256))
+        flops = 2 * m * (2 * 32 * 32 + 4 * 64 * 32 + (2 * 32 * 32 if last else 0))
+        _lib.call("t2h_trunk_block_bwd",
+                  None if last else _lib.ptr(dx_next), 64, None if last else _lib.ptr(dx_next) + 128, 64,
+                  None if last else _lib.ptr(winners[i]), _lib.ptr(tile.cell), _lib.ptr(tile.off0),
+                  _lib.ptr(g_out) if last else None, _lib.ptr(w_c.contiguous()) if last else None,
+                  _lib.ptr(cats[-1]) if last else None, _lib.ptr(hrs[i]), None if first else _lib.ptr(cats[i]),
+                  _lib.ptr(pts) if first else None, pts.shape[1], _lib.ptr(w_pos.contiguous()) if first else None,
+                  _lib.ptr(b_pos) if first else None, _lib.ptr(w0.contiguous()), _lib.ptr(w1.contiguous()),
+                  _lib.ptr(wsc.contiguous()), m, None if dx is None else _lib.ptr(dx), _lib.ptr(ws), ws_bytes, _lib.stream(),
+                  nbytes=nbytes, flops=flops, tag="t2h_trunk_block_bwd")
+        extra = (w_pos, b_pos) if first else ((w_c, b_c) if last else None)
+        if direct:
+            dst = [w0.grad, b0.grad, w1.grad, b1.grad, wsc.grad] + ([extra[0].grad, extra[1].grad] if extra else [None, None])
+        else:
+            dst = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in (w0, b0, w1, b1, wsc)]
+            dst += [torch.empty_like(t, memory_format=torch.contiguous_format) for t in extra] if extra else [None, None]
+            grads[2 + 5 * i: 7 + 5 * i] = dst[:5]
+            if first:
+                grads[0], grads[1] = dst[5], dst[6]
+            if last:
+                grads[-2], grads[-1] = dst[5], dst[6]
+        _lib.call("t2h_trunk_block_reduce", _lib.ptr(ws), m, int(first), int(last), _lib.ptr(dst[0]), _lib.ptr(dst[1]),
+                  _lib.ptr(dst[2]), _lib.ptr(dst[3]), _lib.ptr(dst[4]), None if dst[5] is None else _lib.ptr(dst[5]),
+                  None if dst[6] is None else _lib.ptr(dst[6]), 1 if direct else 0, _lib.stream(),
+                  nbytes=ws_bytes, tag="t2h_trunk_block_reduce")
+        dx_next = dx
+    return grads
 
 
 class _PointTrunk(torch.autograd.Function):
@@ -373,8 +423,11 @@ class _PointTrunk(torch.autograd.Function):
         ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
         if _fused_trunk_applicable(pts, params, n_blocks):
             out, cats, hrs, winners = _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
+            ctx.fused = True
+            cats[0] = pts.new_empty(0)                     # block 0's input is recomputed from the points in the backward
             ctx.save_for_backward(pts, *params, *cats, *hrs, *winners)
             return out
+        ctx.fused = False
         cats, hrs, winners = [], [], []
         cat0 = _empty(m, w_pos.shape[0], pts)
         linear_fwd_(pts, w_pos, b_pos, cat0)                                   # pointnet.py:72
@@ -408,6 +461,8 @@ class _PointTrunk(torch.autograd.Function):
         w_c, b_c = params[-2], params[-1]
 
         g_out = g_out.contiguous()
+        if ctx.fused:
+            return (None, None, *_trunk_backward_fused(tile, pts, params, cats, hrs, winners, g_out))
         dw_c, db_c = _wgrad(g_out, cats[-1], w_c, b_c, relu_in=True)
         g = linear_dgrad_(g_out, w_c, torch.empty_like(cats[-1]), mask=cats[-1])     # grad of the last block output
         grads = [None] * n_params
