@@ -296,12 +296,12 @@ int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_strea
  * scatter_max + gather + torch.cat (pointnet.py:76-78) run inside the block's loader: the pooled half of X is never
  * written to memory.  winner [M, 8] receives the arg-max bits of net_prev's pooling (bit j of byte l: the row holds the
  * first maximum of its cell for channel 4l + j -- torch_scatter's CPU tie-break), as t2h_pool_max_fwd would.
- * x_full (optional, [M, 64]): the block input X materialised (tests; the unfused backward).
+ * pooled (optional, [M, 32]): the pooled half of X, which the backward reads; x_full (optional, [M, 64]): all of X (tests).
  * w0, ws [32, 64]; w1, wc [32, 32]; w_pos [64, 3]: nn.Linear layouts.  cell / off0: from t2h_tile_build. */
 int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *net_prev,
                         int ld_prev, const int32_t *cell, const int32_t *off0, const float *w0, const float *b0,
                         const float *w1, const float *b1, const float *ws, const float *wc, const float *bc, int64_t M,
-                        float *x_full, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
+                        float *x_full, float *pooled, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
                         t2h_stream_t stream);
 
 /* Backward of t2h_trunk_block_fwd, one launch per block (+ one small reduction):
@@ -311,14 +311,16 @@ int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const flo
  *           (gc != NULL, last block: g = (gc wc) * (out_last > 0), and dWc / dbc of fc_c, pointnet.py:81-82)
  *     dhr = (g w1) * (hr > 0);   dX = g ws + (dhr w0) * (X > 0)  -> dx [M, 64] = [d net_prev | d pooled_prev]
  *     slabs of dW0, dWs, dW1, db0, db1 (and dWc, dbc / dWpos, dbpos) per workgroup in `workspace`
+ * X = [x_left | x_right] (row strides ld_xl, ld_xr): the previous block's output and the pooled half the forward kept.
  * pts != NULL (first block): X is recomputed from the points, dx is not written, fc_pos's gradients are produced.
  * t2h_trunk_block_reduce adds the slabs in a fixed order into the gradients ([dst +=] when accumulate != 0). */
 size_t t2h_trunk_block_bwd_workspace_bytes(int64_t M);
 int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_pool, int ld_gp, const uint8_t *winner,
                         const int32_t *cell, const int32_t *off0, const float *gc, const float *wc,
-                        const float *out_last, const float *hr, const float *x_full, const float *pts, int dim,
-                        const float *w_pos, const float *b_pos, const float *w0, const float *w1, const float *ws,
-                        int64_t M, float *dx, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+                        const float *out_last, const float *hr, const float *x_left, int ld_xl, const float *x_right,
+                        int ld_xr, const float *pts, int dim, const float *w_pos, const float *b_pos, const float *w0,
+                        const float *w1, const float *ws, int64_t M, float *dx, void *workspace, size_t workspace_bytes,
+                        t2h_stream_t stream);
 int t2h_trunk_block_reduce(const void *workspace, int64_t M, int first, int last, float *dw0, float *db0, float *dw1,
                            float *db1, float *dws, float *dwx, float *dbx, int accumulate, t2h_stream_t stream);
 

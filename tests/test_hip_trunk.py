@@ -50,16 +50,17 @@ def test_fused_forward_vs_unfused_and_pool_exact(name):
     params = [p.detach() for p in _params(enc)]
     nb = len(enc.blocks)
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
-    c, cats, hrs, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1],
-                                                     materialise_x0=True)
+    c, nets, pooled_f, hrs, winners, cats = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2],
+                                                                     params[-1], want_x_full=True)
     # (1) the pooling inside the loader == t2h_pool_max_fwd on the same block output: values and arg-max bits exact
     for i in range(1, nb):
-        net = cats[i][:, :32].contiguous()
+        net = nets[i - 1]
         assert torch.equal(net, cats[i][:, :32])
         pooled = torch.empty_like(net)
         win = torch.empty(net.shape[0], 8, dtype=torch.uint8, device=net.device)
         mlp._pool_fwd_(tile, net, pooled, win)
         assert torch.equal(pooled, cats[i][:, 32:]), f"pooled half of block {i}"
+        assert torch.equal(pooled, pooled_f[i]), f"kept pooled half of block {i}"
         assert torch.equal(win, winners[i - 1]), f"winner bits of block {i}"
     # (2) the GEMM side against the unfused path (different k order inside the MFMA chain: fp32 rounding only)
     old = mlp.FUSED_TRUNK
@@ -81,7 +82,7 @@ def test_fused_forward_vs_unfused_and_pool_exact(name):
         hr = torch.relu(torch.relu(xi) @ w0.t() + b0)
         out = xi @ ws.t() + hr @ w1.t() + b1
         np.testing.assert_allclose(hrs[i].cpu().numpy(), hr.cpu().numpy(), rtol=0, atol=2e-6 * (hr.abs().max().item() + 1))
-        got = cats[i + 1][:, :32] if i + 1 < nb else cats[-1]
+        got = nets[i]
         np.testing.assert_allclose(got.cpu().numpy(), out.cpu().numpy(), rtol=0, atol=2e-6 * (out.abs().max().item() + 1))
 
 
@@ -95,12 +96,12 @@ def test_fused_pool_matches_c_oracle_scatter_max():
     tile = TileIndex(cloud, 256)
     params = [p.detach() for p in _params(enc)]
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(len(enc.blocks))]
-    _, cats, _, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
-    net = cats[1][:, :32].cpu()                                   # sorted rows; the sort is stable inside a cell
+    _, nets, pooled_f, _, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+    net = nets[0].cpu()                                           # sorted rows; the sort is stable inside a cell
     idx = tile.cell.cpu().long()
     out, arg = scatter_ref.scatter_max(net.t()[None], idx[None, None], dim=-1, dim_size=256 * 256)
     want = out[0].t()[idx]                                        # gather back to the points (pointnet.py:98)
-    assert torch.equal(cats[1][:, 32:].cpu(), want)
+    assert torch.equal(pooled_f[1].cpu(), want)
     rows = torch.arange(net.shape[0])
     is_win = (arg[0].t()[idx] == rows[:, None])                   # [M, 32] bool
     bits = winners[0].cpu()
@@ -164,17 +165,17 @@ def test_fused_backward_vs_float64_with_the_same_masks(name):
     params = [p.detach() for p in _params(enc)]
     nb = len(enc.blocks)
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
-    c, cats, hrs, winners = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1],
-                                                     materialise_x0=True)
+    c, nets, pooled_f, hrs, winners, cats = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2],
+                                                                     params[-1], want_x_full=True)
     g_out = torch.randn(c.shape, generator=torch.Generator().manual_seed(5)).to(_dev())
-    got = mlp._trunk_backward_fused(tile, tile.pts, params, cats, hrs, winners, g_out)
+    got = mlp._trunk_backward_fused(tile, tile.pts, params, nets, pooled_f, hrs, winners, g_out)
     assert all(g is not None for g in got)
 
     d = torch.float64
     w = [p.to(d) for p in params]
     want = [None] * len(params)
     go = g_out.to(d)
-    out_last = cats[-1].to(d)
+    out_last = nets[-1].to(d)
     want[-2], want[-1] = go.t() @ torch.relu(out_last), go.sum(0)
     g = (go @ w[-2]) * (out_last > 0)
     cell = tile.cell.long()

@@ -72,10 +72,10 @@ SIGNATURES = {
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),
     "t2h_tile_crop_normalise": (_i, [_vp, _i64] + [ctypes.c_double] * 7 + [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "t2h_tile_crop_finish": (_i, [_vp, _vp]),
-    "t2h_trunk_block_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp] + [_vp] * 7 + [_i64, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "t2h_trunk_block_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp] + [_vp] * 7 + [_i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "t2h_trunk_block_bwd_workspace_bytes": (_sz, [_i64]),
-    "t2h_trunk_block_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
-                                 _i64, _vp, _vp, _sz, _vp]),
+    "t2h_trunk_block_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
+                                 _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "t2h_trunk_block_reduce": (_i, [_vp, _i64, _i, _i] + [_vp] * 7 + [_i, _vp]),
     "t2h_adamw_chunk_elems": (_i, []),
     "t2h_adamw_flat_step": (_i, [_vp, _vp, _i] + [ctypes.c_double] * 5 + [_i64, _i, _vp]),

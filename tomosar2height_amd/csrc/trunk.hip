@@ -40,7 +40,8 @@ struct TrunkFwdArgs {
     const float *net_prev; int ld_prev; const int32_t *cell, *off0;       // later blocks
     const float *w0, *b0, *w1, *b1, *ws, *wc, *bc;
     int M;
-    float *x_full;       // optional [M, 64]: the block input materialised (tests / unfused backward)
+    float *x_full;       // optional [M, 64]: the block input materialised (tests)
+    float *pooled;       // optional [M, 32]: the pooled half of the input (what the backward reads), later blocks
     float *hr;           // [M, 32]
     float *out; int ld_out;
     uint8_t *winner;     // [M, 8]: arg-max bits of net_prev's pooling (later blocks)
@@ -126,7 +127,14 @@ __device__ inline void pool_into_tile(const TrunkFwdArgs &a, float *Xs, float *s
             b.a = make_int4(ar.x < 0 ? -1 : -2, ar.y < 0 ? -1 : -2, ar.z < 0 ? -1 : -2, ar.w < 0 ? -1 : -2);
         }
         const int end = min(sege[p], r1);
-        for (int n = row; n < end; ++n)
+        int n = row;
+        for (; n + 3 < end; n += 4) {                                     // four LDS rows in flight
+            const float *xp = Xs + (n - r0) * XS + lane * 4;
+            const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + XS);
+            const float4 v2 = *reinterpret_cast<const float4 *>(xp + 2 * XS), v3 = *reinterpret_cast<const float4 *>(xp + 3 * XS);
+            best_strict(b, v0, n - r0); best_strict(b, v1, n + 1 - r0); best_strict(b, v2, n + 2 - r0); best_strict(b, v3, n + 3 - r0);
+        }
+        for (; n < end; ++n)
             best_strict(b, *reinterpret_cast<const float4 *>(Xs + (n - r0) * XS + lane * 4), n - r0);
         if (sege[p] > r1) {                                               // later rows: only a larger value wins
             const float4 v = oval[G + lane];
@@ -258,6 +266,14 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     } else {
         pool_into_tile(a, Xs, Hsm, r0, r1, tid);
     }
+    if (!FIRST && a.pooled) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int idx = tid + f * 256, row = idx >> 3, c = (idx & 7) * 4;
+            if (r0 + row < r1)
+                *reinterpret_cast<float4 *>(a.pooled + (size_t)(r0 + row) * 32 + c) = *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
+        }
+    }
     if (a.x_full) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
@@ -326,7 +342,7 @@ struct TrunkBwdArgs {
     const float *g_net; int ld_gn;
     const float *g_pool; int ld_gp; const uint8_t *winner; const int32_t *cell, *off0;
     const float *gc, *wc, *out_last;                                        // last block
-    const float *hr, *x_full;
+    const float *hr, *x_left, *x_right; int ld_xl, ld_xr;                     // X = [x_left | x_right], 32 columns each
     const float *pts; int dim; const float *wpos, *bpos;                    // first block
     const float *w0, *w1, *ws;
     int M, tiles_per_wg;
@@ -484,6 +500,10 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
         const int rb = wrow0 + 4 * h;
 #define T2H_RO(q) (((q) & 3) + 8 * ((q) >> 2))
 #define T2H_ROW_OK(q) (rb + T2H_RO(q) < r1)
+        // hr in the C/D layout, requested before the g stage: its barriers keep the compiler from hoisting the loads itself
+        float hr_cd[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hr_cd[q] = T2H_ROW_OK(q) ? (a.hr + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
 
         // ---------------------------------------------------------------- g -> Gs (row-major) and g_cd (registers)
         if constexpr (LAST) {
@@ -524,9 +544,6 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
         // ---------------------------------------------------------------- dhr = (g W1) * (hr > 0); dW1, db1, db0
         float d_cd[16];
         {
-            float hr_cd[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) hr_cd[q] = T2H_ROW_OK(q) ? (a.hr + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
             f32x16 acc_d;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc_d[q] = 0.f;
@@ -571,7 +588,11 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) x_cd[q] = T2H_ROW_OK(q) ? (a.x_full + (size_t)rb * 64 + 32 * t + r)[T2H_RO(q) * 64] : 0.f;
+                for (int q = 0; q < 16; ++q) {
+                    const float *xp = t == 0 ? a.x_left + (size_t)rb * a.ld_xl + r : a.x_right + (size_t)rb * a.ld_xr + r;
+                    const int ldx = t == 0 ? a.ld_xl : a.ld_xr;
+                    x_cd[q] = T2H_ROW_OK(q) ? xp[T2H_RO(q) * ldx] : 0.f;
+                }
             }
             {
                 float xr[16];
@@ -675,20 +696,35 @@ constexpr int kMaxSegs = 48;
 struct ReduceArgs { ReduceSeg seg[kMaxSegs]; int n_segs, n_slabs; long long stride; };
 
 __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceArgs a) {
+    // a block owns 32 consecutive outputs; its 8 slab lanes each add the slabs z = lane, lane + 8, ... (eight loads in
+    // flight, four interleaved partial sums), the lanes' partials are added in lane order: fixed order, deterministic
+    __shared__ float part[8][32];
     const ReduceSeg sg = a.seg[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < sg.n; i += gridDim.x * 256) {
-        // four partial sums over interleaved slabs keep loads in flight; combined in a fixed order
+    const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (int i0 = blockIdx.x * 32; i0 < sg.n; i0 += gridDim.x * 32) {
+        const int i = i0 + e;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int z = 0;
-        for (; z + 3 < a.n_slabs; z += 4) {
-            s0 += sg.src[(size_t)z * a.stride + i];
-            s1 += sg.src[(size_t)(z + 1) * a.stride + i];
-            s2 += sg.src[(size_t)(z + 2) * a.stride + i];
-            s3 += sg.src[(size_t)(z + 3) * a.stride + i];
+        if (i < sg.n) {
+            const float *src = sg.src + i;
+            int z = sl;
+            for (; z + 56 < a.n_slabs; z += 64) {
+                const float v0 = src[(size_t)z * a.stride], v1 = src[(size_t)(z + 8) * a.stride];
+                const float v2 = src[(size_t)(z + 16) * a.stride], v3 = src[(size_t)(z + 24) * a.stride];
+                const float v4 = src[(size_t)(z + 32) * a.stride], v5 = src[(size_t)(z + 40) * a.stride];
+                const float v6 = src[(size_t)(z + 48) * a.stride], v7 = src[(size_t)(z + 56) * a.stride];
+                s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+            }
+            for (; z < a.n_slabs; z += 8) s0 += src[(size_t)z * a.stride];
         }
-        for (; z < a.n_slabs; ++z) s0 += sg.src[(size_t)z * a.stride + i];
-        const float t = (s0 + s1) + (s2 + s3);
-        sg.dst[i] = sg.accumulate ? sg.dst[i] + t : t;
+        part[sl][e] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && i < sg.n) {
+            float t = part[0][e];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) t += part[j][e];
+            sg.dst[i] = sg.accumulate ? sg.dst[i] + t : t;
+        }
+        __syncthreads();
     }
 }
 
@@ -702,7 +738,7 @@ static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *net_prev,
                                 int ld_prev, const int32_t *cell, const int32_t *off0, const float *w0, const float *b0,
                                 const float *w1, const float *b1, const float *ws, const float *wc, const float *bc, int64_t M,
-                                float *x_full, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
+                                float *x_full, float *pooled, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
                                 t2h_stream_t stream) {
     const bool first = pts != nullptr;
     const bool last = wc != nullptr;
@@ -712,7 +748,8 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     if (first && last) return fail(T2H_ERR_ARG, "trunk_block_fwd: a block is either the first or the last");
     if (last && (!bc || !c_out)) return fail(T2H_ERR_ARG, "trunk_block_fwd: last block needs bc and c_out");
     if (M < 0 || M >= ((int64_t)1 << 31) - TR || ld_out < 32 || ld_out % 4) return fail(T2H_ERR_ARG, "trunk_block_fwd: bad shape");
-    if (!al16(w0) || !al16(w1) || !al16(ws) || !al16(hr) || !al16(out) || (x_full && !al16(x_full)) || (net_prev && !al16(net_prev)) ||
+    if (!al16(w0) || !al16(w1) || !al16(ws) || !al16(hr) || !al16(out) || (x_full && !al16(x_full)) || (pooled && !al16(pooled)) ||
+        (net_prev && !al16(net_prev)) ||
         (wc && !al16(wc)) || (c_out && !al16(c_out)))
         return fail(T2H_ERR_ARG, "trunk_block_fwd: pointers must be 16-byte aligned");
     if (M == 0) return T2H_OK;
@@ -720,7 +757,7 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos;
     a.net_prev = net_prev; a.ld_prev = ld_prev; a.cell = cell; a.off0 = off0;
     a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.ws = ws; a.wc = wc; a.bc = bc;
-    a.M = (int)M; a.x_full = x_full; a.hr = hr; a.out = out; a.ld_out = ld_out; a.winner = winner; a.c_out = c_out;
+    a.M = (int)M; a.x_full = x_full; a.pooled = pooled; a.hr = hr; a.out = out; a.ld_out = ld_out; a.winner = winner; a.c_out = c_out;
     const dim3 grid((unsigned)((M + TR - 1) / TR));
     hipStream_t s = as_stream(stream);
     if (first) hipLaunchKernelGGL((trunk_block_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
@@ -749,9 +786,10 @@ T2H_API size_t t2h_trunk_block_bwd_workspace_bytes(int64_t M) {
 
 T2H_API int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_pool, int ld_gp, const uint8_t *winner,
                                 const int32_t *cell, const int32_t *off0, const float *gc, const float *wc,
-                                const float *out_last, const float *hr, const float *x_full, const float *pts, int dim,
-                                const float *w_pos, const float *b_pos, const float *w0, const float *w1, const float *ws,
-                                int64_t M, float *dx, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+                                const float *out_last, const float *hr, const float *x_left, int ld_xl, const float *x_right,
+                                int ld_xr, const float *pts, int dim, const float *w_pos, const float *b_pos, const float *w0,
+                                const float *w1, const float *ws, int64_t M, float *dx, void *workspace, size_t workspace_bytes,
+                                t2h_stream_t stream) {
     const bool first = pts != nullptr, last = gc != nullptr;
     if (!hr || !w0 || !w1 || !ws || !workspace) return fail(T2H_ERR_ARG, "trunk_block_bwd: null pointer");
     if (first && last) return fail(T2H_ERR_ARG, "trunk_block_bwd: a block is either the first or the last");
@@ -759,7 +797,8 @@ T2H_API int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_po
         return fail(T2H_ERR_ARG, "trunk_block_bwd: bad output-gradient description");
     if (g_pool && (last || !winner || !cell || !off0 || ld_gp < 32 || ld_gp % 4))
         return fail(T2H_ERR_ARG, "trunk_block_bwd: bad pooled-gradient description");
-    if (first ? (!w_pos || !b_pos || dim < 3) : (!x_full || !dx)) return fail(T2H_ERR_ARG, "trunk_block_bwd: bad input description");
+    if (first ? (!w_pos || !b_pos || dim < 3) : (!x_left || !x_right || !dx || ld_xl < 32 || ld_xr < 32))
+        return fail(T2H_ERR_ARG, "trunk_block_bwd: bad input description");
     if (M < 0 || M >= ((int64_t)1 << 31) - TR) return fail(T2H_ERR_ARG, "trunk_block_bwd: bad shape");
     if (!al16(w0) || !al16(w1) || !al16(ws) || !al16(hr) || (g_net && !al16(g_net)) || (g_pool && !al16(g_pool)) ||
         (gc && (!al16(gc) || !al16(wc))) || !al16(workspace))
@@ -769,7 +808,7 @@ T2H_API int t2h_trunk_block_bwd(const float *g_net, int ld_gn, const float *g_po
         return fail(T2H_ERR_WORKSPACE, "trunk_block_bwd: workspace %zu < %zu bytes", workspace_bytes, t2h_trunk_block_bwd_workspace_bytes(M));
     TrunkBwdArgs a{};
     a.g_net = g_net; a.ld_gn = ld_gn; a.g_pool = g_pool; a.ld_gp = ld_gp; a.winner = winner; a.cell = cell; a.off0 = off0;
-    a.gc = gc; a.wc = wc; a.out_last = out_last; a.hr = hr; a.x_full = x_full;
+    a.gc = gc; a.wc = wc; a.out_last = out_last; a.hr = hr; a.x_left = x_left; a.ld_xl = ld_xl; a.x_right = x_right; a.ld_xr = ld_xr;
     a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos; a.w0 = w0; a.w1 = w1; a.ws = ws;
     a.M = (int)M; a.tiles_per_wg = trunk_bwd_tiles_per_wg(M); a.dx = dx;
     a.slab = static_cast<float *>(workspace); a.slab_floats = kTrunkSlabFloats;
@@ -797,6 +836,6 @@ T2H_API int t2h_trunk_block_reduce(const void *workspace, int64_t M, int first, 
     if (last) { add(SL_X, dwx, 1024); add(SL_X + 1024, dbx, 32); }
     if (first) { add(SL_X, dwx, 192); add(SL_X + 192, dbx, 64); }
     r.n_segs = n; r.n_slabs = trunk_bwd_slabs(M); r.stride = kTrunkSlabFloats;
-    hipLaunchKernelGGL(reduce_segments_kernel, dim3(8, n), dim3(256), 0, as_stream(stream), r);
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(64, n), dim3(256), 0, as_stream(stream), r);
     return check_launch("trunk_block_reduce");
 }

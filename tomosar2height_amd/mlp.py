@@ -320,21 +320,23 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
-def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_x=True, materialise_x0=False):
-    """pointnet.py:72-82 as one launch per block: (cats, hrs, winners) in the layout the backward expects -- cats[i] is
-    block i's [M, 64] input (= [net | pooled]; cats[0] = fc_pos output), cats[-1] the last block's [M, 32] output."""
+def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, want_x_full=False):
+    """pointnet.py:72-82 as one launch per block.  Returns (c, nets, pooled, hrs, winners[, x_full]): nets[i] = block i's
+    [M, 32] output, pooled[i] (i >= 1) = the pooled half of block i's input (= pool_local(nets[i-1])), winners[i-1] its
+    arg-max bits, hrs[i] the hidden activations; ``want_x_full`` also materialises every block's [M, 64] input (tests)."""
     m, nb, dev = pts.shape[0], len(blocks), pts.device
-    cats, hrs, winners = [], [], []
+    nets, pooled, hrs, winners, x_fulls = [], [None], [], [], []
     net_prev, c_out = None, None
     for i, (w0, b0, w1, b1, ws) in enumerate(blocks):
         first, last = i == 0, i == nb - 1
-        x_full = _empty(m, 64, pts) if (materialise_x and (not first or materialise_x0)) else None
+        x_full = _empty(m, 64, pts) if want_x_full else None
+        pool = None if first else _empty(m, 32, pts)
         hr, out = _empty(m, 32, pts), _empty(m, 32, pts)
         win = None if first else torch.empty(m, 8, dtype=torch.uint8, device=dev)
         if last:
             c_out = _empty(m, 32, pts)
         wts = [t.contiguous() for t in (w0, b0, w1, b1, ws)]
-        nbytes = m * ((4 * pts.shape[1] if first else 4 * 32 + 4) + 2 * 128 + (0 if first else 8) + (128 if last else 0)
+        nbytes = m * ((4 * pts.shape[1] if first else 4 * 32 + 4) + 2 * 128 + (0 if first else 8 + 128) + (128 if last else 0)
                       + (256 if x_full is not None else 0))
         flops = 2 * m * (2 * 64 * 32 + 32 * 32 + (32 * 32 if last else 0) + (3 * 64 if first else 0))
         _lib.call("t2h_trunk_block_fwd",
@@ -343,19 +345,23 @@ def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, materialise_
                   None if first else _lib.ptr(net_prev), 32, None if first else _lib.ptr(tile.cell),
                   None if first else _lib.ptr(tile.off0),
                   *[_lib.ptr(t) for t in wts], _lib.ptr(w_c.contiguous()) if last else None, _lib.ptr(b_c) if last else None,
-                  m, None if x_full is None else _lib.ptr(x_full), _lib.ptr(hr), _lib.ptr(out), 32,
-                  None if win is None else _lib.ptr(win), None if c_out is None else _lib.ptr(c_out), _lib.stream(),
-                  nbytes=nbytes, flops=flops, tag="t2h_trunk_block_fwd")
-        cats.append(x_full)
+                  m, None if x_full is None else _lib.ptr(x_full), None if pool is None else _lib.ptr(pool), _lib.ptr(hr),
+                  _lib.ptr(out), 32, None if win is None else _lib.ptr(win), None if c_out is None else _lib.ptr(c_out),
+                  _lib.stream(), nbytes=nbytes, flops=flops,
+                  tag="t2h_trunk_block_fwd[%s]" % ("first" if first else ("last" if last else "mid")))
+        nets.append(out)
         hrs.append(hr)
-        if win is not None:
+        x_fulls.append(x_full)
+        if not first:
+            pooled.append(pool)
             winners.append(win)
         net_prev = out
-    cats.append(net_prev)
-    return c_out, cats, hrs, winners
+    if want_x_full:
+        return c_out, nets, pooled, hrs, winners, x_fulls
+    return c_out, nets, pooled, hrs, winners
 
 
-def _trunk_backward_fused(tile, pts, params, cats, hrs, winners, g_out):
+def _trunk_backward_fused(tile, pts, params, nets, pooled, hrs, winners, g_out):
     """Backward of ``_trunk_forward_fused``: one t2h_trunk_block_bwd + one slab reduction per block, last block first.
     Block i's kernel folds the backward of the pooling that consumed its output (gather -> scatter-add over the cell,
     scatter_max -> its arg-max row, pointnet.py:95-98) into its loader, the last block's the backward of
@@ -381,11 +387,13 @@ def _trunk_backward_fused(tile, pts, params, cats, hrs, winners, g_out):
                   None if last else _lib.ptr(dx_next), 64, None if last else _lib.ptr(dx_next) + 128, 64,
                   None if last else _lib.ptr(winners[i]), _lib.ptr(tile.cell), _lib.ptr(tile.off0),
                   _lib.ptr(g_out) if last else None, _lib.ptr(w_c.contiguous()) if last else None,
-                  _lib.ptr(cats[-1]) if last else None, _lib.ptr(hrs[i]), None if first else _lib.ptr(cats[i]),
+                  _lib.ptr(nets[-1]) if last else None, _lib.ptr(hrs[i]),
+                  None if first else _lib.ptr(nets[i - 1]), 32, None if first else _lib.ptr(pooled[i]), 32,
                   _lib.ptr(pts) if first else None, pts.shape[1], _lib.ptr(w_pos.contiguous()) if first else None,
                   _lib.ptr(b_pos) if first else None, _lib.ptr(w0.contiguous()), _lib.ptr(w1.contiguous()),
                   _lib.ptr(wsc.contiguous()), m, None if dx is None else _lib.ptr(dx), _lib.ptr(ws), ws_bytes, _lib.stream(),
-                  nbytes=nbytes, flops=flops, tag="t2h_trunk_block_bwd")
+                  nbytes=nbytes, flops=flops,
+                  tag="t2h_trunk_block_bwd[%s]" % ("first" if first else ("last" if last else "mid")))
         extra = (w_pos, b_pos) if first else ((w_c, b_c) if last else None)
         if direct:
             dst = [w0.grad, b0.grad, w1.grad, b1.grad, wsc.grad] + ([extra[0].grad, extra[1].grad] if extra else [None, None])
@@ -422,10 +430,9 @@ class _PointTrunk(torch.autograd.Function):
         h = blocks[0][2].shape[0]
         ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
         if _fused_trunk_applicable(pts, params, n_blocks):
-            out, cats, hrs, winners = _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
-            ctx.fused = True
-            cats[0] = pts.new_empty(0)                     # block 0's input is recomputed from the points in the backward
-            ctx.save_for_backward(pts, *params, *cats, *hrs, *winners)
+            out, nets, pooled, hrs, winners = _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
+            ctx.fused = True                               # (block 0's input is recomputed from the points in the backward)
+            ctx.save_for_backward(pts, *params, *nets, *pooled[1:], *hrs, *winners)
             return out
         ctx.fused = False
         cats, hrs, winners = [], [], []
@@ -462,7 +469,9 @@ class _PointTrunk(torch.autograd.Function):
 
         g_out = g_out.contiguous()
         if ctx.fused:
-            return (None, None, *_trunk_backward_fused(tile, pts, params, cats, hrs, winners, g_out))
+            rest = saved[1 + n_params:]
+            nets, pooled, hrs, winners = rest[:nb], [None, *rest[nb:2 * nb - 1]], rest[2 * nb - 1:3 * nb - 1], rest[3 * nb - 1:]
+            return (None, None, *_trunk_backward_fused(tile, pts, params, nets, pooled, hrs, winners, g_out.contiguous()))
         dw_c, db_c = _wgrad(g_out, cats[-1], w_c, b_c, relu_in=True)
         g = linear_dgrad_(g_out, w_c, torch.empty_like(cats[-1]), mask=cats[-1])     # grad of the last block output
         grads = [None] * n_params
