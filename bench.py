@@ -37,8 +37,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
-SCATTER_REDUCE_TAGS = ("t2h_segmean_fwd[C=512,r=32]", "t2h_pool_max_fwd", "t2h_pool_max_bwd", "t2h_trunk_block_fwd",
-                       "t2h_trunk_block_bwd")
+# the scatter-reduce kernels north_star names: the largest scatter_mean, and pool_local -- which since r02 has no kernel of
+# its own: the segmented max / its backward run in the loaders of the fused trunk block kernels (csrc/trunk.hip)
+SCATTER_REDUCE_TAGS = ("t2h_segmean_fwd[C=512,r=32]", "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]",
+                       "t2h_pool_max_fwd", "t2h_pool_max_bwd")
 
 
 def parse():

@@ -170,7 +170,9 @@ def test_rasterise_mean_golden():
 @pytest.mark.parametrize("n,reso,c,level,batch,cl", [(150, 8, 4, 0, 1, False), (150, 16, 8, 0, 2, True),
                                                      (5000, 64, 32, 0, 1, False), (5000, 64, 64, 1, 1, True),
                                                      (40000, 256, 32, 0, 1, False), (20000, 256, 512, 3, 1, False),
-                                                     (3000, 64, 12, 2, 1, False), (2000, 256, 16, 8, 1, False)])
+                                                     (3000, 64, 12, 2, 1, False), (2000, 256, 16, 8, 1, False),
+                                                     (30000, 256, 128, 1, 2, True), (9000, 256, 64, 0, 1, True),
+                                                     (700, 8, 32, 0, 3, False), (6000, 32, 20, 1, 1, False)])
 def test_sample_plane_vs_oracle(n, reso, c, level, batch, cl):
     from tomosar2height_amd import ops
     from oracle import c_oracle
@@ -191,6 +193,11 @@ def test_sample_plane_vs_oracle(n, reso, c, level, batch, cl):
     want_g = c_oracle.grid_sample_bwd(gout.numpy(), cloud.numpy(), r, r)
     scale = np.abs(want_g).max() + 1e-6
     np.testing.assert_allclose(p.grad.cpu().numpy(), want_g, rtol=1e-4, atol=1e-5 * scale)
+    # the backward has no atomics at any level: a second run gives the same bits
+    first = p.grad.clone()
+    p.grad = None
+    ops.sample_plane(t, p).backward(t.sort_rows(gout.to(_dev())))
+    assert torch.equal(first, p.grad)
 
 
 def test_sample_plane_golden():
