@@ -687,80 +687,100 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const floa
 // per phase, phases run in a fixed order and a cell's rows in sorted order => bit-reproducible.  The slot sums of a
 // phase's cell are built in registers (global loads in flight) before the barrier that orders the LDS updates.
 constexpr int kPB = 8;
+constexpr int kTileSplit = 2;         // lane groups per cell: a dense cell's rows are dealt to them in runs of four
 template <int LGG>
-__global__ __launch_bounds__(256) void sample_bwd_tiles_kernel(const float *__restrict__ gout,
-                                                               const float *__restrict__ pts, int dim,
-                                                               const int32_t *__restrict__ off0, int nbits, int level,
-                                                               int C, float *__restrict__ gplane) {
-    constexpr int G = 1 << LGG, CH = 4 * G;          // 256 / G >= 16 lane groups: one per cell of a colour phase
+__global__ __launch_bounds__(16 * kTileSplit * (1 << LGG)) void sample_bwd_tiles_kernel(
+    const float *__restrict__ gout, const float *__restrict__ pts, int dim, const int32_t *__restrict__ off0, int nbits,
+    int level, int C, float *__restrict__ gplane) {
+    constexpr int G = 1 << LGG, CH = 4 * G, NT = 16 * kTileSplit * G;        // 16 cells per colour phase at most
     __shared__ float4 tile[kPB * kPB * G];
+    __shared__ int seg[(kPB + 2) * (kPB + 2) * 2];                           // [cell of the 10 x 10 region][start, end)
     const int rbits = nbits - level, r = 1 << rbits, bbits = rbits - 3;      // r / 8 blocks per side
     const int tid = threadIdx.x, lane = tid & (G - 1), grp = tid >> LGG;
+    const int cellslot = grp / kTileSplit, split = grp % kTileSplit;
     const uint32_t bm = blockIdx.x & ((1u << (2 * bbits)) - 1);              // blocks in Morton order: neighbours share L2 lines
     const int b = (int)(blockIdx.x >> (2 * bbits));
     const int X0 = (int)compact1by1(bm) * kPB, Y0 = (int)compact1by1(bm >> 1) * kPB;
     const int c = blockIdx.y * CH + lane * 4;
     const bool cv = c < C;
-    for (int i = tid; i < kPB * kPB * G; i += 256) tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < kPB * kPB * G; i += NT) tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const size_t span = (size_t)1 << (2 * level);
+    for (int i = tid; i < (kPB + 2) * (kPB + 2); i += NT) {                  // all row ranges up front: one latency
+        const int cx = X0 - 1 + i % (kPB + 2), cy = Y0 - 1 + i / (kPB + 2);
+        int s0 = 0, e0 = 0;
+        if (cx >= 0 && cx < r && cy >= 0 && cy < r) {
+            const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
+            s0 = off0[obase]; e0 = off0[obase + span];
+        }
+        seg[2 * i] = s0; seg[2 * i + 1] = e0;
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int phase = 0; phase < 9; ++phase) {
         const int colx = phase % 3, coly = phase / 3;
         const int fx = X0 - 1 + (colx - (X0 + 2) % 3 + 3) % 3, fy = Y0 - 1 + (coly - (Y0 + 2) % 3 + 3) % 3;
         const int nx = (X0 + kPB - fx) / 3 + 1, ny = (Y0 + kPB - fy) / 3 + 1;
-        const int cx = fx + 3 * (grp % nx), cy = fy + 3 * (grp / nx);
-        const bool mine = grp < nx * ny && cx >= 0 && cx < r && cy >= 0 && cy < r && cv;
+        const int cx = fx + 3 * (cellslot % nx), cy = fy + 3 * (cellslot / nx);
+        const bool mine = cellslot < nx * ny && cv;
         float4 acc[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any = false;
         if (mine) {
-            const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
-            const int s = off0[obase], e = off0[obase + span];
-            for (int n = s; n < e; n += 2) {                                // two rows in flight; the second may be a dummy
-                const int n1 = min(n + 1, e - 1);
-                const float4 g0 = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
-                const float4 g1 = *reinterpret_cast<const float4 *>(gout + (size_t)n1 * C + c);
-                const Taps t0 = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-                const Taps t1 = make_taps(pts[(size_t)n1 * dim + 0], pts[(size_t)n1 * dim + 1], r);
-                const float live1 = n + 1 < e ? 1.0f : 0.0f;
-                const int dx0 = t0.x0 - cx + 1, dy0 = t0.y0 - cy + 1, dx1 = t1.x0 - cx + 1, dy1 = t1.y0 - cy + 1;
+            const int ci = (cy - (Y0 - 1)) * (kPB + 2) + (cx - (X0 - 1));
+            const int s = seg[2 * ci], e = seg[2 * ci + 1];
+            for (int n0 = s + 4 * split; n0 < e; n0 += 4 * kTileSplit) {    // four rows in flight (dummies past the end)
+                any = true;
+                float4 g[4];
+                Taps t[4];
+                float live[4];
 #pragma unroll
-                for (int sy = 0; sy < 3; ++sy) {
-                    const float wy0 = (sy == dy0) ? t0.wy0 : ((sy == dy0 + 1) ? t0.wy1 : 0.0f);
-                    const float wy1 = live1 * ((sy == dy1) ? t1.wy0 : ((sy == dy1 + 1) ? t1.wy1 : 0.0f));
+                for (int u = 0; u < 4; ++u) {
+                    const int n = min(n0 + u, e - 1);
+                    g[u] = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
+                    t[u] = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+                    live[u] = n0 + u < e ? 1.0f : 0.0f;
+                }
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const float w0 = __fmul_rn((sx == dx0) ? t0.wx0 : ((sx == dx0 + 1) ? t0.wx1 : 0.0f), wy0);
-                        const float w1 = __fmul_rn((sx == dx1) ? t1.wx0 : ((sx == dx1 + 1) ? t1.wx1 : 0.0f), wy1);
-                        float4 &a = acc[sy * 3 + sx];
-                        a.x = __fadd_rn(__fadd_rn(a.x, __fmul_rn(w0, g0.x)), __fmul_rn(w1, g1.x));
-                        a.y = __fadd_rn(__fadd_rn(a.y, __fmul_rn(w0, g0.y)), __fmul_rn(w1, g1.y));
-                        a.z = __fadd_rn(__fadd_rn(a.z, __fmul_rn(w0, g0.z)), __fmul_rn(w1, g1.z));
-                        a.w = __fadd_rn(__fadd_rn(a.w, __fmul_rn(w0, g0.w)), __fmul_rn(w1, g1.w));
+                for (int u = 0; u < 4; ++u) {
+                    const int dx = t[u].x0 - cx + 1, dy = t[u].y0 - cy + 1;
+#pragma unroll
+                    for (int sy = 0; sy < 3; ++sy) {
+                        const float wy = live[u] * ((sy == dy) ? t[u].wy0 : ((sy == dy + 1) ? t[u].wy1 : 0.0f));
+#pragma unroll
+                        for (int sx = 0; sx < 3; ++sx) {
+                            const float w = __fmul_rn((sx == dx) ? t[u].wx0 : ((sx == dx + 1) ? t[u].wx1 : 0.0f), wy);
+                            float4 &a = acc[sy * 3 + sx];
+                            a.x = __fadd_rn(a.x, __fmul_rn(w, g[u].x)); a.y = __fadd_rn(a.y, __fmul_rn(w, g[u].y));
+                            a.z = __fadd_rn(a.z, __fmul_rn(w, g[u].z)); a.w = __fadd_rn(a.w, __fmul_rn(w, g[u].w));
+                        }
                     }
                 }
             }
         }
-        __syncthreads();                        // the previous phase's tile updates (and the zero fill) are complete
-        if (mine) {
+#pragma unroll 1
+        for (int sp = 0; sp < kTileSplit; ++sp) {
+            __syncthreads();                    // earlier tile updates (previous phase / previous split / zero fill) are complete
+            if (any && split == sp) {
 #pragma unroll
-            for (int sy = 0; sy < 3; ++sy) {
-                const int py = cy - 1 + sy - Y0;
+                for (int sy = 0; sy < 3; ++sy) {
+                    const int py = cy - 1 + sy - Y0;
 #pragma unroll
-                for (int sx = 0; sx < 3; ++sx) {
-                    const int px = cx - 1 + sx - X0;
-                    if (px >= 0 && px < kPB && py >= 0 && py < kPB) {       // pixels of other blocks belong to other workgroups
-                        float4 t = tile[(py * kPB + px) * G + lane];
-                        const float4 a = acc[sy * 3 + sx];
-                        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-                        tile[(py * kPB + px) * G + lane] = t;
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const int px = cx - 1 + sx - X0;
+                        if (px >= 0 && px < kPB && py >= 0 && py < kPB) {   // pixels of other blocks belong to other workgroups
+                            float4 t = tile[(py * kPB + px) * G + lane];
+                            const float4 a = acc[sy * 3 + sx];
+                            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+                            tile[(py * kPB + px) * G + lane] = t;
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < kPB * kPB * G; i += 256) {
+    for (int i = tid; i < kPB * kPB * G; i += NT) {
         const int pix = i >> LGG, l = i & (G - 1), cc = blockIdx.y * CH + l * 4;
         if (cc < C)
             *reinterpret_cast<float4 *>(gplane + (((size_t)b * r + Y0 + pix / kPB) * r + X0 + pix % kPB) * C + cc) = tile[i];
@@ -1017,11 +1037,11 @@ T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const i
         const dim3 grid((unsigned)(groups >> 6), (unsigned)((C + ch - 1) / ch));
         hipStream_t st = as_stream(stream);
         switch (lgg) {
-            case 4: hipLaunchKernelGGL(sample_bwd_tiles_kernel<4>, grid, dim3(256), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 3: hipLaunchKernelGGL(sample_bwd_tiles_kernel<3>, grid, dim3(256), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 2: hipLaunchKernelGGL(sample_bwd_tiles_kernel<2>, grid, dim3(256), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 1: hipLaunchKernelGGL(sample_bwd_tiles_kernel<1>, grid, dim3(256), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            default: hipLaunchKernelGGL(sample_bwd_tiles_kernel<0>, grid, dim3(256), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
+            case 4: hipLaunchKernelGGL(sample_bwd_tiles_kernel<4>, grid, dim3(16 * kTileSplit << 4), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
+            case 3: hipLaunchKernelGGL(sample_bwd_tiles_kernel<3>, grid, dim3(16 * kTileSplit << 3), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
+            case 2: hipLaunchKernelGGL(sample_bwd_tiles_kernel<2>, grid, dim3(16 * kTileSplit << 2), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
+            case 1: hipLaunchKernelGGL(sample_bwd_tiles_kernel<1>, grid, dim3(16 * kTileSplit << 1), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
+            default: hipLaunchKernelGGL(sample_bwd_tiles_kernel<0>, grid, dim3(16 * kTileSplit << 0), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
         }
         note_kernel("sample_bwd_tiles_kernel");
         return check_launch("sample_bwd(tiles)");
