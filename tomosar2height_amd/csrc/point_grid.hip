@@ -467,17 +467,30 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
     const int rbits = nbits - level, r = 1 << rbits;
     if (gid >= (int64_t)B * r * r) return;
     int b = (int)(gid >> (2 * rbits));
-    int py = (int)((gid >> rbits) & (r - 1)), px = (int)(gid & (r - 1));
+    // pixels in Morton order: the pixels of a workgroup form a compact 2-D block, so the rows of the cells around them
+    // are re-read from this CU's L1 instead of from L2 by ~9 different workgroups
+    const uint32_t pm = (uint32_t)(gid & (((int64_t)1 << (2 * rbits)) - 1));
+    int py = (int)compact1by1(pm >> 1), px = (int)compact1by1(pm);
     int span = VEC << lg;
     int c0 = ((int)t & ((1 << lg) - 1)) * VEC;
+    // the row ranges of the (up to) nine cells, requested together
+    int segs[9], sege[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int cy = py - 1 + q / 3, cx = px - 1 + q % 3;
+        segs[q] = sege[q] = 0;
+        if (cx >= 0 && cx < r && cy >= 0 && cy < r) {
+            size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
+            segs[q] = off0[obase]; sege[q] = off0[obase + ((size_t)1 << (2 * level))];
+        }
+    }
     for (int c = c0; c < C; c += span) {
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
-        for (int cy = max(py - 1, 0); cy <= min(py + 1, r - 1); ++cy)
-            for (int cx = max(px - 1, 0); cx <= min(px + 1, r - 1); ++cx) {
-                size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
-                int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+                const int s = segs[q], e = sege[q];
                 for (int n = s; n < e; n += 2) {   // two rows in flight; a row that misses this pixel gets weight 0
                     const int n1 = min(n + 1, e - 1);
                     Taps t0 = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
@@ -679,114 +692,6 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const floa
     }
 }
 
-// grid_sample backward at the fine / medium levels (a handful of rows per cell): every gradient row is read ONCE per
-// workgroup instead of by the ~9 pixels it touches.  A workgroup owns an 8 x 8 PIXEL block (and a chunk of <= 64 channels)
-// whose sums live in LDS, and visits the cells of the 10 x 10 region around it in nine COLOUR phases, colour =
-// (cx mod 3, cy mod 3): a cell only touches the 3 x 3 pixels around it, so the cells of one colour touch disjoint pixels
-// and one lane group per cell can add its nine slot sums into the tile without atomics; a pixel receives exactly one cell
-// per phase, phases run in a fixed order and a cell's rows in sorted order => bit-reproducible.  The slot sums of a
-// phase's cell are built in registers (global loads in flight) before the barrier that orders the LDS updates.
-constexpr int kPB = 8;
-constexpr int kTileSplit = 2;         // lane groups per cell: a dense cell's rows are dealt to them in runs of four
-template <int LGG>
-__global__ __launch_bounds__(16 * kTileSplit * (1 << LGG)) void sample_bwd_tiles_kernel(
-    const float *__restrict__ gout, const float *__restrict__ pts, int dim, const int32_t *__restrict__ off0, int nbits,
-    int level, int C, float *__restrict__ gplane) {
-    constexpr int G = 1 << LGG, CH = 4 * G, NT = 16 * kTileSplit * G;        // 16 cells per colour phase at most
-    __shared__ float4 tile[kPB * kPB * G];
-    __shared__ int seg[(kPB + 2) * (kPB + 2) * 2];                           // [cell of the 10 x 10 region][start, end)
-    const int rbits = nbits - level, r = 1 << rbits, bbits = rbits - 3;      // r / 8 blocks per side
-    const int tid = threadIdx.x, lane = tid & (G - 1), grp = tid >> LGG;
-    const int cellslot = grp / kTileSplit, split = grp % kTileSplit;
-    const uint32_t bm = blockIdx.x & ((1u << (2 * bbits)) - 1);              // blocks in Morton order: neighbours share L2 lines
-    const int b = (int)(blockIdx.x >> (2 * bbits));
-    const int X0 = (int)compact1by1(bm) * kPB, Y0 = (int)compact1by1(bm >> 1) * kPB;
-    const int c = blockIdx.y * CH + lane * 4;
-    const bool cv = c < C;
-    for (int i = tid; i < kPB * kPB * G; i += NT) tile[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const size_t span = (size_t)1 << (2 * level);
-    for (int i = tid; i < (kPB + 2) * (kPB + 2); i += NT) {                  // all row ranges up front: one latency
-        const int cx = X0 - 1 + i % (kPB + 2), cy = Y0 - 1 + i / (kPB + 2);
-        int s0 = 0, e0 = 0;
-        if (cx >= 0 && cx < r && cy >= 0 && cy < r) {
-            const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
-            s0 = off0[obase]; e0 = off0[obase + span];
-        }
-        seg[2 * i] = s0; seg[2 * i + 1] = e0;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int phase = 0; phase < 9; ++phase) {
-        const int colx = phase % 3, coly = phase / 3;
-        const int fx = X0 - 1 + (colx - (X0 + 2) % 3 + 3) % 3, fy = Y0 - 1 + (coly - (Y0 + 2) % 3 + 3) % 3;
-        const int nx = (X0 + kPB - fx) / 3 + 1, ny = (Y0 + kPB - fy) / 3 + 1;
-        const int cx = fx + 3 * (cellslot % nx), cy = fy + 3 * (cellslot / nx);
-        const bool mine = cellslot < nx * ny && cv;
-        float4 acc[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool any = false;
-        if (mine) {
-            const int ci = (cy - (Y0 - 1)) * (kPB + 2) + (cx - (X0 - 1));
-            const int s = seg[2 * ci], e = seg[2 * ci + 1];
-            for (int n0 = s + 4 * split; n0 < e; n0 += 4 * kTileSplit) {    // four rows in flight (dummies past the end)
-                any = true;
-                float4 g[4];
-                Taps t[4];
-                float live[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int n = min(n0 + u, e - 1);
-                    g[u] = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
-                    t[u] = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-                    live[u] = n0 + u < e ? 1.0f : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int dx = t[u].x0 - cx + 1, dy = t[u].y0 - cy + 1;
-#pragma unroll
-                    for (int sy = 0; sy < 3; ++sy) {
-                        const float wy = live[u] * ((sy == dy) ? t[u].wy0 : ((sy == dy + 1) ? t[u].wy1 : 0.0f));
-#pragma unroll
-                        for (int sx = 0; sx < 3; ++sx) {
-                            const float w = __fmul_rn((sx == dx) ? t[u].wx0 : ((sx == dx + 1) ? t[u].wx1 : 0.0f), wy);
-                            float4 &a = acc[sy * 3 + sx];
-                            a.x = __fadd_rn(a.x, __fmul_rn(w, g[u].x)); a.y = __fadd_rn(a.y, __fmul_rn(w, g[u].y));
-                            a.z = __fadd_rn(a.z, __fmul_rn(w, g[u].z)); a.w = __fadd_rn(a.w, __fmul_rn(w, g[u].w));
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll 1
-        for (int sp = 0; sp < kTileSplit; ++sp) {
-            __syncthreads();                    // earlier tile updates (previous phase / previous split / zero fill) are complete
-            if (any && split == sp) {
-#pragma unroll
-                for (int sy = 0; sy < 3; ++sy) {
-                    const int py = cy - 1 + sy - Y0;
-#pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const int px = cx - 1 + sx - X0;
-                        if (px >= 0 && px < kPB && py >= 0 && py < kPB) {   // pixels of other blocks belong to other workgroups
-                            float4 t = tile[(py * kPB + px) * G + lane];
-                            const float4 a = acc[sy * 3 + sx];
-                            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-                            tile[(py * kPB + px) * G + lane] = t;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < kPB * kPB * G; i += NT) {
-        const int pix = i >> LGG, l = i & (G - 1), cc = blockIdx.y * CH + l * 4;
-        if (cc < C)
-            *reinterpret_cast<float4 *>(gplane + (((size_t)b * r + Y0 + pix / kPB) * r + X0 + pix % kPB) * C + cc) = tile[i];
-    }
-}
-
 // Generic backward (any r, any point order): float atomics, caller zeroes gplane.
 __global__ __launch_bounds__(kThreads) void sample_bwd_atomic_kernel(const float *__restrict__ gout,
                                                                      const float *__restrict__ pts, int dim,
@@ -849,7 +754,7 @@ T2H_API size_t t2h_segmean_workspace_bytes(int B, int N, int nbits, int level, i
     return ((size_t)B << (2 * (nbits - level))) * p.S * C * sizeof(float);
 }
 
-constexpr int kSampleBwdMinPts = 16;  // below: the pixel-block kernel (rows read once); from here on: per-cell partials + gather9
+constexpr int kSampleBwdMinPts = 6;   // the 3x3 gather re-reads rows ~9x: switch to read-once partials early
 
 T2H_API size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C) {
     if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1) return 0;
@@ -1029,22 +934,6 @@ T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const i
         hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                            partial, B, nbits - level, C, g.lg, cp.S, gplane_nhwc);
         return check_launch("sample_bwd(coarse)");
-    }
-    if (C % 4 == 0 && nbits - level >= 3 && N > 0) {
-        // 8 x 8 pixel blocks, <= 64 channels per workgroup
-        const int lgg = C >= 64 ? 4 : group_log2(C, 4);
-        const int ch = 4 << lgg;
-        const dim3 grid((unsigned)(groups >> 6), (unsigned)((C + ch - 1) / ch));
-        hipStream_t st = as_stream(stream);
-        switch (lgg) {
-            case 4: hipLaunchKernelGGL(sample_bwd_tiles_kernel<4>, grid, dim3(16 * kTileSplit << 4), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 3: hipLaunchKernelGGL(sample_bwd_tiles_kernel<3>, grid, dim3(16 * kTileSplit << 3), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 2: hipLaunchKernelGGL(sample_bwd_tiles_kernel<2>, grid, dim3(16 * kTileSplit << 2), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            case 1: hipLaunchKernelGGL(sample_bwd_tiles_kernel<1>, grid, dim3(16 * kTileSplit << 1), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-            default: hipLaunchKernelGGL(sample_bwd_tiles_kernel<0>, grid, dim3(16 * kTileSplit << 0), 0, st, gout, pts, dim, off0, nbits, level, C, gplane_nhwc); break;
-        }
-        note_kernel("sample_bwd_tiles_kernel");
-        return check_launch("sample_bwd(tiles)");
     }
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
