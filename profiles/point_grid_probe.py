@@ -47,10 +47,16 @@ for C, r in ((32, 256), (64, 256), (128, 128), (256, 64), (512, 32)):
     if args.only in ("", "sample_fwd"):
         rows["sample_fwd"] = (timed(lambda: ops.sample_plane(tile, plane)), 4 * C * N + 8 * N + 4 * C * r * r)
     if args.only in ("", "sample_bwd"):
-        p = plane.clone().requires_grad_(True)
-        out = ops.sample_plane(tile, p)
-        rows["sample_bwd"] = (timed(lambda: torch.autograd.grad(out, p, feat, retain_graph=True)), 4 * C * N + 8 * N + 4 * C * r * r)
+        gplane = torch.empty(1, r, r, C, device=dev)
+        lvl = tile.level(r)
+        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(1, N, tile.nbits, lvl, C)
+        ws = _lib.workspace(ws_bytes, dev)
+
+        def bwd():
+            _lib.call("t2h_sample_bwd", _lib.ptr(feat), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), 1, N, tile.nbits, lvl,
+                      C, _lib.ptr(gplane), _lib.ptr(ws), ws_bytes, _lib.stream())
+        rows["sample_bwd"] = (timed(bwd), 4 * C * N + 8 * N + 4 * C * r * r)
     if args.only in ("", "segmean_fwd"):
         rows["segmean_fwd"] = (timed(lambda: ops.rasterise_mean(tile, feat, r, True)), 4 * C * N + 4 * N + 4 * C * r * r)
     for k, (us, nbytes) in rows.items():
-        print(f"{k:12s} C={C:4d} r={r:4d} {us:8.1f} us {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / us / 8e6 * 100:5.1f} % of 8 TB/s)")
+        print(f"{k:18s} C={C:4d} r={r:4d} {us:8.1f} us {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / us / 8e6 * 100:5.1f} % of 8 TB/s)")

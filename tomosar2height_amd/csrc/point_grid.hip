@@ -9,6 +9,7 @@
 // cross-lane traffic is needed.  Segments are contiguous runs of rows thanks to the Morton sort, so the
 // reductions are plain sequential loops over neighbouring rows: no atomics, deterministic sums.
 #include <float.h>
+#include <stdlib.h>
 
 #include "t2h_common.h"
 
@@ -518,84 +519,14 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
 }
 
 
-// The gather above recomputes every visited row's taps in every lane of every one of the ~9 pixels that visit it: at the
-// fine levels it is VALU bound (rocprofv3: 2100 vector instructions per wave, 90 loads).  This variant reads a per-point
-// tap table instead -- tap_pix[n] = y0 * r + x0 (tile-local pixel of the north-west tap), tap_w[n] = (nw, ne, sw, se)
-// with the taps beyond the border zeroed -- written once per call by sample_taps_kernel; a visited row then costs one
-// compare chain on (pixel - tap_pix[n]).  Same products, same summation order: bit-identical to sample_bwd_kernel.
-__global__ __launch_bounds__(kThreads) void sample_taps_kernel(const float *__restrict__ pts, int dim, int64_t npts, int r,
-                                                               int32_t *__restrict__ tap_pix, float4 *__restrict__ tap_w) {
-    int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (n >= npts) return;
-    Taps tp = make_taps(pts[n * dim + 0], pts[n * dim + 1], r);
-    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
-    tap_pix[n] = tp.y0 * r + tp.x0;
-    tap_w[n] = make_float4(__fmul_rn(tp.wx0, tp.wy0), x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.0f,
-                           y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.0f, (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.0f);
-}
-
-__device__ inline float tap_weight(int d, int r, const float4 &w) {
-    return d == 0 ? w.x : (d == 1 ? w.y : (d == r ? w.z : (d == r + 1 ? w.w : 0.0f)));
-}
-
-template <int VEC>
-__global__ __launch_bounds__(kThreads) void sample_bwd_taps_kernel(const float *__restrict__ gout,
-                                                                   const int32_t *__restrict__ tap_pix,
-                                                                   const float4 *__restrict__ tap_w,
-                                                                   const int32_t *__restrict__ off0, int B, int nbits,
-                                                                   int level, int C, int lg, float *__restrict__ gplane) {
-    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    int64_t gid = t >> lg;
-    const int rbits = nbits - level, r = 1 << rbits;
-    if (gid >= (int64_t)B * r * r) return;
-    const int b = (int)(gid >> (2 * rbits));
-    const uint32_t pm = (uint32_t)(gid & (((int64_t)1 << (2 * rbits)) - 1));     // pixels in Morton order (L1 reuse of rows)
-    const int py = (int)compact1by1(pm >> 1), px = (int)compact1by1(pm);
-    const int P = py * r + px;
-    // Morton codes of the three neighbouring columns / rows, combined per cell: 6 bit-spreads instead of 18
-    uint32_t mx[3], my[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { mx[i] = part1by1((uint32_t)(px - 1 + i)); my[i] = part1by1((uint32_t)(py - 1 + i)) << 1; }
-    int segs[9], sege[9];
-    const size_t tbase = (size_t)b << (2 * nbits);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const int cy = py - 1 + q / 3, cx = px - 1 + q % 3;
-        segs[q] = sege[q] = 0;
-        if (cx >= 0 && cx < r && cy >= 0 && cy < r) {
-            const size_t obase = tbase + ((size_t)(mx[q % 3] | my[q / 3]) << (2 * level));
-            segs[q] = off0[obase]; sege[q] = off0[obase + ((size_t)1 << (2 * level))];
-        }
-    }
-    const int span = VEC << lg;
-    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
-        float acc[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int s = segs[q], e = sege[q];
-            for (int n = s; n < e; n += 2) {           // two rows in flight; a row that misses this pixel gets weight 0
-                const int n1 = min(n + 1, e - 1);
-                const int p0 = tap_pix[n], p1 = tap_pix[n1];
-                const float4 w40 = tap_w[n], w41 = tap_w[n1];
-                Vec<VEC> g0 = Vec<VEC>::load(gout + (size_t)n * C + c);
-                Vec<VEC> g1 = Vec<VEC>::load(gout + (size_t)n1 * C + c);
-                const float w0 = tap_weight(P - p0, r, w40);
-                const float w1 = (n + 1 < e) ? tap_weight(P - p1, r, w41) : 0.0f;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    acc[j] = __fadd_rn(acc[j], __fmul_rn(w0, g0.v[j]));
-                    acc[j] = __fadd_rn(acc[j], __fmul_rn(w1, g1.v[j]));
-                }
-            }
-        }
-        Vec<VEC> o;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
-        o.store(gplane + (((size_t)b * r + py) * r + px) * C + c);
-    }
-}
+// Measured alternatives to this gather at the fine levels (r02, N = 131072 clustered, C = 64, r = 256: 78 us here):
+//   * 8 x 8 pixel blocks accumulated in LDS, cells visited in nine colour phases so that no two lane groups touch one
+//     pixel at a time (rows read once, deterministic): 99-260 us -- nine dependent global-load rounds per workgroup with
+//     a handful of rows in flight each;
+//   * a per-point tap table (pixel of the north-west tap + the four weights) so that a visited row costs one compare
+//     chain instead of recomputing the taps: 103 us -- rocprofv3 shows ~2100 vector and ~90 load instructions per wave
+//     here, and the two extra loads per visited row cost more than the arithmetic they save.
+// What did pay: x * 0.5f instead of the IEEE division in unnormalize_clip (bit-identical), mostly in sample_fwd.
 
 // ------------------------------------------------------------------------------ coarse levels (many points / cell)
 // At coarse ALTO levels a cell holds tens to hundreds of points, so "one lane-group walks one cell" leaves the
@@ -838,7 +769,7 @@ constexpr int kSampleBwdMinPts = 6;   // the 3x3 gather re-reads rows ~9x: switc
 T2H_API size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C) {
     if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1) return 0;
     CoarsePlan p = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
-    if (!p.use) return (size_t)B * (N > 0 ? N : 0) * (sizeof(float4) + sizeof(int32_t)) + 16;      // the tap table
+    if (!p.use) return 0;
     return 9 * ((size_t)B << (2 * (nbits - level))) * p.S * C * sizeof(float);
 }
 
@@ -1014,27 +945,13 @@ T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const i
                            partial, B, nbits - level, C, g.lg, cp.S, gplane_nhwc);
         return check_launch("sample_bwd(coarse)");
     }
-    const int64_t npts = (int64_t)B * N;
-    if (npts == 0) {
-        if (hipMemsetAsync(gplane_nhwc, 0, (size_t)groups * C * sizeof(float), as_stream(stream)) != hipSuccess)
-            return check_launch("sample_bwd/memset");
-        return T2H_OK;
-    }
-    const size_t need = t2h_sample_bwd_workspace_bytes(B, N, nbits, level, C);
-    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15))
-        return fail(T2H_ERR_WORKSPACE, "sample_bwd: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
-    float4 *tap_w = static_cast<float4 *>(workspace);
-    int32_t *tap_pix = reinterpret_cast<int32_t *>(tap_w + npts);
-    hipLaunchKernelGGL(sample_taps_kernel, dim3((unsigned)((npts + kThreads - 1) / kThreads)), dim3(kThreads), 0, as_stream(stream),
-                       pts, dim, npts, 1 << (nbits - level), tap_pix, tap_w);
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
-          hipLaunchKernelGGL(sample_bwd_taps_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gout, tap_pix, tap_w, off0, B, nbits, level, C, g.lg, gplane_nhwc); },
+          hipLaunchKernelGGL(sample_bwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); },
         { GroupCfg g = group_cfg<1>(C);
-          hipLaunchKernelGGL(sample_bwd_taps_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gout, tap_pix, tap_w, off0, B, nbits, level, C, g.lg, gplane_nhwc); });
-    note_kernel("sample_bwd_taps_kernel");
+          hipLaunchKernelGGL(sample_bwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); });
     return check_launch("sample_bwd");
 }
 
