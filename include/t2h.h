@@ -287,6 +287,19 @@ int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_strea
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * nn.Conv2d(Cin <= 8, Cout, 3, padding=1): the image U-Net's first layer              encoder/unet.py:112-187
+ * (Conv2d(3, 32, ...) at 512 x 512: the one convolution of the image configs that t2h_conv3x3_* does not take --
+ * their reduction runs in 16-channel slabs).  NHWC activations, weight memory [Cout][3][3][Cin], Cout % 4 == 0, <= 64.
+ * flags: T2H_RELU_OUT (forward), T2H_ACCUM (dgrad / wgrad add to the destination).  Deterministic (slabs, no atomics). */
+int t2h_conv3x3_smallcin_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int Cin,
+                             int Cout, int flags, t2h_stream_t stream);
+int t2h_conv3x3_smallcin_dgrad(const float *dy, const float *w, float *dx, int B, int H, int W, int Cin, int Cout,
+                               int flags, t2h_stream_t stream);
+size_t t2h_conv3x3_smallcin_wgrad_workspace_bytes(int Cin, int Cout);
+int t2h_conv3x3_smallcin_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin,
+                               int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused PointNet trunk block, hidden_dim = 32               pointnet.py:72-82, 92-99; resnet.py:36-54
  * One launch per ResnetBlockFC(64 -> 32) over the cell-sorted rows:
  *     X   = [net_prev | pool_local(net_prev)]       (pts != NULL: X = fc_pos(pts) instead, pointnet.py:72)

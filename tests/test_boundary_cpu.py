@@ -137,6 +137,12 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),
         "t2h_tile_crop_finish": (n, n),
         "t2h_adamw_flat_step": (n, n, 4, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, 0, n),
+        "t2h_conv3x3_smallcin_fwd": (n, n, n, n, 1, 32, 32, 3, 32, 0, n),
+        "t2h_conv3x3_smallcin_dgrad": (n, n, n, 1, 32, 32, 3, 32, 0, n),
+        "t2h_conv3x3_smallcin_wgrad": (n, n, n, n, 1, 32, 32, 3, 32, 0, n, 0, n),
+        "t2h_trunk_block_fwd": (n, 3, n, n, n, 32, n, n, n, n, n, n, n, n, n, 100, n, n, n, n, 32, n, n, n),
+        "t2h_trunk_block_bwd": (n, 32, n, 32, n, n, n, n, n, n, n, n, 32, n, 32, n, 3, n, n, n, n, n, 100, n, n, 0, n),
+        "t2h_trunk_block_reduce": (n, 100, 0, 0, n, n, n, n, n, n, n, 0, n),
         "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }

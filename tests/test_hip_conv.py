@@ -373,3 +373,71 @@ def test_residual_addend_rides_the_epilogue(kind, cin, cout, hw):
     _close(rg.grad, rr.grad)
     _close(conv.weight.grad, ref.weight.grad)
     _close(conv.bias.grad, ref.bias.grad)
+
+
+# ------------------------------------------------------------------------------------------------ few input channels
+@pytest.mark.parametrize("b,h,w,cin,cout,relu", [(1, 64, 64, 3, 32, True), (2, 37, 50, 3, 32, False), (1, 512, 512, 3, 32, True),
+                                                 (1, 16, 16, 1, 8, True), (1, 40, 24, 8, 64, False)])
+def test_conv3x3_small_cin_vs_torch(b, h, w, cin, cout, relu):
+    """csrc/conv_small.hip (the image U-Net's Conv2d(3, 32, 3, padding=1), encoder/unet.py:112-187) against float64
+    F.conv2d: forward, input gradient, weight and bias gradient; and bit-reproducible."""
+    import torch.nn.functional as F
+    from tomosar2height_amd import grid
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(b * h + cin)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(b, cout, h, w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    assert grid.conv3x3_small_supported(x, conv)
+    y = grid.conv_bias_act(x, conv, relu=relu)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, bd, padding=1)
+    yd = torch.relu(yd) if relu else yd
+    yd.backward(gy.double())
+    for got, want, what in ((y, yd, "y"), (x.grad, xd.grad, "dx"), (conv.weight.grad, wd.grad, "dw"), (conv.bias.grad, bd.grad, "db")):
+        scale = want.abs().max().item() + 1e-30
+        assert (got.double() - want).abs().max().item() <= 2e-5 * scale, what
+    first = (conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.weight.grad = None; conv.bias.grad = None; x.grad = None
+    grid.conv_bias_act(x, conv, relu=relu).backward(gy)
+    assert torch.equal(first[0], conv.weight.grad) and torch.equal(first[1], conv.bias.grad)
+
+
+def test_no_library_fallback_on_the_reference_configurations():
+    """Berlin cloud-only and Munich cloud+image+footprint training steps take NO MIOpen / rocBLAS / ATen fallback (the
+    default policy would raise on one): every convolution incl. the image U-Net's 3-channel first layer, every Linear
+    and every pooling runs on libt2h_hip.so."""
+    import tomosar2height_amd as t2h
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config, munich_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    t2h.fallback_counts(reset=True)
+    for cfg, image, foot in ((berlin_config(), False, False), (munich_config(use_image=True), True, True)):
+        torch.manual_seed(1)
+        model = TomoSAR2Height(cfg).to(dev)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=2, use_cloud=True,
+                     use_image=image, use_footprint=foot)
+        tile = berlin_tile(3, n_points=5000, with_image=image)
+        for _ in range(2):
+            tr.train_step({k: v.to(dev) for k, v in tile.items() if k != "is_valid"})
+        torch.cuda.synchronize()
+    assert t2h.fallback_counts() == {}
+
+
+def test_unsupported_geometry_raises_unless_allowed():
+    import tomosar2height_amd as t2h
+    from tomosar2height_amd import _lib, grid
+    dev = torch.device("cuda:0")
+    conv = torch.nn.Conv2d(16, 16, 5, padding=2).to(dev)
+    x = torch.randn(1, 16, 32, 32, device=dev).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(_lib.T2HLibraryError, match="library fallbacks are off"):
+        grid.conv_bias_act(x, conv)
+    t2h.fallback_counts(reset=True)
+    with t2h.allow_library_fallback():
+        y = grid.conv_bias_act(x, conv)
+    assert y.shape == (1, 16, 32, 32) and sum(t2h.fallback_counts(reset=True).values()) == 1

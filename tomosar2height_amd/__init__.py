@@ -10,5 +10,6 @@ from .model import TomoSAR2Height
 from .decoder import decoder_dict
 from .encoder import encoder_dict
 from .tile import TileIndex
+from ._lib import allow_library_fallback, fallback_counts
 
-__all__ = ["TomoSAR2Height", "decoder_dict", "encoder_dict", "TileIndex"]
+__all__ = ["TomoSAR2Height", "decoder_dict", "encoder_dict", "TileIndex", "allow_library_fallback", "fallback_counts"]

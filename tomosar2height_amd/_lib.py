@@ -72,6 +72,10 @@ SIGNATURES = {
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),
     "t2h_tile_crop_normalise": (_i, [_vp, _i64] + [ctypes.c_double] * 7 + [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "t2h_tile_crop_finish": (_i, [_vp, _vp]),
+    "t2h_conv3x3_smallcin_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2h_conv3x3_smallcin_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2h_conv3x3_smallcin_wgrad_workspace_bytes": (_sz, [_i, _i]),
+    "t2h_conv3x3_smallcin_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_trunk_block_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp] + [_vp] * 7 + [_i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "t2h_trunk_block_bwd_workspace_bytes": (_sz, [_i64]),
     "t2h_trunk_block_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
@@ -90,6 +94,53 @@ _lib = None
 
 class T2HLibraryError(RuntimeError):
     pass
+
+
+# ---------------------------------------------------------------------------------------------- library fallbacks
+# A few shapes off the reference's default configurations have no t2h kernel (odd Linear widths of the per-pixel FC
+# decoder, convolutions other than 3x3/s1/p1, 1x1 and 2x2/s2-transposed, the NCHW grid side).  They used to run on
+# MIOpen / rocBLAS / ATen silently; now such a call RAISES unless fallbacks are allowed, and every fallback taken is
+# counted, so a regression that flips a layer of the default path onto a vendor library cannot pass the tests.
+_fallback_allowed = os.environ.get("T2H_ALLOW_LIBRARY_FALLBACK", "0") == "1"
+_fallback_counts = {}
+
+
+def library_fallback(what: str):
+    """Call right before computing with a vendor-library / ATen op in place of a t2h kernel."""
+    if not _fallback_allowed:
+        raise T2HLibraryError(
+            f"{what}: no t2h kernel covers this shape, and library fallbacks are off.  Wrap the call in "
+            "`with tomosar2height_amd.allow_library_fallback():` (or set T2H_ALLOW_LIBRARY_FALLBACK=1) to run it on "
+            "MIOpen / rocBLAS / ATen instead.")
+    _fallback_counts[what] = _fallback_counts.get(what, 0) + 1
+
+
+class allow_library_fallback:
+    """Context manager (or ``allow_library_fallback(True).set()`` for good): vendor-library fallbacks may be taken."""
+
+    def __init__(self, allowed: bool = True):
+        self.allowed = allowed
+
+    def set(self):
+        global _fallback_allowed
+        _fallback_allowed = self.allowed
+        return self
+
+    def __enter__(self):
+        global _fallback_allowed
+        self.prev, _fallback_allowed = _fallback_allowed, self.allowed
+        return self
+
+    def __exit__(self, *exc):
+        global _fallback_allowed
+        _fallback_allowed = self.prev
+
+
+def fallback_counts(reset: bool = False) -> dict:
+    out = dict(_fallback_counts)
+    if reset:
+        _fallback_counts.clear()
+    return out
 
 
 def load():

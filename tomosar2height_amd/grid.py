@@ -19,8 +19,15 @@ import torch.nn.functional as F
 
 from . import _lib, mlp
 
-# A/B switch: T2H_HIP_CONV=0 keeps every convolution on MIOpen
+# A/B switch: T2H_HIP_CONV=0 keeps every convolution on MIOpen (an explicit request, so it also allows the fallbacks)
 USE_HIP_CONV = os.environ.get("T2H_HIP_CONV", "1") != "0"
+if not USE_HIP_CONV:
+    _lib.allow_library_fallback(True).set()
+
+
+def fallback_count() -> int:
+    """Vendor-library / ATen fallbacks taken so far in this process (0 on the reference's default configurations)."""
+    return sum(_lib.fallback_counts().values())
 
 
 def is_cl(x: torch.Tensor) -> bool:
@@ -176,6 +183,63 @@ def _conv3x3_param_grads(gm, x, weight, bias):
     return dw, db
 
 
+# ------------------------------------------------------------------------------------------------ conv3x3, few input channels
+def conv3x3_small_supported(x: torch.Tensor, conv) -> bool:
+    """The image U-Net's first layer (encoder/unet.py:112-187: Conv2d(3, 32, 3, padding=1)): csrc/conv_small.hip."""
+    return (USE_HIP_CONV and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.in_channels <= 8 and conv.out_channels % 4 == 0 and conv.out_channels <= 64 and conv.bias is not None
+            and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32)
+
+
+class _Conv3x3Small(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool, grad_premasked: bool):
+        x = _as_cl(x)
+        w = _w_cl(weight)
+        b, cin, h, wd = x.shape
+        cout = w.shape[0]
+        y = _empty_cl(b, cout, h, wd, x.device)
+        _lib.call("t2h_conv3x3_smallcin_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), b, h, wd, cin, cout,
+                  _lib.RELU_OUT if relu else 0, _lib.stream(), nbytes=4 * (x.numel() + y.numel()),
+                  flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_smallcin_fwd[{cin}->{cout},{h}x{wd}]")
+        need_y = relu and not grad_premasked
+        ctx.save_for_backward(x, weight, bias, y if need_y else None)
+        ctx.conf = (relu, grad_premasked)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, y = ctx.saved_tensors
+        relu, grad_premasked = ctx.conf
+        g = _as_cl(g)
+        w = _w_cl(weight)
+        b, cin, h, wd = x.shape
+        cout = w.shape[0]
+        if relu and not grad_premasked:
+            gm = torch.empty_like(g, memory_format=torch.channels_last)
+            _lib.call("t2h_relu_mask", _lib.ptr(g), _lib.ptr(y), _lib.ptr(gm), g.numel(), _lib.stream(), nbytes=12 * g.numel())
+        else:
+            gm = g
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            _lib.call("t2h_conv3x3_smallcin_dgrad", _lib.ptr(gm), _lib.ptr(w), _lib.ptr(dx), b, h, wd, cin, cout, 0,
+                      _lib.stream(), nbytes=4 * (gm.numel() + dx.numel()), flops=2 * 9 * cin * cout * b * h * wd,
+                      tag=f"t2h_conv3x3_smallcin_dgrad[{cout}->{cin},{h}x{wd}]")
+        wg, bg = weight.grad, bias.grad
+        direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous() and bg is not None
+                  and bg.is_contiguous())
+        dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
+        db = bg if direct else torch.empty_like(bias)
+        nws = _lib.load().t2h_conv3x3_smallcin_wgrad_workspace_bytes(cin, cout)
+        ws = _lib.workspace(nws, g.device)
+        _lib.call("t2h_conv3x3_smallcin_wgrad", _lib.ptr(gm), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), b, h, wd, cin, cout,
+                  _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (gm.numel() + x.numel()),
+                  flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_smallcin_wgrad[{cin}->{cout},{h}x{wd}]")
+        return (dx, None, None, None, None) if direct else (dx, dw, db, None, None)
+
+
 def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True, mask_input: bool = False,
                   grad_premasked: bool = False) -> torch.Tensor:
     """``relu(conv(x))`` (or ``conv(x)``).  3x3 / stride 1 / padding 1 convs with 16-aligned channel counts run on the
@@ -183,8 +247,11 @@ def conv_bias_act(x: torch.Tensor, conv: torch.nn.Conv2d, relu: bool = True, mas
     fused into one pass each."""
     if conv3x3_supported(x, conv):
         return _Conv3x3.apply(x, conv.weight, conv.bias, relu, mask_input, grad_premasked)
+    if conv3x3_small_supported(x, conv) and not mask_input:
+        return _Conv3x3Small.apply(x, conv.weight, conv.bias, relu, grad_premasked)
     if mask_input or grad_premasked:
         raise ValueError("conv_bias_act: mask_input / grad_premasked need the HIP conv3x3 path")
+    _lib.library_fallback(f"conv2d {conv.in_channels}->{conv.out_channels} k{tuple(conv.kernel_size)} s{tuple(conv.stride)} (MIOpen)")
     if conv.bias is None or conv.out_channels % 4 or conv.groups != 1 or conv.dilation != (1, 1) or not x.is_cuda:
         y = conv(x)
         return F.relu(y) if relu else y
@@ -196,13 +263,18 @@ def conv3x3_chain(x: torch.Tensor, convs, relu_last: bool = True) -> torch.Tenso
     conv1 -> conv2 pairs of alto.py:98-99,226-227): each data gradient applies the previous ReLU's mask in its
     epilogue, so only the last ReLU needs a backward pass of its own."""
     convs = list(convs)
-    fused = all(conv3x3_supported(x, c) for c in convs)
+    # conv i applies the ReLU mask of its input in its data gradient (mask_input) iff it runs on the implicit-GEMM kernels;
+    # its producer (also a small-Cin first layer) then skips its own ReLU backward (grad_premasked)
+    cin, masks = x.shape[1], []
+    for c in convs:
+        probe = x if c.in_channels == x.shape[1] else x.new_empty((x.shape[0], c.in_channels, x.shape[2], x.shape[3]))
+        masks.append(conv3x3_supported(probe, c))
+    own = [masks[i] or conv3x3_small_supported(x, c) for i, c in enumerate(convs)]
     for i, conv in enumerate(convs):
         last = i == len(convs) - 1
-        if fused:
-            x = conv_bias_act(x, conv, relu=relu_last or not last, mask_input=i > 0, grad_premasked=not last)
-        else:
-            x = conv_bias_act(x, conv, relu=relu_last or not last)
+        mask_in = i > 0 and masks[i] and own[i - 1]
+        premasked = (not last) and own[i] and masks[i + 1]
+        x = conv_bias_act(x, conv, relu=relu_last or not last, mask_input=mask_in, grad_premasked=premasked)
     return x
 
 
@@ -264,6 +336,7 @@ def conv1x1(x: torch.Tensor, conv: torch.nn.Conv2d, addend: torch.Tensor = None)
           and conv.groups == 1 and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and x.is_cuda
           and x.dtype == torch.float32)
     if not ok:
+        _lib.library_fallback(f"conv1x1 {conv.in_channels}->{conv.out_channels} (MIOpen)")
         return conv(x) if addend is None else addend + conv(x)
     return _Conv1x1.apply(x, conv.weight, conv.bias, addend)
 
@@ -340,6 +413,7 @@ class _UpConv2x2(torch.autograd.Function):
 def upconv2x2(x: torch.Tensor, conv, addend: torch.Tensor = None) -> torch.Tensor:
     """``conv(x)`` or ``addend + conv(x)`` for the 2x2 stride-2 transposed convolutions of the ALTO up path."""
     if not upconv2x2_supported(x, conv):
+        _lib.library_fallback(f"conv_transpose2d {conv.in_channels}->{conv.out_channels} (MIOpen)")
         return conv(x) if addend is None else addend + conv(x)
     return _UpConv2x2.apply(x, conv.weight, conv.bias, addend)
 
@@ -494,6 +568,7 @@ def maxpool2x2(x: torch.Tensor, pool: torch.nn.MaxPool2d = None) -> torch.Tensor
         ok = ok and (k in (2, (2, 2))) and (st in (2, (2, 2))) and pool.padding in (0, (0, 0)) and not pool.ceil_mode \
             and pool.dilation in (1, (1, 1)) and not pool.return_indices
     if not ok:
+        _lib.library_fallback(f"max_pool2d on {tuple(x.shape)} (ATen)")
         return pool(x) if pool is not None else F.max_pool2d(x, 2, 2)
     return _MaxPool2x2.apply(x)
 

@@ -144,6 +144,7 @@ def _wgrad(dy, x, w, bias, relu_in=False):
     if w.shape[0] % 4 != 0:
         # odd output widths (the 1-channel head of the non-default per-pixel FC decoder, pixel.py:51) are off the
         # per-point hot path: library GEMM on the device
+        _lib.library_fallback(f"linear wgrad with {w.shape[0]} output column(s) (rocBLAS)")
         xa = torch.relu(x) if relu_in else x
         return dy.t() @ xa, (dy.sum(0) if bias is not None else None)
     dw = torch.empty_like(w, memory_format=torch.contiguous_format)
@@ -200,6 +201,7 @@ class _Linear(torch.autograd.Function):
             if w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0:
                 dx = linear_dgrad_(gy, w, torch.empty_like(x), mask=x if ctx.relu_in else None)
             else:   # odd widths never occur on the network's hot path; keep the generic seam correct
+                _lib.library_fallback(f"linear dgrad {w.shape[0]}->{w.shape[1]} (rocBLAS)")
                 dx = gy @ w
                 if ctx.relu_in:
                     dx = dx * (x > 0)

@@ -48,6 +48,7 @@ class TomoSAR2Height(nn.Module):
             self.image_encoder.set_channels_last(flag)
         if hasattr(self.decoder, "set_channels_last"):
             self.decoder.set_channels_last(flag)
+        self._channels_last = bool(flag)
         fmt = torch.channels_last if flag else torch.contiguous_format
         for m in self.modules():
             if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
@@ -67,6 +68,9 @@ class TomoSAR2Height(nn.Module):
 
     def forward(self, input_cloud=None, input_image=None):
         assert self.use_image or self.use_cloud, "At least one input modality must be used."
+        if not self._channels_last:
+            from . import _lib
+            _lib.library_fallback("NCHW grid side: convolutions on MIOpen (set_channels_last(False))")
         feature_planes = self.encode_inputs(input_cloud, input_image)
         pa, pb = self.decoder(feature_planes)
         return pa * self.z_scale, pb
