@@ -34,6 +34,16 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+@pytest.fixture(autouse=True)
+def _library_fallback_policy():
+    """Every test starts (and ends) with vendor-library fallbacks OFF: a layer of a default configuration that lands on
+    MIOpen / rocBLAS / ATen raises.  Tests of off-default shapes opt in with ``allow_library_fallback(...).set()``."""
+    from tomosar2height_amd import _lib
+    _lib.allow_library_fallback(False).set()
+    yield
+    _lib.allow_library_fallback(False).set()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

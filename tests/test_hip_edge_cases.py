@@ -119,6 +119,8 @@ def test_training_step_on_ragged_point_counts(channels_last):
     from tomosar2height_amd.config import berlin_config
     cfg = berlin_config()
     cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    import tomosar2height_amd as t2h
+    t2h.allow_library_fallback(not channels_last).set()        # the NCHW grid side is MIOpen's by definition
     ref = det_init_(torch_ref.TomoSAR2Height(cfg), seed=32)
     model = TomoSAR2Height(cfg)
     model.load_state_dict(ref.state_dict())

@@ -54,6 +54,8 @@ def test_pixelwise_decoder_golden(mode, foot, img):
     from tomosar2height_amd.decoder.pixel import PixelwiseDecoder
     g = load_golden("pixelwise_decoder")
     tag = f"{mode}_f{int(foot)}_i{int(img)}"
+    import tomosar2height_amd as t2h
+    t2h.allow_library_fallback(mode == "fc").set()     # the per-pixel FC head has a 1-column Linear (rocBLAS in its backward)
     dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode=mode, use_footprint=foot), seed=7)
     assert list(dec.state_dict()) == g[f"keys_{tag}"].tolist()
     dec.to(_dev())
@@ -89,6 +91,8 @@ def test_full_model_golden(tag, channels_last):
     """Full-size networks at N=4096 against the reference's own output (fixture 8 of SURVEY 8c)."""
     from tomosar2height_amd.trainer import Trainer
     g = load_golden(f"full_model_{tag}_n4096")
+    import tomosar2height_amd as t2h
+    t2h.allow_library_fallback(not channels_last).set()        # the NCHW grid side is MIOpen's by definition
     model, cfg = _full_model(tag)
     assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
     assert list(model.state_dict()) == g["state_keys"].tolist()
@@ -174,6 +178,8 @@ def test_trainer_accumulation_golden():
     from tomosar2height_amd.trainer import Trainer
     g = load_golden("trainer_accumulation")
     cfg = berlin_config()
+    import tomosar2height_amd as t2h
+    t2h.allow_library_fallback(True).set()             # reduced widths (start_filts = 8): below the kernels' 16-channel slabs
     cfg.model.encoder_kwargs.plane_resolution = 16
     cfg.model.encoder_kwargs.unet_kwargs.depth = 3
     cfg.model.encoder_kwargs.unet_kwargs.start_filts = 8

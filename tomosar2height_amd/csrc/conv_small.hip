@@ -100,8 +100,11 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float gt[TS * TS * kMaxCout];         // dy tile [pixel][co]
     const int tid = threadIdx.x, K = 9 * a.Cin, co4n = a.Cout / 4;
     const int tiles_x = (a.W + TS - 1) / TS, tiles_y = (a.H + TS - 1) / TS, n_tiles = a.B * tiles_x * tiles_y;
-    // thread -> (4 output channels, one (tap, ci)); K * Cout / 4 <= 27 * 16 = 432 pairs: up to two per thread
-    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    // thread -> (4 output channels, one (tap, ci)) pairs: K * Cout / 4 <= 72 * 16 = 1152, up to kPairs per thread
+    constexpr int kPairs = (9 * kMaxCin * (kMaxCout / 4) + 255) / 256;
+    float4 acc[kPairs];
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     float bacc = 0.0f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / (tiles_x * tiles_y), t = tile % (tiles_x * tiles_y);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallArgs a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kPairs; ++u) {
             const int pair = tid + u * 256;
             if (pair >= K * co4n) continue;
             const int c4 = pair / K, k = pair % K, tap = k / a.Cin, ci = k % a.Cin;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallArgs a) {
     float *slab = a.slab + (size_t)blockIdx.x * a.Cout * K;
     float *colslab = a.slab + (size_t)gridDim.x * a.Cout * K + (size_t)blockIdx.x * a.Cout;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kPairs; ++u) {
         const int pair = tid + u * 256;
         if (pair >= K * co4n) continue;
         const int c4 = pair / K, k = pair % K;
