@@ -335,6 +335,8 @@ def main():
     from tomosar2height_amd.synthetic import berlin_tile
     from tomosar2height_amd.trainer import Trainer, broadcast_parameters
 
+    if not args.channels_last:
+        _lib.allow_library_fallback(True).set()       # the NCHW grid side is MIOpen's by definition (A/B runs only)
     if args.mode == "infer":
         return infer_bench(args, world, rank, dev, group)
 
