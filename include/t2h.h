@@ -280,6 +280,19 @@ int t2h_tile_crop_normalise(const double *chunk, int64_t P, double min_x, double
                             int32_t *count, double *z_shift, void *workspace, size_t workspace_bytes,
                             t2h_stream_t stream);
 int t2h_tile_crop_finish(double *z_shift, t2h_stream_t stream);
+/* The same with the training augmentation of dataset.py:253-270: rot_times in 0..3 quarter turns (clockwise about z, in
+ * the centred tile frame), then flip_dim -1 (none) / 0 (x := -x) / 1 (y := -y); (0, -1) is t2h_tile_crop_normalise. */
+int t2h_tile_crop_normalise_aug(const double *chunk, int64_t P, double min_x, double min_y, double max_x, double max_y,
+                                double scale_x, double scale_y, double scale_z, int rot_times, int flip_dim, float *out,
+                                int32_t *src_index, int32_t *count, double *z_shift, void *workspace,
+                                size_t workspace_bytes, t2h_stream_t stream);
+
+/* Raster half of the tile (dataset.py:291-328): the DSM target / satellite image patch of a raster resident in HBM.
+ * raster [C, H, W] (float32, or float64 when is_f64: the mean/std-normalised image is held in double by the reference);
+ * out [C, ph, pw] float32 = raster[:, row0:row0+ph, col0:col0+pw] .rot90(rot_times, [-1, -2]) .flip(-1 if flip_dim == 0,
+ * -2 if flip_dim == 1) .float() .flip(-2)  -- one gather through the composed index map. */
+int t2h_raster_patch(const void *raster, int is_f64, int C, int H, int W, int row0, int col0, int ph, int pw,
+                     int rot_times, int flip_dim, float *out, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout glue between the conv side (NCHW) and the point side (NHWC): [B, C, P] <-> [B, P, C]. */

@@ -6,7 +6,7 @@ tests/golden/tile_producer.npz, produced with the reference's own crop_pc_2d / i
 import numpy as np
 
 
-def produce_tile(chunk, anchor, patch_size=(512.0, 512.0), z_span=190.2):
+def produce_tile(chunk, anchor, patch_size=(512.0, 512.0), z_span=190.2, rot_times=0, flip_dim=-1):
     chunk = np.asarray(chunk, np.float64)
     lo = np.asarray(anchor, np.float64)
     hi = lo + np.asarray(patch_size, np.float64)
@@ -17,7 +17,27 @@ def produce_tile(chunk, anchor, patch_size=(512.0, 512.0), z_span=190.2):
     pts = chunk[idx]
     z_shift = pts[:, 2].min()
     centre = (lo + hi) / 2.0
-    norm = np.stack([(pts[:, 0] - centre[0]) / patch_size[0] + 0.5, (pts[:, 1] - centre[1]) / patch_size[1] + 0.5,
-                     (pts[:, 2] - z_shift) / z_span], 1).astype(np.float32)
+    u, v = (pts[:, 0] - centre[0]) / patch_size[0], (pts[:, 1] - centre[1]) / patch_size[1]
+    for _ in range(rot_times):            # flip_mat @ rot_mat of dataset.py:253-269: -90 deg about z per step, then the flip
+        u, v = v, -u
+    if flip_dim == 0:
+        u = -u
+    if flip_dim == 1:
+        v = -v
+    norm = np.stack([u + 0.5, v + 0.5, (pts[:, 2] - z_shift) / z_span], 1).astype(np.float32)
     keep = (norm[:, 0] > 0) & (norm[:, 0] < 1) & (norm[:, 1] > 0) & (norm[:, 1] < 1)
     return idx[keep], norm[keep], z_shift
+
+
+def raster_patch(raster, row, col, shape, rot_times=0, flip_dim=-1):
+    """dataset.py:296-328: raster [C, H, W]; (col, row) = pixel of the window's bottom-left corner; the patch's rows end at
+    `row` (rasters are north-up); quarter turns in the (W, H) plane, the augmentation flip, float32, south row first."""
+    raster = np.asarray(raster)
+    t = raster[:, row - shape[0] + 1:row + 1, col:col + shape[1]]
+    if rot_times > 0:
+        t = np.rot90(t, rot_times, axes=(-1, -2))
+    if flip_dim == 0:
+        t = t[:, :, ::-1]
+    if flip_dim == 1:
+        t = t[:, ::-1, :]
+    return np.ascontiguousarray(t.astype(np.float32)[:, ::-1, :])

@@ -321,10 +321,81 @@ def tile_producer_fixture():
     save("tile_producer", **arrs)
 
 
+def _rotation_z(angle):
+    """`transformations.rotation_matrix(angle, [0, 0, 1])` (dataset.py:30-35; the package is absent here, so its published
+    formula is restated: R = cos I + (1 - cos) n n^T + sin [n]x with math.sin / math.cos -- cos(-pi/2) is 6e-17, not 0)."""
+    import math
+    sina, cosa = math.sin(angle), math.cos(angle)
+    m = torch.eye(4, dtype=torch.float64)
+    m[0, 0], m[0, 1], m[1, 0], m[1, 1] = cosa, -sina, sina, cosa
+    return m
+
+
+def _reflection(axis):
+    """`transformations.reflection_matrix(origin, axis)` = I - 2 n n^T for a plane through the origin (dataset.py:38-42)."""
+    m = torch.eye(4, dtype=torch.float64)
+    m[axis, axis] = -1.0
+    return m
+
+
+def tile_producer_aug_fixture():
+    """(12) TomoSARDataset.__getitem__ with augmentation (dataset.py:253-328): points through the reference's own
+    crop_pc_2d / invert_transform / apply_transform with flip_mat @ rot_mat for every (rot_times, flip_dim); the DSM and
+    image patches through the torch indexing expressions of dataset.py:296-328 (slice, rot90(k, [-1, -2]), flip, .float(),
+    .flip(-2))."""
+    import math
+    import_reference()
+    from utils import crop_pc_2d, invert_transform, apply_transform
+    g = torch.Generator().manual_seed(12)
+    p = 1500
+    chunk = torch.stack([1000.0 + torch.rand(p, generator=g, dtype=torch.float64) * 900.0,
+                         2000.0 + torch.rand(p, generator=g, dtype=torch.float64) * 900.0,
+                         10.0 + torch.rand(p, generator=g, dtype=torch.float64) * 50.0], 1)
+    anchor = torch.tensor([1200.0, 2150.0], dtype=torch.float64)
+    patch_size = torch.tensor([512.0, 512.0], dtype=torch.float64)
+    z_bound = [-33.7, 156.5]
+    scale_mat = torch.diag(torch.tensor([512.0, 512.0, z_bound[1] - z_bound[0], 1], dtype=torch.float64))
+    shift_norm = torch.cat([torch.eye(4, 3, dtype=torch.float64), torch.tensor([0.5, 0.5, 0, 1]).reshape(-1, 1)], 1)
+    rot_mat_dic = {k: (torch.eye(4).double() if k == 0 else _rotation_z(-90.0 * k * math.pi / 180.0)) for k in range(4)}
+    flip_mat_dic = {-1: torch.eye(4).double(), 0: _reflection(0), 1: _reflection(1)}
+    dsm_data = torch.rand(40, 48, generator=g) * 30.0                                   # float32 raster (dataset.py:133)
+    image = (torch.randint(0, 2048, (3, 40, 48), generator=g).double() - 500.0) / 300.0   # (int - mean) / std, float64 (:113)
+    row, col, shape = 25, 7, (16, 16)
+    arrs = {"chunk": chunk, "anchor": anchor, "dsm_data": dsm_data, "image": image, "row_col_shape": np.array([row, col, 16, 16])}
+    min_bound, max_bound = anchor, anchor + patch_size
+    inputs, index = crop_pc_2d(chunk, min_bound, max_bound)
+    z_shift = torch.min(inputs[:, 2]).double().reshape(1)
+    for rot_times in range(4):
+        for flip_dim in (-1, 0, 1):
+            tag = f"r{rot_times}_f{flip_dim + 1}"
+            transform_mat = scale_mat.clone()
+            transform_mat[0:3, 3] = torch.cat([(min_bound + max_bound) / 2., z_shift], 0)
+            normalize_mat = shift_norm.double() @ flip_mat_dic[flip_dim].double() @ rot_mat_dic[rot_times].double() \
+                @ invert_transform(transform_mat).double()                                       # dataset.py:268-269
+            inputs_norm = apply_transform(inputs, normalize_mat).float()
+            inputs_norm, index2 = crop_pc_2d(inputs_norm, [0.0, 0.0], [1.0, 1.0])
+            arrs[f"index_{tag}"] = index[index2]
+            arrs[f"inputs_{tag}"] = inputs_norm
+            for name, src in (("dsm", dsm_data[None]), ("image", image)):
+                t = src[:, row - shape[0] + 1:row + 1, col:col + shape[1]]                        # dataset.py:299-300, 316
+                if rot_times > 0:
+                    t = t.rot90(rot_times, [-1, -2])
+                if flip_dim == 0:
+                    t = t.flip(-1)
+                if flip_dim == 1:
+                    t = t.flip(-2)
+                arrs[f"{name}_{tag}"] = t.float().flip(-2)                                        # :310, :328
+    save("tile_producer_aug", **arrs)
+
+
 if __name__ == "__main__":
+    if "--only-aug" in sys.argv:
+        tile_producer_aug_fixture()
+        sys.exit(0)
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         main()
     if "--only-producer" not in sys.argv:
         blend_weight_fixture()
     if "--only-blend" not in sys.argv:
         tile_producer_fixture()
+        tile_producer_aug_fixture()

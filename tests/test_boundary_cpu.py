@@ -136,6 +136,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_mosaic_finalize": (n, n, 100, n),
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),
         "t2h_tile_crop_finish": (n, n),
+        "t2h_tile_crop_normalise_aug": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, 0, -1, n, n, n, n, n, 0, n),
+        "t2h_raster_patch": (n, 0, 1, 64, 64, 0, 0, 16, 16, 0, -1, n, n),
         "t2h_adamw_flat_step": (n, n, 4, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, 0, n),
         "t2h_conv3x3_smallcin_fwd": (n, n, n, n, 1, 32, 32, 3, 32, 0, n),
         "t2h_conv3x3_smallcin_dgrad": (n, n, n, 1, 32, 32, 3, 32, 0, n),

@@ -62,3 +62,52 @@ def test_device_producer_matches_fixture_and_feeds_the_model():
     from tomosar2height_amd.tile import TileIndex
     t = TileIndex(tile["inputs"], 256)
     assert t.out_of_domain() == 0 and t.n_points == idx.size
+
+
+AUG = [(r, f) for r in range(4) for f in (-1, 0, 1)]
+
+
+def test_oracle_augmentation_matches_reference_fixture():
+    """flip_mat @ rot_mat on the points and rot90 / flip on the rasters (dataset.py:253-328) against the fixture composed
+    from the reference's own utilities."""
+    g = load_golden("tile_producer_aug")
+    row, col, ph, pw = (int(v) for v in g["row_col_shape"])
+    for rot, flip in AUG:
+        tag = f"r{rot}_f{flip + 1}"
+        idx, pts, _ = producer_ref.produce_tile(g["chunk"], g["anchor"], z_span=Z_SPAN, rot_times=rot, flip_dim=flip)
+        assert np.array_equal(idx, g[f"index_{tag}"]), tag
+        _ulp_close(pts, g[f"inputs_{tag}"])
+        assert np.array_equal(producer_ref.raster_patch(g["dsm_data"][None], row, col, (ph, pw), rot, flip), g[f"dsm_{tag}"]), tag
+        assert np.array_equal(producer_ref.raster_patch(g["image"], row, col, (ph, pw), rot, flip), g[f"image_{tag}"]), tag
+
+
+@pytest.mark.gpu
+def test_device_augmented_tiles_match_fixture():
+    from tomosar2height_amd.producer import RasterPatcher, TileProducer, TileSource
+    g = load_golden("tile_producer_aug")
+    dev = torch.device("cuda:0")
+    row, col, ph, pw = (int(v) for v in g["row_col_shape"])
+    prod = TileProducer(torch.from_numpy(g["chunk"]).to(dev))
+    # a raster whose pixel (row, col) holds the window's bottom-left corner: 32 m pixels, 16 x 16 pixel patches
+    px = 32.0
+    left, top = float(g["anchor"][0]) - col * px, float(g["anchor"][1]) + (row + 1) * px
+    dsm = RasterPatcher(torch.from_numpy(g["dsm_data"]).to(dev), left, top, (px, px))
+    img = RasterPatcher(torch.from_numpy(g["image"]).to(dev), left, top, (px, px))
+    assert dsm.patch_shape == (ph, pw) and dsm.query_col_row(float(g["anchor"][0]) + px / 2, float(g["anchor"][1]) + px / 2) == (col, row)
+    for rot, flip in AUG:
+        tag = f"r{rot}_f{flip + 1}"
+        tile = prod.crop(g["anchor"], with_index=True, rot_times=rot, flip_dim=flip)
+        assert np.array_equal(tile["index"].cpu().numpy(), g[f"index_{tag}"]), tag
+        _ulp_close(tile["inputs"][0].cpu().numpy(), g[f"inputs_{tag}"])
+        assert np.array_equal(dsm.patch(g["anchor"], rot, flip).cpu().numpy(), g[f"dsm_{tag}"]), tag
+        assert np.array_equal(img.patch(g["anchor"], rot, flip).cpu().numpy(), g[f"image_{tag}"]), tag
+
+    class _Fixed:                         # the augmentation draw of dataset.py:253-263, pinned
+        def __init__(self, seq): self.seq = list(seq)
+        def choice(self, n): return self.seq.pop(0)
+    src = TileSource(prod, dsm, img, flip_augm=True, rotate_augm=True, rng=_Fixed([3, 1]))     # rot 3, flip key index 1 -> 0
+    t = src.get(g["anchor"])
+    assert (t["rotate"], t["flip"]) == (3, 0) and t["dsm"].shape == (1, ph, pw) and t["image"].shape == (1, 3, ph, pw)
+    assert np.array_equal(t["dsm"].cpu().numpy(), g["dsm_r3_f1"]) and np.array_equal(t["image"][0].cpu().numpy(), g["image_r3_f1"])
+    with pytest.raises(RuntimeError, match="leave the"):
+        dsm.patch((left - 10 * px, float(g["anchor"][1])))

@@ -72,6 +72,8 @@ SIGNATURES = {
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),
     "t2h_tile_crop_normalise": (_i, [_vp, _i64] + [ctypes.c_double] * 7 + [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "t2h_tile_crop_finish": (_i, [_vp, _vp]),
+    "t2h_tile_crop_normalise_aug": (_i, [_vp, _i64] + [ctypes.c_double] * 7 + [_i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_raster_patch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_conv3x3_smallcin_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_conv3x3_smallcin_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_conv3x3_smallcin_wgrad_workspace_bytes": (_sz, [_i, _i]),
