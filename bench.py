@@ -455,7 +455,8 @@ def main():
                 out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps; "
                                           "class totals: sum(algorithmic flops or bytes) / sum(duration)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
-                out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n)) for n in SCATTER_REDUCE_TAGS if n in named]
+                out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"])))
+                                                  for n in SCATTER_REDUCE_TAGS if n in named]
                 out["roofline_top_symbols"] = [{"kernel": s["kernel"][:60], "ms_per_step": s["ms_per_step"], "frac": s["frac"],
                                                 "bound": s["bound"]} for s in syms[:6]]
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in tags), 3)

@@ -1,87 +1,108 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc passes over profiles/pmc_probe.py (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_traffic.json.
+"""HBM traffic per launch from rocprofv3 PMC passes -> profiles/pmc_traffic.json (read by bench.py for `roofline.traffic`).
 
-Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-byte
-streaming stores.  Per launch = mean over the probe's repetitions; ops made of two kernels are summed."""
+Two sources, each collected as two separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
+
+  bench passes  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d F -- python3 bench.py --steps 6 --warmup 3 \
+                    --skip-cpu-baseline --profile-steps 0        (and the same with WRITE_SIZE -> W)
+                -> per DEVICE KERNEL SYMBOL, mean over the launches of the last tile-steps (steady state, delimited by
+                   tile_keys_kernel): the key bench.py's `roofline` uses (t2h_last_kernel_name), e.g. gemm_dma_kernel
+  probe passes  the same two passes over profiles/pmc_probe.py -> per ENTRY-POINT TAG for ops that share a kernel
+                symbol across shapes (the largest scatter_mean, the coarse sample kernels)
+
+    python profiles/collect_pmc.py --bench F W [--probe PF PW]
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-byte streaming
+stores: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+import argparse
 import collections
 import csv
 import glob
 import json
 import os
-import sys
+import re
 
-OPS = {   # bench.py kernel tag -> kernel-name substrings that make up one launch of the op ("#k": k-th probe op using it)
-    "t2h_linear_fwd[K=512,N=1024]": ["gemm_dma_kernel"],
-    "t2h_linear_fwd[K=1024,N=512]": ["gemm_dma_kernel#2"],
-    "t2h_linear_dgrad[N=1024,K=512]": ["gemm_dma_nn_kernel"],
-    "t2h_linear_dgrad[N=512,K=1024]": ["gemm_dma_nn_kernel#2"],
-    "t2h_linear_wgrad[N=1024,K=512]": ["gemm_kernel<128, 128, 2, 2, false, false", "reduce_slabs_kernel"],
-    "t2h_linear_wgrad[N=512,K=1024]": ["gemm_kernel<128, 128, 2, 2, false, false#2", "reduce_slabs_kernel#2"],
+PROBE_OPS = {   # bench.py tag -> kernel-name substrings of one launch of the op, in the probe's order
     "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],
-    "t2h_pool_max_fwd": ["pool_max_fwd_kernel"],
     "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
     "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_kernel", "sample_bwd_gather9_kernel"],
-    "t2h_conv3x3_fwd[64->128,512x512]": ["conv_rows_kernel<128, 2, 2, 0"],
-    "t2h_conv3x3_dgrad[128->64,512x512]": ["conv_rows_kernel<64, 2, 2, 1"],
-    "t2h_conv3x3_wgrad[64->128,512x512]": ["conv_wgrad_kernel<128, 128, 2, 2, 4, false", "reduce_slabs_kernel#3"],
 }
+# entry points of point_grid.hip do not note a kernel symbol: bench.py keys them by entry-point name
+ENTRY_OF = {"sample_fwd_kernel": "t2h_sample_fwd", "segmean_bwd_kernel": "t2h_segmean_bwd"}
 
 
-REPS = 3      # profiles/pmc_probe.py runs every op this many times, one launch of each kernel per run
+def short(name):
+    """rocprofv3's demangled name -> the symbol t2h_last_kernel_name() reports."""
+    n = re.sub(r"\(.*$", "", name)                         # argument list
+    n = n.replace("void ", "").replace("t2h::", "").replace("(anonymous namespace)::", "").replace(" ", "")
+    return n
 
 
-def read_counter(folder, counter):
-    """mean counter value per kernel name; a kernel that serves several probe ops (REPS dispatches each) is split by
-    dispatch order into name, name#2, name#3 ..."""
+def rows_of(folder, counter):
     rows = []
     for path in glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    seen, sums, counts = collections.defaultdict(int), collections.defaultdict(float), collections.defaultdict(int)
+    return rows
+
+
+def steady(rows, steps):
+    starts = [i for i, r in enumerate(rows) if "tile_keys_kernel" in r["Kernel_Name"]]
+    if len(starts) <= steps:
+        return rows
+    return rows[starts[-(steps + 1)]:starts[-1]]
+
+
+def mean_by(rows, key):
+    s, c = collections.defaultdict(float), collections.defaultdict(int)
     for r in rows:
-        name = r["Kernel_Name"]
-        group = seen[name] // REPS
-        seen[name] += 1
-        key = name if group == 0 else f"{name}#{group + 1}"
-        sums[key] += float(r["Counter_Value"])
-        counts[key] += 1
-    return {k: sums[k] / counts[k] for k in sums}, counts
-
-
-def _suffix(key):
-    return int(key.rsplit("#", 1)[1]) if "#" in key and key.rsplit("#", 1)[1].isdigit() else 1
+        k = key(r["Kernel_Name"])
+        s[k] += float(r["Counter_Value"])
+        c[k] += 1
+    return {k: s[k] / c[k] for k in s}, c
 
 
 def main():
-    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    fetch, nf = read_counter(fetch_dir, "FETCH_SIZE")
-    write, nw = read_counter(write_dir, "WRITE_SIZE")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bench", nargs=2, metavar=("FETCH_DIR", "WRITE_DIR"))
+    ap.add_argument("--probe", nargs=2, metavar=("FETCH_DIR", "WRITE_DIR"))
+    ap.add_argument("--steps", type=int, default=4)
+    a = ap.parse_args()
     out, detail = {}, {}
-    for tag, parts in OPS.items():
-        total, rows = 0.0, []
-        for sub in parts:
-            want = _suffix(sub)
-            stem = sub.rsplit("#", 1)[0] if want > 1 else sub
-            kf = [k for k in fetch if stem in k and _suffix(k) == want]
-            kw = [k for k in write if stem in k and _suffix(k) == want]
-            if not kf or not kw:
-                total = None
-                break
-            f_kib = max(fetch[k] for k in kf)
-            w_kib = max(write[k] for k in kw)
-            rows.append({"kernel": sub, "FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib})
-            total += (2.0 * f_kib + w_kib) * 1024.0
-        if total is not None:
-            out[tag] = int(total)
-            detail[tag] = rows
+    if a.bench:
+        f, nf = mean_by(steady(rows_of(a.bench[0], "FETCH_SIZE"), a.steps), short)
+        w, _ = mean_by(steady(rows_of(a.bench[1], "WRITE_SIZE"), a.steps), short)
+        for k in f:
+            if k in w:
+                out[k] = int((2.0 * f[k] + w[k]) * 1024.0)
+                detail[k] = {"FETCH_SIZE_KiB": round(f[k], 1), "WRITE_SIZE_KiB": round(w[k], 1),
+                             "launches_per_step": round(nf[k] / a.steps, 2), "source": "bench.py steady state"}
+                if k.split("<")[0] in ENTRY_OF:
+                    out[ENTRY_OF[k.split("<")[0]]] = out[k]
+    if a.probe:
+        fr, wr = rows_of(a.probe[0], "FETCH_SIZE"), rows_of(a.probe[1], "WRITE_SIZE")
+        f, _ = mean_by(fr, lambda n: n)
+        w, _ = mean_by(wr, lambda n: n)
+        for tag, parts in PROBE_OPS.items():
+            total, rows = 0.0, []
+            for sub in parts:
+                kf, kw = [k for k in f if sub in k], [k for k in w if sub in k]
+                if not kf or not kw:
+                    total = None
+                    break
+                rows.append({"kernel": sub, "FETCH_SIZE_KiB": round(f[kf[0]], 1), "WRITE_SIZE_KiB": round(w[kw[0]], 1)})
+                total += (2.0 * f[kf[0]] + w[kw[0]]) * 1024.0
+            if total is not None:
+                out[tag] = int(total)
+                detail[tag] = {"parts": rows, "source": "profiles/pmc_probe.py"}
     here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "pmc_traffic.json"), "w") as f:
-        json.dump({"workload": "BASELINE.json configs[1], N=131072, profiles/pmc_probe.py",
+    with open(os.path.join(here, "pmc_traffic.json"), "w") as fjs:
+        json.dump({"workload": "BASELINE.json configs[1], N=131072",
                    "formula": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts half of wide reads)",
-                   "bytes_per_launch": out, "detail": detail}, f, indent=1)
-    for k, v in out.items():
-        print(f"{k:<36s} {v / 1e6:10.1f} MB / launch")
+                   "bytes_per_launch": out, "detail": detail}, fjs, indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1])[:40]:
+        print(f"{k:<60s} {v / 1e6:10.1f} MB / launch")
 
 
 if __name__ == "__main__":
