@@ -34,9 +34,9 @@ ENTRY_OF = {"sample_fwd_kernel": "t2h_sample_fwd", "segmean_bwd_kernel": "t2h_se
 
 def short(name):
     """rocprofv3's demangled name -> the symbol t2h_last_kernel_name() reports."""
-    n = re.sub(r"\(.*$", "", name)                         # argument list
-    n = n.replace("void ", "").replace("t2h::", "").replace("(anonymous namespace)::", "").replace(" ", "")
-    return n
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = re.sub(r"\(.*$", "", n)                            # argument list
+    return n.replace("t2h::", "").replace(" ", "")
 
 
 def rows_of(folder, counter):
