@@ -82,4 +82,23 @@ if args.only in ("", "conv"):
             us = timed(fn)
             total += us * calls
             report(f"conv3x3_{name}[{cin}->{cout},{h}x{h}] x{calls}", us, fl)
+if args.only in ("", "upconv"):
+    # (Cin, Cout, H of the INPUT plane, calls per step) of the 2x2 stride-2 transposed convolutions (alto.py:175,215-218)
+    from tomosar2height_amd import _lib
+    for cin, cout, h, calls in [(512, 256, 32, 2), (256, 128, 64, 2), (128, 64, 128, 2)]:
+        x, gy = cl(rnd(1, cin, h, h)), cl(rnd(1, cout, 2 * h, 2 * h))
+        w = (rnd(cin, cout, 2, 2) / (4 * cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+        b = rnd(cout)
+        y, dx, dw = grid._empty_cl(1, cout, 2 * h, 2 * h, dev), grid._empty_cl(1, cin, h, h, dev), torch.empty_like(w)
+        lib = _lib.load()
+        ws_d = _lib.workspace(lib.t2h_upconv2x2_dgrad_workspace_bytes(1, h, h, cin, cout), dev)
+        ws_w = _lib.workspace(lib.t2h_upconv2x2_wgrad_workspace_bytes(1, h, h, cin, cout), dev)
+        fl = 2.0 * 4 * cin * cout * h * h
+        for name, fn in (
+                ("fwd", lambda: _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
+                ("dgrad", lambda: _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_d), ws_d.numel(), _lib.stream())),
+                ("wgrad", lambda: _lib.call("t2h_upconv2x2_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), 1, h, h, cin, cout, 0, _lib.ptr(ws_w), ws_w.numel(), _lib.stream()))):
+            us = timed(fn)
+            total += us * calls
+            report(f"upconv2x2_{name}[{cin}->{cout},{h}x{h}] x{calls}", us, fl)
 print(f"sum over one step's calls: {total / 1e3:.2f} ms")

@@ -423,7 +423,13 @@ template <int GEOM>
 RowsPlan rows_plan_for(long long M, int Cin, int Cout) {
     RowsShape sh = rows_shape<GEOM>(Cin, Cout);
     RowsPlan r = rows_plan(M, sh.N, sh.K);
-    if (GEOM == G_UP_FWD && r.splits > 1) { r.splits = 1; r.k_chunk = sh.K; }     // scattering epilogue: no slabs
+    if (GEOM == G_UP_FWD && r.splits > 1) {
+        // scattering epilogue: no slabs, so parallelism can only come from narrower column tiles (a 32 x 32 plane with
+        // 512 -> 256 channels is a 1024 x 1024 x 512 GEMM: 64 tiles of 128 x 128 would occupy a quarter of the CUs)
+        r.splits = 1; r.k_chunk = sh.K;
+        const long long row_tiles = (M + 127) / 128;
+        while (r.bn > 32 && row_tiles * ((sh.N + r.bn - 1) / r.bn) < 256) r.bn >>= 1;
+    }
     return r;
 }
 
