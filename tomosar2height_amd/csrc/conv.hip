@@ -22,6 +22,7 @@
 // coordinates kept in registers, out-of-image taps read as zero).  Small planes with many channels (32^2 x 512: 32
 // output tiles) split the reduction over grid.z into slabs in caller workspace, summed in a fixed order by the
 // epilogue kernel (bias / ReLU / mask / accumulate applied there) -- deterministic, no atomics.
+#include <stdlib.h>
 #include <string>
 #include "t2h_common.h"
 #include "gemm_args.h"
@@ -381,6 +382,9 @@ struct RowsPlan { int bn, splits, k_chunk; };
 RowsPlan rows_plan(long long M, int N, int K) {
     RowsPlan r{};
     r.bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    // (narrower column tiles before splitting the reduction were A/B'd for the 32^2-128^2 planes in r02: 5.58 -> 5.61-5.66 ms
+    // over the step's 3x3 layers, so the 128-wide tile + split reduction stays; only the transposed-conv forward, which
+    // cannot split, narrows its tiles -- rows_plan_for)
     const long long tiles = ((M + 127) / 128) * ((N + r.bn - 1) / r.bn);
     const int nk = K / BK;
     int splits = 1;
