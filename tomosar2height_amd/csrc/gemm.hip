@@ -415,6 +415,8 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
     if (mode == 2) return launch_rows_p<B_KC, 2>(a, s, what);
     if (mode == 1) return launch_rows_p<B_KC, 1>(a, s, what);
     static const bool use_dma = !(getenv("T2H_GEMM_DMA") && getenv("T2H_GEMM_DMA")[0] == '0');
+    // (r02 A/B: 128 x 64 tiles for the 128- / 256-wide layers -- twice the workgroups, VERDICT r01 item 6 -- lose 5-14 % on
+    // the forward and gain 10 % only on the data gradient into 256 columns from a 128-long reduction; not adopted)
     if (use_dma && gemm_dma_applicable(B_KC, a)) return launch_gemm_dma(B_KC, a, s, what);
     return launch_rows_p<B_KC, 0>(a, s, what);
 }
