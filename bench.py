@@ -81,9 +81,10 @@ def parse():
                     help="train the cloud+image network (BASELINE configs[2] with --mlp-precision bf16): image U-Net encoder on")
     ap.add_argument("--uniform-xy", action="store_true", help="no-skew control: all points uniform in the tile (SURVEY 8d)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (gloo smoke test only)")
-    ap.add_argument("--check-dp", action="store_true",
+    ap.add_argument("--check-dp", type=int, default=-1,
                     help="SURVEY 8e equivalence check: the W-rank accumulated + all-reduced gradient of 2W fixed tiles vs "
-                         "the same tiles accumulated by one rank alone; reports max_rel_diff, allreduce_ms, rccl_ranks")
+                         "the same tiles accumulated by one rank alone; reports max_rel_diff, allreduce_ms, rccl_ranks.  "
+                         "-1 (default): on whenever N > 1 (it runs after the timed region and costs < 1 s), 0 / 1: off / on")
     ap.add_argument("--fused-optimizer", type=int, default=1, help="1 = t2h flat-bucket AdamW kernel, 0 = torch.optim.AdamW")
     return ap.parse_args()
 
@@ -419,7 +420,12 @@ def main():
     fence()
     boundary_ms = eb.elapsed_time(ee)
 
-    dp = check_dp(args, world, rank, dev, group, model, make_trainer) if args.check_dp else None
+    dp = None
+    if args.check_dp == 1 or (args.check_dp < 0 and world > 1):
+        try:
+            dp = check_dp(args, world, rank, dev, group, model, make_trainer)
+        except Exception as e:          # the headline line must survive a failing diagnostic (every rank fails alike or the
+            dp = {"error": f"{type(e).__name__}: {e}"[:300]}      # collective inside raises on all of them)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -439,6 +445,7 @@ def main():
                        "optimizer_steps_in_timed_region": timed_optimizer_steps, "optimizer": opt_name,
                        "optimizer_boundary_ms": round(boundary_ms, 3),
                        "parallelism": f"dp{world}", "collective": (dist.get_backend(group) if world > 1 else None),
+                       "rccl_ranks": world if (world > 1 and dist.get_backend(group) == "nccl") else 0,
                        "channels_last": bool(args.channels_last),
                        "point_distribution": "uniform (no-skew control)" if args.uniform_xy else "70 % in 160 buildings + 30 % uniform",
                        "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",

@@ -63,12 +63,13 @@ def test_multi_rank_mosaic_equals_single(tmp_path):
 @pytest.mark.gpu
 def test_bench_two_ranks_check_dp_line_is_compact():
     r = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4",
-                    "--warmup", "1", "--points", "8192", "--optimize-every", "4", "--profile-steps", "2", "--check-dp",
+                    "--warmup", "1", "--points", "8192", "--optimize-every", "4", "--profile-steps", "2",
                     "--kernel-table", os.path.join(ROOT, "gpurun_out", "bench_kernels_test.json")])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), "the JSON line must be the last thing on stdout"
     assert len(lines[0]) <= 4096
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["optimizer_steps_in_timed_region"] == 2
-    assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]
+    assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]      # on by default for N > 1
+    assert d["config"]["rccl_ranks"] == 0 and d["config"]["collective"] == "gloo"             # (RCCL needs one GPU per rank)
     assert "roofline" in d and d["roofline"]["frac"] > 0
