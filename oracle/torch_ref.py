@@ -4,8 +4,8 @@ module-level parity tests and the ``cpu_baseline`` ("port") leg of ``bench.py``.
 Never imported by the product package.
 
 Pinned against the reference's own Python modules (imported in the build
-container with stub IO deps) through the fixtures in ``tests/golden/`` and the
-direct comparison in ``tests/test_oracle_vs_reference.py``; the only unpinned
+container with stub IO deps, ``tests/golden/make_golden.py``) through the fixtures in
+``tests/golden/``, which ``tests/test_oracle_golden.py`` replays; the only unpinned
 piece is the ``scatter_max`` tie-break (see ``oracle/scatter_ref.py``).
 
 Each class keeps the reference's constructor arguments and ``state_dict`` keys
