@@ -119,6 +119,11 @@ int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nb
                     float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N,
                     int nbits, int level, int C, float *gfeat, t2h_stream_t stream);
+/* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
+ * rasterisation and the next level's fc_c (alto.py:123-130), so their gradient is a sum of two -- formed here instead of
+ * by an extra elementwise pass (gfeat may alias addend). */
+int t2h_segmean_bwd_add(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N, int nbits,
+                        int level, int C, const float *addend, float *gfeat, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * sample_plane_feature: F.grid_sample(c, 2*xy-1, bilinear, border, align_corners=True)

@@ -289,3 +289,35 @@ def test_operator_level_dropins_reference_signatures():
         np.testing.assert_allclose(out.detach().cpu().numpy(), gs[f"out_r{r}"], rtol=1e-5, atol=1e-6)
         out.backward(torch.from_numpy(gs[f"gout_r{r}"]).to(_dev()))
         np.testing.assert_allclose(p.grad.cpu().numpy(), gs[f"gplane_r{r}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("c,reso,level", [(32, 256, 0), (128, 256, 1), (12, 64, 2), (512, 256, 3)])
+def test_rasterise_mean_thru_sums_the_two_gradients_bit_exactly(c, reso, level):
+    """ops.rasterise_mean_thru: the gradient of point features that feed both the rasterisation and another consumer
+    (alto.py:123-130) is the same sum autograd would form with an extra add, bit for bit."""
+    from tomosar2height_amd import ops
+    g = torch.Generator().manual_seed(c)
+    cloud = synth_cloud(7000, seed=3)
+    t = _tile(cloud, reso)
+    r = reso >> level
+    feat = torch.randn(7000, c, generator=g).to(_dev())
+    gplane = torch.randn(1, c, r, r, generator=g).to(_dev())
+    gother = torch.randn(7000, c, generator=g).to(_dev())
+    a = feat.clone().requires_grad_(True)
+    plane_a = ops.rasterise_mean(t, a, r)
+    torch.autograd.backward([plane_a, a * 1.0], [gplane, gother])               # autograd's own sum of the two gradients
+    b = feat.clone().requires_grad_(True)
+    plane_b, thru = ops.rasterise_mean_thru(t, b, r)
+    assert thru.data_ptr() == b.data_ptr() and torch.equal(plane_a, plane_b)
+    torch.autograd.backward([plane_b, thru * 1.0], [gplane, gother])
+    assert torch.equal(a.grad, b.grad)
+    # either consumer alone
+    d = feat.clone().requires_grad_(True)
+    plane_d, thru_d = ops.rasterise_mean_thru(t, d, r)
+    plane_d.backward(gplane)
+    e = feat.clone().requires_grad_(True)
+    ops.rasterise_mean(t, e, r).backward(gplane)
+    assert torch.equal(d.grad, e.grad)
+    f = feat.clone().requires_grad_(True)
+    (ops.rasterise_mean_thru(t, f, r)[1] * 1.0).backward(gother)
+    assert torch.equal(f.grad, gother)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "t2h_segmean_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_segmean_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_segmean_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_segmean_bwd_add": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -374,7 +374,8 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void segmean_bwd_kernel(const float *__restrict__ gplane,
                                                                const int32_t *__restrict__ cell,
                                                                const int32_t *__restrict__ off0, int64_t npts, int nbits,
-                                                               int level, int C, int lg, float *__restrict__ gfeat) {
+                                                               int level, int C, int lg, const float *__restrict__ addend,
+                                                               float *__restrict__ gfeat) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t n = t >> lg;
     if (n >= npts) return;
@@ -393,6 +394,11 @@ __global__ __launch_bounds__(kThreads) void segmean_bwd_kernel(const float *__re
         Vec<VEC> g = Vec<VEC>::load(grow + c);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) g.v[j] = __fdiv_rn(g.v[j], den);
+        if (addend) {           // the other gradient of a point-feature tensor with two consumers: summed here, not by a pass of its own
+            Vec<VEC> o = Vec<VEC>::load(addend + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g.v[j] = __fadd_rn(o.v[j], g.v[j]);
+        }
         g.store(gfeat + (size_t)n * C + c);
     }
 }
@@ -890,7 +896,13 @@ T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N
 
 T2H_API int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N, int nbits,
                             int level, int C, float *gfeat, t2h_stream_t stream) {
+    return t2h_segmean_bwd_add(gplane_nhwc, cell, off0, B, N, nbits, level, C, nullptr, gfeat, stream);
+}
+
+T2H_API int t2h_segmean_bwd_add(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N, int nbits,
+                                int level, int C, const float *addend, float *gfeat, t2h_stream_t stream) {
     if (!gplane_nhwc || !cell || !off0 || !gfeat) return fail(T2H_ERR_ARG, "segmean_bwd: null pointer");
+    if (addend && C % 4 == 0 && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "segmean_bwd: addend must be 16-byte aligned");
     int rc = check_level("segmean_bwd", B, nbits, level, C);
     if (rc) return rc;
     if (N < 0) return fail(T2H_ERR_ARG, "segmean_bwd: N < 0");
@@ -899,10 +911,10 @@ T2H_API int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
           hipLaunchKernelGGL(segmean_bwd_kernel<4>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, gfeat); },
+                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, addend, gfeat); },
         { GroupCfg g = group_cfg<1>(C);
           hipLaunchKernelGGL(segmean_bwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, gfeat); });
+                             gplane_nhwc, cell, off0, npts, nbits, level, C, g.lg, addend, gfeat); });
     return check_launch("segmean_bwd");
 }
 

@@ -68,7 +68,8 @@ class _PointGridLevel(nn.Module):
         fa, fb = self.fc_comm[0], self.fc_comm[2]
         c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
                          self.fc_c.weight, self.fc_c.bias)                       # alto.py:123-128 / 248-253
-        raster = ops.rasterise_mean(tile, c, plane.shape[2], self.channels_last)  # alto.py:130 / 255
+        # alto.py:130 / 255; `c` also feeds the next level's fc_c: its two gradients are summed in the rasterisation's backward
+        raster, c = ops.rasterise_mean_thru(tile, c, plane.shape[2], self.channels_last)
         return raster, c
 
 

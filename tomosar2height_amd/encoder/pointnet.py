@@ -71,7 +71,10 @@ class LocalPoolPointnet(nn.Module):
         if self.check_domain:
             tile.check_domain()
         net = self.point_features(tile)
-        plane = ops.rasterise_mean(tile, net, self.reso_plane, self.channels_last)      # pointnet.py:83
+        if self.unet_type == "alto":      # net also feeds ALTO's first fc_c: one fused gradient sum (ops.rasterise_mean_thru)
+            plane, net = ops.rasterise_mean_thru(tile, net, self.reso_plane, self.channels_last)      # pointnet.py:83
+        else:
+            plane = ops.rasterise_mean(tile, net, self.reso_plane, self.channels_last)
         if self.unet_type == "unet":
             return {"xy": self.unet(plane)}
         return {"xy": self.unet.forward_sorted(tile, plane, net)}                       # pointnet.py:88

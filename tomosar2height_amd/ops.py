@@ -116,6 +116,42 @@ class _RasteriseMean(torch.autograd.Function):
         return gfeat, None, None, None
 
 
+class _RasteriseMeanThru(torch.autograd.Function):
+    """``(rasterise_mean(feat), feat)``: the second output is ``feat`` itself for its OTHER consumer (the next level's
+    ``fc_c``, alto.py:126-128 / 251-253).  Autograd would sum the two gradients of ``feat`` with an elementwise pass over
+    an [N, C] tensor (0.4 ms per step over all levels); here the rasterisation's backward adds the other gradient while it
+    writes its own (``t2h_segmean_bwd_add``) -- same sum, bit for bit."""
+
+    @staticmethod
+    def forward(ctx, feat, tile: TileIndex, level: int, channels_last: bool):
+        plane = _RasteriseMean.forward(ctx, feat, tile, level, channels_last)
+        return plane, feat.view_as(feat)
+
+    @staticmethod
+    def backward(ctx, gplane, gthru):
+        tile = ctx.tile
+        n, c = tile.n_points, ctx.c
+        if gplane is None:
+            return gthru, None, None, None
+        g = to_nhwc(gplane)
+        addend = None
+        if gthru is not None:
+            addend = gthru.contiguous()
+            _lib.require_device(addend, what="rasterise_mean_thru")
+        gfeat = torch.empty(n, c, dtype=torch.float32, device=g.device)
+        _lib.call("t2h_segmean_bwd_add", _lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
+                  ctx.level, c, None if addend is None else _lib.ptr(addend), _lib.ptr(gfeat), _lib.stream(),
+                  nbytes=4 * g.numel() + 4 * n + 4 * g.numel() // c + 4 * c * n * (2 if addend is not None else 1),
+                  tag=f"t2h_segmean_bwd[C={c},r={g.shape[1]}]")
+        return gfeat, None, None, None
+
+
+def rasterise_mean_thru(tile: TileIndex, feat: torch.Tensor, reso: int, channels_last: bool = False):
+    """``(plane, feat)`` -- use the returned ``feat`` for every further consumer of the point features so that their
+    gradient is summed inside the rasterisation's backward kernel."""
+    return _RasteriseMeanThru.apply(feat, tile, tile.level(reso), channels_last)
+
+
 def rasterise_mean(tile: TileIndex, feat: torch.Tensor, reso: int, channels_last: bool = False) -> torch.Tensor:
     """Per-cell mean of point features -> ``[B, C, reso, reso]``; empty cells are 0
     (generate_plane_features: pointnet.py:101-111; alto.py:76-88,187-197)."""
