@@ -385,6 +385,10 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup)
+    if args.warmup > 0:
+        # one optimizer boundary belongs to the warm-up: the optimizer's lazy state (moment buffers, FlatAdamW's chunk table)
+        # is created by its first step, exactly like the kernels' first launches above
+        trainer.optimizer_boundary()
     if args.hip_graph:
         trainer.capture_graph(tiles[0])
         run(2)

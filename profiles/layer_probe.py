@@ -102,3 +102,15 @@ if args.only in ("", "upconv"):
             total += us * calls
             report(f"upconv2x2_{name}[{cin}->{cout},{h}x{h}] x{calls}", us, fl)
 print(f"sum over one step's calls: {total / 1e3:.2f} ms")
+if args.only in ("", "small"):
+    # the image U-Net's first layer (encoder/unet.py:112-187): Conv2d(3, 32, 3, padding=1) at 512 x 512
+    from tomosar2height_amd import _lib
+    cin, cout, h = 3, 32, 512
+    x, gy = cl(rnd(1, cin, h, h)), cl(rnd(1, cout, h, h))
+    w, b = cl(rnd(cout, cin, 3, 3) / 5.2), rnd(cout)
+    y, dw, db = grid._empty_cl(1, cout, h, h, dev), torch.empty(cout, cin, 3, 3, device=dev).contiguous(memory_format=torch.channels_last), torch.empty(cout, device=dev)
+    ws = _lib.workspace(_lib.load().t2h_conv3x3_smallcin_wgrad_workspace_bytes(cin, cout), dev)
+    fl = 2.0 * 9 * cin * cout * h * h
+    for name, fn in (("fwd", lambda: _lib.call("t2h_conv3x3_smallcin_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), 1, h, h, cin, cout, 2, _lib.stream())),
+                     ("wgrad", lambda: _lib.call("t2h_conv3x3_smallcin_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), 1, h, h, cin, cout, 0, _lib.ptr(ws), ws.numel(), _lib.stream()))):
+        report(f"conv3x3_smallcin_{name}[{cin}->{cout},{h}x{h}]", timed(fn), fl)
