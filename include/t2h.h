@@ -259,6 +259,10 @@ int t2h_upconv2x2_dgrad(const float *dy, const float *w, float *dx, int B, int H
 size_t t2h_upconv2x2_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int B, int H, int W, int Cin, int Cout, int flags,
                         void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+/* The same, also producing the bias gradient db[Cout] (= the column sums of dy, formed from the operand tiles the kernel
+ * stages anyway; db may be NULL).  Workspace: t2h_upconv2x2_wgrad_workspace_bytes. */
+int t2h_upconv2x2_wgrad_bias(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
+                             int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DSM mosaic of the inference path                     generator.py:147-157

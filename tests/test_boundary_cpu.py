@@ -131,6 +131,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upconv2x2_fwd_add": (n, n, n, n, n, 1, 32, 32, 32, 32, 0, n),
         "t2h_upconv2x2_dgrad": (n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_upconv2x2_wgrad": (n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
+        "t2h_upconv2x2_wgrad_bias": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_maxpool2x2_nhwc_fwd": (n, 1, 64, 64, 32, n, n, n),
         "t2h_maxpool2x2_nhwc_bwd": (n, n, 1, 64, 64, 32, n, n),
         "t2h_mosaic_accumulate": (n, 64, 64, n, n, n, 100, 100, 0, 0, 1, n),

@@ -66,6 +66,7 @@ SIGNATURES = {
     "t2h_upconv2x2_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "t2h_upconv2x2_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_upconv2x2_wgrad_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_maxpool2x2_nhwc_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_maxpool2x2_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

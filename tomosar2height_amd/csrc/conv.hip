@@ -315,7 +315,10 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
 
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool do_colsum = p.colsum != nullptr && tile_n == 0;
+    const bool do_colsum = !UP && p.colsum != nullptr && tile_n == 0;
+    // transposed conv: the bias gradient is the column sum of dY = the B operand; one row tile per column tile forms it
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_bsum = UP && p.colsum != nullptr && tile_m == 0;
 
     if (nk > 0) {
         la.load(p.mat, p.ldmat, m0, p.M, kbeg, kend, tid, false);
@@ -331,6 +334,10 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
             for (int f = 0; f < LoaderA::PER; ++f) {
                 csum.x += la.r[f].x; csum.y += la.r[f].y; csum.z += la.r[f].z; csum.w += la.r[f].w;
             }
+        }
+        if (do_bsum) {
+#pragma unroll
+            for (int f = 0; f < PER; ++f) { bsum.x += rb[f].x; bsum.y += rb[f].y; bsum.z += rb[f].z; bsum.w += rb[f].w; }
         }
         if (kt + 1 < nk) {
             la.load(p.mat, p.ldmat, m0, p.M, kbeg + (kt + 1) * BK, kend, tid, false);
@@ -359,6 +366,19 @@ __global__ __launch_bounds__(NT, MINW) void conv_wgrad_kernel(ConvArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (m0 + tid * 4 + q < p.M) dst[q] = tv[q];
+        }
+        __syncthreads();
+    }
+
+    if (do_bsum) {     // threads (krow) that share a column group are summed in krow order: colsum[split][n0 + 4 ic ..]
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < GROUPS) {
+            float4 t = red[tid];
+            for (int j = tid + GROUPS; j < NT; j += GROUPS) { t.x += red[j].x; t.y += red[j].y; t.z += red[j].z; t.w += red[j].w; }
+            float *dst = p.colsum + (size_t)split * p.N + n0 + tid * 4;
+            if (n0 + tid * 4 < p.N) *reinterpret_cast<float4 *>(dst) = t;
         }
         __syncthreads();
     }
@@ -616,11 +636,16 @@ T2H_API int t2h_upconv2x2_dgrad(const float *dy, const float *w, float *dx, int 
 T2H_API size_t t2h_upconv2x2_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
     WgradPlan p = wgrad_plan_for((long long)B * H * W, Cin, 4 * Cout);
-    return (size_t)p.splits * (size_t)Cin * 4 * Cout * sizeof(float);
+    return (size_t)p.splits * ((size_t)Cin * 4 * Cout + 4 * Cout) * sizeof(float);
 }
 
 T2H_API int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int B, int H, int W, int Cin, int Cout, int flags,
                                 void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    return t2h_upconv2x2_wgrad_bias(dy, x, dw, nullptr, B, H, W, Cin, Cout, flags, workspace, workspace_bytes, stream);
+}
+
+T2H_API int t2h_upconv2x2_wgrad_bias(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin,
+                                     int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "upconv2x2_wgrad: null pointer");
     if (int rc = check_up("upconv2x2_wgrad", B, H, W, Cin, Cout)) return rc;
     if (!al16(dy) || !al16(x)) return fail(T2H_ERR_ARG, "upconv2x2_wgrad: pointers must be 16-byte aligned");
@@ -633,7 +658,8 @@ T2H_API int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int 
     WgradPlan p = wgrad_plan_for(P, Cin, Ncols);
     float *slab = static_cast<float *>(workspace);
     ConvArgs a{};
-    a.act = dy; a.mat = x; a.C = slab; a.colsum = nullptr;
+    float *colslab = slab + (size_t)p.splits * Cin * Ncols;            // [splits][4 taps][Cout]: column sums of dY
+    a.act = dy; a.mat = x; a.C = slab; a.colsum = db ? colslab : nullptr;
     a.H = H; a.W = W; a.logW = ilog2_exact(W); a.Ca = Cout;
     a.M = Cin; a.N = Ncols; a.K = (int)P; a.ldmat = Cin; a.ldc = Ncols;
     a.k_chunk = p.k_chunk; a.slab_stride = (long long)Cin * Ncols;
@@ -644,6 +670,7 @@ T2H_API int t2h_upconv2x2_wgrad(const float *dy, const float *x, float *dw, int 
     else hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 1, 4, 4, true>), grid, dim3(NT), 0, s, a);
     note_kernel(p.bm == 128 ? "conv_wgrad_kernel<128,128,2,2,4,true>" : (p.bm == 64 ? "conv_wgrad_kernel<64,128,2,2,4,true>" : "conv_wgrad_kernel<32,128,1,4,4,true>"));
     if (int rc = check_launch("upconv2x2_wgrad")) return rc;
+    // the bias gradient sums the column slabs over the splits AND the four taps: [splits * 4][Cout] rows of length Cout
     return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw,
-                               nullptr, nullptr, s);
+                               db ? colslab : nullptr, db, s, db ? 4 * p.splits : 0, Cout);
 }

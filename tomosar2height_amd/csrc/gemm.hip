@@ -244,25 +244,26 @@ template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
                                                           int rows, int cols, int ld_out, int accumulate,
                                                           float *__restrict__ out, const float *__restrict__ col_slabs,
-                                                          float *__restrict__ col_out, unsigned matrix_blocks) {
+                                                          float *__restrict__ col_out, unsigned matrix_blocks, int col_splits,
+                                                          int col_rows) {
     __shared__ float red[256 * VEC];
     const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
     if (blockIdx.x >= matrix_blocks) {
         const long long e = (long long)(blockIdx.x - matrix_blocks) * 16 + el;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        if (e < rows) {
+        if (e < col_rows) {
             int z = q;
-            for (; z + 48 < splits; z += 64) {
-                s0 += col_slabs[(size_t)z * rows + e];
-                s1 += col_slabs[(size_t)(z + 16) * rows + e];
-                s2 += col_slabs[(size_t)(z + 32) * rows + e];
-                s3 += col_slabs[(size_t)(z + 48) * rows + e];
+            for (; z + 48 < col_splits; z += 64) {
+                s0 += col_slabs[(size_t)z * col_rows + e];
+                s1 += col_slabs[(size_t)(z + 16) * col_rows + e];
+                s2 += col_slabs[(size_t)(z + 32) * col_rows + e];
+                s3 += col_slabs[(size_t)(z + 48) * col_rows + e];
             }
-            for (; z < splits; z += 16) s0 += col_slabs[(size_t)z * rows + e];
+            for (; z < col_splits; z += 16) s0 += col_slabs[(size_t)z * col_rows + e];
         }
         red[threadIdx.x] = (s0 + s1) + (s2 + s3);
         __syncthreads();
-        if (q == 0 && e < rows) {
+        if (q == 0 && e < col_rows) {
             float t = red[el];
             for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
             col_out[e] = accumulate ? col_out[e] + t : t;
@@ -424,17 +425,20 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, const float *col_slabs, float *col_out, hipStream_t s) {
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits, int col_rows) {
+    // col_slabs [col_splits][col_rows] -> col_out[col_rows]; by default the matrix's split count and row count
+    if (col_splits <= 0) col_splits = splits;
+    if (col_rows <= 0) col_rows = rows;
     const long long total = (long long)rows * cols;
     const bool vec = cols % 4 == 0 && ld_out % 4 == 0 && stride % 4 == 0 && (uintptr_t)slabs % 16 == 0 && (uintptr_t)out % 16 == 0;
     const unsigned mb = (unsigned)((total + (vec ? 63 : 15)) / (vec ? 64 : 16));
-    const unsigned cb = col_out ? (unsigned)((rows + 15) / 16) : 0u;
+    const unsigned cb = col_out ? (unsigned)((col_rows + 15) / 16) : 0u;
     if (vec)
         hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
-                           accumulate, out, col_slabs, col_out, mb);
+                           accumulate, out, col_slabs, col_out, mb, col_splits, col_rows);
     else
         hipLaunchKernelGGL(reduce_slabs_kernel<1>, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
-                           accumulate, out, col_slabs, col_out, mb);
+                           accumulate, out, col_slabs, col_out, mb, col_splits, col_rows);
     return check_launch("reduce_slabs");
 }
 

@@ -143,6 +143,6 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
 // reduce_slabs_kernel of gemm.hip: out[r, c] = [out +] sum_z slabs[z][r * cols + c] in a fixed order, and in the same
 // launch col_out[r] = [col_out +] sum_z col_slabs[z][r] (the bias gradient; col_out may be null)
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, const float *col_slabs, float *col_out, hipStream_t s);
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0);
 
 }  // namespace t2h

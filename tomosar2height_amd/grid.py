@@ -396,16 +396,11 @@ class _UpConv2x2(torch.autograd.Function):
         db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
         nws = lib.t2h_upconv2x2_wgrad_workspace_bytes(b, h, wd, cin, cout)
         ws = _lib.workspace(nws, g.device)
-        _lib.call("t2h_upconv2x2_wgrad", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), b, h, wd, cin, cout,
-                  _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
+        # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
+        _lib.call("t2h_upconv2x2_wgrad_bias", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
+                  b, h, wd, cin, cout, _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                   tag=f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
-        if db is not None:
-            pix = 4 * b * h * wd
-            nws = lib.t2h_bias_relu_bwd_workspace_bytes(pix, cout)
-            ws = _lib.workspace(nws, g.device)
-            _lib.call("t2h_bias_relu_bwd", _lib.ptr(g), None, None, pix, cout, 0, 1 if direct else 0, _lib.ptr(db),
-                      _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * g.numel())
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
