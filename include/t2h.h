@@ -143,6 +143,12 @@ size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C)
 int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                    int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                    t2h_stream_t stream);
+/* The same with `addend` [B, r, r, C] (may be NULL) added to the result: a conv output that is sampled also feeds the next
+ * level's residual convolution (alto.py:104-114, 233-236), so its gradient is a sum of two -- formed in this kernel's final
+ * store instead of by an extra elementwise pass. */
+int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                       int level, int C, const float *addend, float *gplane_nhwc, void *workspace,
+                       size_t workspace_bytes, t2h_stream_t stream);
 int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
                           float *gplane_nhwc, t2h_stream_t stream);
 
@@ -218,6 +224,9 @@ int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, 
 int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream);
 int t2h_maxpool2x2_nhwc_bwd(const float *gout, const uint8_t *which, int B, int H, int W, int C, float *gin,
                             t2h_stream_t stream);
+/* ... with `addend` [B, H, W, C] (may be NULL) added: the pooled plane is also a U-Net skip connection (alto.py:135-138). */
+int t2h_maxpool2x2_nhwc_bwd_add(const float *gout, const uint8_t *which, int B, int H, int W, int C, const float *addend,
+                                float *gin, t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
                                    t2h_stream_t stream);
 

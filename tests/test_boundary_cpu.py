@@ -110,6 +110,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_segmean_bwd_add": (n, n, n, 1, 10, 8, 0, 32, n, n, n),
         "t2h_sample_fwd": (n, n, 3, 1, 10, 32, 32, n, n),
         "t2h_sample_bwd": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n),
+        "t2h_sample_bwd_add": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, n, 0, n),
         "t2h_sample_bwd_atomic": (n, n, 3, 1, 10, 32, 32, n, n),
         "t2h_linear_fwd": (n, 32, n, n, n, 32, 10, 32, 32, 0, n),
         "t2h_linear_fwd_add": (n, 32, n, n, n, 32, n, 32, 10, 32, 32, 0, n),
@@ -134,6 +135,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upconv2x2_wgrad_bias": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_maxpool2x2_nhwc_fwd": (n, 1, 64, 64, 32, n, n, n),
         "t2h_maxpool2x2_nhwc_bwd": (n, n, 1, 64, 64, 32, n, n),
+        "t2h_maxpool2x2_nhwc_bwd_add": (n, n, 1, 64, 64, 32, n, n, n),
         "t2h_mosaic_accumulate": (n, 64, 64, n, n, n, 100, 100, 0, 0, 1, n),
         "t2h_mosaic_finalize": (n, n, 100, n),
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),

@@ -321,3 +321,41 @@ def test_rasterise_mean_thru_sums_the_two_gradients_bit_exactly(c, reso, level):
     f = feat.clone().requires_grad_(True)
     (ops.rasterise_mean_thru(t, f, r)[1] * 1.0).backward(gother)
     assert torch.equal(f.grad, gother)
+
+
+@pytest.mark.parametrize("c,reso,level,n", [(32, 256, 0, 9000), (64, 64, 1, 40000), (256, 256, 2, 60000), (12, 32, 0, 500)])
+def test_sample_plane_thru_sums_the_two_gradients_bit_exactly(c, reso, level, n):
+    """ops.sample_plane_thru: fine gather and coarse (cells + gather9) backward with the other consumer's gradient added
+    in the final store == autograd's own sum."""
+    from tomosar2height_amd import ops
+    g = torch.Generator().manual_seed(c + n)
+    t = _tile(synth_cloud(n, seed=5), reso)
+    r = reso >> level
+    plane = torch.randn(1, c, r, r, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    gs = torch.randn(n, c, generator=g).to(_dev())
+    gother = torch.randn(1, c, r, r, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    a = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    torch.autograd.backward([ops.sample_plane(t, a), a * 1.0], [gs, gother])
+    b = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    sampled, thru = ops.sample_plane_thru(t, b)
+    torch.autograd.backward([sampled, thru * 1.0], [gs, gother])
+    assert torch.equal(a.grad, b.grad)
+    d = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    ops.sample_plane_thru(t, d)[0].backward(gs)
+    e = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    ops.sample_plane(t, e).backward(gs)
+    assert torch.equal(d.grad, e.grad)
+
+
+def test_maxpool_thru_sums_the_two_gradients_bit_exactly():
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 32, 16, 24, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    gp = torch.randn(2, 32, 8, 12, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    gother = torch.randn(2, 32, 16, 24, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    a = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    torch.autograd.backward([grid.maxpool2x2(a), a * 1.0], [gp, gother])
+    b = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
+    pooled, thru = grid.maxpool2x2_thru(b)
+    torch.autograd.backward([pooled, thru * 1.0], [gp, gother])
+    assert torch.equal(a.grad, b.grad) and torch.equal(pooled, grid.maxpool2x2(x))

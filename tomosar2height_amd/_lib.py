@@ -37,6 +37,7 @@ SIGNATURES = {
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "t2h_sample_bwd_add": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_linear_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_linear_fwd_add": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "t2h_upconv2x2_wgrad_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_maxpool2x2_nhwc_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_maxpool2x2_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_maxpool2x2_nhwc_bwd_add": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),

@@ -468,7 +468,8 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__restrict__ gout,
                                                               const float *__restrict__ pts, int dim,
                                                               const int32_t *__restrict__ off0, int B, int nbits,
-                                                              int level, int C, int lg, float *__restrict__ gplane) {
+                                                              int level, int C, int lg, const float *__restrict__ addend,
+                                                              float *__restrict__ gplane) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t gid = t >> lg;
     const int rbits = nbits - level, r = 1 << rbits;
@@ -520,7 +521,13 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
         Vec<VEC> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
-        o.store(gplane + (((size_t)b * r + py) * r + px) * C + c);
+        const size_t at = (((size_t)b * r + py) * r + px) * C + c;
+        if (addend) {       // the plane's other gradient (it also feeds a convolution): summed here, not by a pass of its own
+            Vec<VEC> a = Vec<VEC>::load(addend + at);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] = __fadd_rn(a.v[j], o.v[j]);
+        }
+        o.store(gplane + at);
     }
 }
 
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
 // stage 2: pixel (px,py) sums the matching slot of its (up to) 9 neighbouring cells, cells row-major, splits in order.
 __global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const float *__restrict__ partial, int B,
                                                                      int rbits, int C, int lg, int S,
+                                                                     const float *__restrict__ addend,
                                                                      float *__restrict__ gplane) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t gid = t >> lg;
@@ -704,7 +712,12 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const floa
                     acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
                 }
             }
-        *reinterpret_cast<float4 *>(gplane + (((size_t)b * r + py) * r + px) * C + c) = acc;
+        const size_t at = (((size_t)b * r + py) * r + px) * C + c;
+        if (addend) {
+            const float4 a = *reinterpret_cast<const float4 *>(addend + at);
+            acc.x = __fadd_rn(a.x, acc.x); acc.y = __fadd_rn(a.y, acc.y); acc.z = __fadd_rn(a.z, acc.z); acc.w = __fadd_rn(a.w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(gplane + at) = acc;
     }
 }
 
@@ -937,7 +950,14 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
 T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                            int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                            t2h_stream_t stream) {
+    return t2h_sample_bwd_add(gout, pts, dim, off0, B, N, nbits, level, C, nullptr, gplane_nhwc, workspace, workspace_bytes, stream);
+}
+
+T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                               int level, int C, const float *addend, float *gplane_nhwc, void *workspace,
+                               size_t workspace_bytes, t2h_stream_t stream) {
     if (!gout || !pts || !off0 || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd: null pointer");
+    if (addend && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "sample_bwd: addend must be 16-byte aligned");
     int rc = check_level("sample_bwd", B, nbits, level, C);
     if (rc) return rc;
     if (dim < 2 || N < 0) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
@@ -954,16 +974,16 @@ T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const i
                            cp.lgG, cp.S, partial);
         GroupCfg g = group_cfg<4>(C);
         hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                           partial, B, nbits - level, C, g.lg, cp.S, gplane_nhwc);
+                           partial, B, nbits - level, C, g.lg, cp.S, addend, gplane_nhwc);
         return check_launch("sample_bwd(coarse)");
     }
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
           hipLaunchKernelGGL(sample_bwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); },
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, addend, gplane_nhwc); },
         { GroupCfg g = group_cfg<1>(C);
           hipLaunchKernelGGL(sample_bwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             gout, pts, dim, off0, B, nbits, level, C, g.lg, gplane_nhwc); });
+                             gout, pts, dim, off0, B, nbits, level, C, g.lg, addend, gplane_nhwc); });
     return check_launch("sample_bwd");
 }
 

@@ -64,13 +64,15 @@ class _PointGridLevel(nn.Module):
         return grid.conv1x1(x, conv, addend)
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
-        sampled = ops.sample_plane(tile, plane)                                   # alto.py:121-122 / 245-246
+        """-> (raster, c, plane): the returned ``plane`` is the input plane for its further consumers (its gradient is then
+        summed inside the sample backward kernel, ops.sample_plane_thru)."""
+        sampled, plane = ops.sample_plane_thru(tile, plane)                       # alto.py:121-122 / 245-246
         fa, fb = self.fc_comm[0], self.fc_comm[2]
         c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
                          self.fc_c.weight, self.fc_c.bias)                       # alto.py:123-128 / 248-253
         # alto.py:130 / 255; `c` also feeds the next level's fc_c: its two gradients are summed in the rasterisation's backward
         raster, c = ops.rasterise_mean_thru(tile, c, plane.shape[2], self.channels_last)
-        return raster, c
+        return raster, c, plane
 
 
 class DownConv(_PointGridLevel):
@@ -96,8 +98,11 @@ class DownConv(_PointGridLevel):
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
             res_in = self._pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
             g = self._conv1x1(self.conv1x1, res_in, addend=g)
-        raster, c = self._exchange(tile, g, c_last)
-        pooled = self._pool(raster) if self.pooling else raster
+        raster, c, g = self._exchange(tile, g, c_last)
+        if self.pooling and self.channels_last:         # raster is also the skip connection: one fused gradient sum
+            pooled, raster = grid.maxpool2x2_thru(raster, self.pool)
+        else:
+            pooled = self._pool(raster) if self.pooling else raster
         return pooled, raster, g, c
 
 
@@ -129,7 +134,7 @@ class UpConv(_PointGridLevel):
             g = self._conv1x1(self.conv1x1, prev_conv, addend=g)                    # alto.py:233-236
         if self.is_last:                                                            # alto.py:241-242
             return g, g, c_last
-        raster, c = self._exchange(tile, g, c_last)
+        raster, c, g = self._exchange(tile, g, c_last)
         return raster, g, c
 
 

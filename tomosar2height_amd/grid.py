@@ -554,6 +554,48 @@ class _MaxPool2x2(torch.autograd.Function):
         return gin
 
 
+class _MaxPool2x2Thru(torch.autograd.Function):
+    """``(maxpool2x2(x), x)``: ``x`` is also a U-Net skip connection (alto.py:135-138, 373-378); the pooling backward adds the
+    skip's gradient while it scatters its own (``t2h_maxpool2x2_nhwc_bwd_add``)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = _MaxPool2x2.forward(ctx, x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, gthru):
+        if g is None:
+            return gthru
+        (which,) = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        g = _as_cl(g)
+        addend = None if gthru is None else _as_cl(gthru)
+        gin = _empty_cl(b, c, h, w, g.device)
+        _lib.call("t2h_maxpool2x2_nhwc_bwd_add", _lib.ptr(g), _lib.ptr(which), b, h, w, c,
+                  None if addend is None else _lib.ptr(addend), _lib.ptr(gin), _lib.stream(),
+                  nbytes=5 * g.numel() + 4 * gin.numel() * (2 if addend is not None else 1), tag="t2h_maxpool2x2_bwd")
+        return gin
+
+
+def maxpool2x2_thru(x: torch.Tensor, pool: torch.nn.MaxPool2d = None):
+    """``(maxpool2x2(x), x)`` -- use the returned ``x`` for the skip connection (see ``_MaxPool2x2Thru``)."""
+    if not _maxpool_ok(x, pool):
+        _lib.library_fallback(f"max_pool2d on {tuple(x.shape)} (ATen)")
+        return (pool(x) if pool is not None else F.max_pool2d(x, 2, 2)), x
+    return _MaxPool2x2Thru.apply(x)
+
+
+def _maxpool_ok(x: torch.Tensor, pool) -> bool:
+    ok = (USE_HIP_CONV and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+          and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2)
+    if pool is not None:
+        k, st = pool.kernel_size, pool.stride
+        ok = ok and (k in (2, (2, 2))) and (st in (2, (2, 2))) and pool.padding in (0, (0, 0)) and not pool.ceil_mode \
+            and pool.dilation in (1, (1, 1)) and not pool.return_indices
+    return ok
+
+
 def maxpool2x2(x: torch.Tensor, pool: torch.nn.MaxPool2d = None) -> torch.Tensor:
     """``nn.MaxPool2d(kernel_size=2, stride=2)(x)`` on channels_last planes (same winners on ties as ATen)."""
     ok = (USE_HIP_CONV and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0

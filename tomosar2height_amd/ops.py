@@ -190,6 +190,40 @@ class _SamplePlane(torch.autograd.Function):
         return from_nhwc(gplane, ctx.was_cl), None
 
 
+class _SamplePlaneThru(torch.autograd.Function):
+    """``(sample_plane(plane), plane)``: the second output is the plane itself for its OTHER consumer (the next level's
+    residual 1x1 / transposed convolution, alto.py:104-114, 233-236); the sample backward adds that consumer's gradient in
+    its final store (``t2h_sample_bwd_add``) instead of autograd summing the two with an extra pass."""
+
+    @staticmethod
+    def forward(ctx, plane, tile: TileIndex):
+        out = _SamplePlane.forward(ctx, plane, tile)
+        return out, plane.view_as(plane)
+
+    @staticmethod
+    def backward(ctx, gout, gthru):
+        tile, r, c = ctx.tile, ctx.r, ctx.c
+        if gout is None:
+            return gthru, None
+        gout = gout.contiguous()
+        addend = None if gthru is None else to_nhwc(gthru)
+        gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
+        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c)
+        ws = _lib.workspace(ws_bytes, gout.device)
+        _lib.call("t2h_sample_bwd_add", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+                  tile.nbits, tile.level(r), c, None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.ptr(ws),
+                  ws_bytes, _lib.stream(),
+                  nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel() * (2 if addend is not None else 1),
+                  tag=f"t2h_sample_bwd[C={c},r={r}]")
+        return from_nhwc(gplane, ctx.was_cl), None
+
+
+def sample_plane_thru(tile: TileIndex, plane: torch.Tensor):
+    """``(sampled, plane)`` -- hand the returned ``plane`` to every further consumer so that its gradient is summed inside
+    the sample backward kernel."""
+    return _SamplePlaneThru.apply(plane, tile)
+
+
 def sample_plane(tile: TileIndex, plane: torch.Tensor) -> torch.Tensor:
     """Bilinear/border/align_corners sample of ``plane [B,C,r,r]`` at every point -> ``[B*N, C]``
     (sample_plane_feature + transpose: alto.py:90-95,122)."""
