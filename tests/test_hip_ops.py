@@ -338,6 +338,8 @@ def test_sample_plane_thru_sums_the_two_gradients_bit_exactly(c, reso, level, n)
     torch.autograd.backward([ops.sample_plane(t, a), a * 1.0], [gs, gother])
     b = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
     sampled, thru = ops.sample_plane_thru(t, b)
+    # the alias keeps the strides exactly (B = 1 channels_last): torch.cat must still see a channels_last plane
+    assert thru.stride() == b.stride() and torch.cat((thru, thru), 1).is_contiguous(memory_format=torch.channels_last)
     torch.autograd.backward([sampled, thru * 1.0], [gs, gother])
     assert torch.equal(a.grad, b.grad)
     d = plane.clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -357,5 +359,8 @@ def test_maxpool_thru_sums_the_two_gradients_bit_exactly():
     torch.autograd.backward([grid.maxpool2x2(a), a * 1.0], [gp, gother])
     b = x.clone(memory_format=torch.preserve_format).requires_grad_(True)
     pooled, thru = grid.maxpool2x2_thru(b)
+    assert thru.stride() == b.stride()
+    x1 = x[:1].clone(memory_format=torch.preserve_format)
+    assert grid.maxpool2x2_thru(x1)[1].stride() == x1.stride()
     torch.autograd.backward([pooled, thru * 1.0], [gp, gother])
     assert torch.equal(a.grad, b.grad) and torch.equal(pooled, grid.maxpool2x2(x))

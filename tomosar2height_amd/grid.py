@@ -30,6 +30,11 @@ def fallback_count() -> int:
     return sum(_lib.fallback_counts().values())
 
 
+def _alias(x: torch.Tensor) -> torch.Tensor:
+    """Same memory, exactly the same strides (see ops._alias)."""
+    return x.as_strided(x.size(), x.stride(), x.storage_offset())
+
+
 def is_cl(x: torch.Tensor) -> bool:
     """[B,C,H,W] tensor whose memory is dense NHWC (a C == 1 or H*W == 1 tensor counts when its NHWC view is contiguous)."""
     return x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.permute(0, 2, 3, 1).is_contiguous()
@@ -561,7 +566,7 @@ class _MaxPool2x2Thru(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         y = _MaxPool2x2.forward(ctx, x)
-        return y, x.view_as(x)
+        return y, _alias(x)
 
     @staticmethod
     def backward(ctx, g, gthru):

@@ -43,6 +43,12 @@ def from_nhwc(x_nhwc: torch.Tensor, channels_last: bool) -> torch.Tensor:
     return out
 
 
+def _alias(x: torch.Tensor) -> torch.Tensor:
+    """A second tensor object on the same memory with EXACTLY the same strides (``view_as`` rewrites the stride of size-1
+    dims, after which ``torch.cat`` no longer recognises a B = 1 channels_last plane and emits NCHW)."""
+    return x.as_strided(x.size(), x.stride(), x.storage_offset())
+
+
 def _is_channels_last(x: torch.Tensor) -> bool:
     return x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous()
 
@@ -125,7 +131,7 @@ class _RasteriseMeanThru(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, tile: TileIndex, level: int, channels_last: bool):
         plane = _RasteriseMean.forward(ctx, feat, tile, level, channels_last)
-        return plane, feat.view_as(feat)
+        return plane, _alias(feat)
 
     @staticmethod
     def backward(ctx, gplane, gthru):
@@ -198,7 +204,7 @@ class _SamplePlaneThru(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plane, tile: TileIndex):
         out = _SamplePlane.forward(ctx, plane, tile)
-        return out, plane.view_as(plane)
+        return out, _alias(plane)
 
     @staticmethod
     def backward(ctx, gout, gthru):
