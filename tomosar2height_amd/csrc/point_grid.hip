@@ -539,6 +539,8 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
 //   * a per-point tap table (pixel of the north-west tap + the four weights) so that a visited row costs one compare
 //     chain instead of recomputing the taps: 103 us -- rocprofv3 shows ~2100 vector and ~90 load instructions per wave
 //     here, and the two extra loads per visited row cost more than the arithmetic they save.
+//   * a 2 x 2 pixel quad per lane group (a row visited by 4 quads instead of 9 pixels, taps computed once per quad,
+//     bit-identical sums): 97 us -- a quarter of the threads with four accumulators each hides less latency.
 // What did pay: x * 0.5f instead of the IEEE division in unnormalize_clip (bit-identical), mostly in sample_fwd.
 
 // ------------------------------------------------------------------------------ coarse levels (many points / cell)
