@@ -541,6 +541,10 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
 //     here, and the two extra loads per visited row cost more than the arithmetic they save.
 //   * a 2 x 2 pixel quad per lane group (a row visited by 4 quads instead of 9 pixels, taps computed once per quad,
 //     bit-identical sums): 97 us -- a quarter of the threads with four accumulators each hides less latency.
+//   * the first 1-3 rows of all nine cells requested before any is used (9-27 rows in flight per lane): 82-239 us --
+//     the extra (dummy) loads for the many empty cells cost more than the latency they hide: the walk is bound by the
+//     NUMBER of load instructions (~1.5 M wave-loads) plus ~35 M vector instructions, both proportional to the nine-fold
+//     visit, not by latency.
 // What did pay: x * 0.5f instead of the IEEE division in unnormalize_clip (bit-identical), mostly in sample_fwd.
 
 // ------------------------------------------------------------------------------ coarse levels (many points / cell)
