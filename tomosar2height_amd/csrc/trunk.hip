@@ -21,6 +21,7 @@
 // MFMAs from it (the k order inside an MFMA pair is free as long as A and B agree), conflict-free for both operands.
 // Each of the 4 waves owns 32 rows: 64 + 16 (+ 16) MFMAs per tile.
 #include <float.h>
+#include <stdlib.h>
 
 #include "t2h_common.h"
 
@@ -106,7 +107,8 @@ __device__ inline void pool_into_tile(const TrunkFwdArgs &a, float *Xs, float *s
         __syncthreads();
         if (grp == 0) {
             Best t; t.v = pval[lane]; t.a = parg[lane];
-            for (int g = 1; g < NG; ++g) {
+            const int used = min(NG, hi - lo);                            // groups past the run's length hold empty partials
+            for (int g = 1; g < used; ++g) {
                 const float4 v = pval[g * G + lane]; const int4 ar = parg[g * G + lane];
                 best_merge(t.v.x, t.a.x, v.x, ar.x); best_merge(t.v.y, t.a.y, v.y, ar.y);
                 best_merge(t.v.z, t.a.z, v.z, ar.z); best_merge(t.v.w, t.a.w, v.w, ar.w);
@@ -200,6 +202,14 @@ __device__ inline void mfma_rows_pair(const float *pa, const float *pb0, const f
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
 __device__ inline int acc_row(int q, int lane) { return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5); }
 
+// Orders this wave's LDS writes before its later LDS reads (the LDS executes one wave's accesses in order; the fences keep
+// the compiler from moving them) -- for data that only this wave touches, instead of a workgroup barrier.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // one wave stores its 32 x 32 LDS tile (stride HS) to global rows [row0, row0 + 32) as float4 rows
 __device__ inline void store_tile_rows(const float *tile, float *dst, int ld, int row0, int M, int lane) {
 #pragma unroll
@@ -219,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     __shared__ __attribute__((aligned(16))) float W1s[32 * HS];
     __shared__ __attribute__((aligned(16))) float Wcs[LAST ? 32 * HS : 4];
     __shared__ float bsm[96];
+    __shared__ float wps[FIRST ? 256 : 4];                                  // fc_pos: [64][3] weights + [64] bias
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * TR, r1 = min(r0 + TR, a.M);
 
     // ---- weights -> LDS (row-major [n][k], padded rows)
 #pragma unroll
@@ -236,12 +246,19 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     }
     if (tid < 32) { bsm[tid] = a.b0[tid]; bsm[32 + tid] = a.b1[tid]; if (LAST) bsm[64 + tid] = a.bc[tid]; }
 
+    if (FIRST) {
+        if (tid < 192) wps[tid] = a.wpos[tid];
+        if (tid < 64) wps[192 + tid] = a.bpos[tid];
+    }
+    __syncthreads();
+    // persistent over tiles (the weights above are staged once; co-resident workgroups drift out of phase, so one's
+    // loader runs under the other's MFMAs)
+    const int n_tiles = (a.M + TR - 1) / TR;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int r0 = tile * TR, r1 = min(r0 + TR, a.M);
     // ---- the block input X -> Xs
     if (FIRST) {
-        float *wp = Hsm;                     // [64][3] + [64] staged through the (still unused) hr tile
-        if (tid < 192) wp[tid] = a.wpos[tid];
-        if (tid < 64) wp[192 + tid] = a.bpos[tid];
-        __syncthreads();
+        const float *wp = wps;
         const int row = tid >> 1, c0 = (tid & 1) * 32;
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
         if (r0 + row < r1) {
@@ -283,41 +300,58 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
         }
     }
 
-    // ---- GEMMs: this wave's 32 rows
+    // ---- GEMMs: this wave's 32 rows.  From here to the end of the tile a wave touches only its own rows of Xs / Hsm (and
+    // the read-only weights), so wave-level ordering suffices -- no workgroup barrier until the next tile's loader -- and
+    // results leave straight from the MFMA C/D registers (each store instruction writes two 128-byte row segments).
     const int r = lane & 31, h = lane >> 5;
     const float *xa = Xs + (wave * 32 + r) * XS + 4 * h;
+    const int rb = r0 + wave * 32 + 4 * h;                                  // global row of C/D register 0
     f32x16 acc_h, acc_s, acc_d;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc_h[q] = 0.f; acc_s[q] = 0.f; acc_d[q] = 0.f; }
     mfma_rows_pair<64>(xa, W0s + r * XS + 4 * h, Wss + r * XS + 4 * h, acc_h, acc_s);
-    float *ht = Hsm + wave * 32 * HS;                                       // this wave's hr tile
+    float *ht = Hsm + wave * 32 * HS;                                       // this wave's hr tile (A operand of fc_1)
     {
         const float b0 = bsm[r];
+        float *hp = a.hr + (size_t)rb * 32 + r;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) ht[acc_row(q, lane) * HS + r] = fmaxf(acc_h[q] + b0, 0.f);   // relu(fc_0(relu(x)))
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            const float v = fmaxf(acc_h[q] + b0, 0.f);                      // relu(fc_0(relu(x)))
+            ht[(ro + 4 * h) * HS + r] = v;
+            if (rb + ro < a.M) hp[ro * 32] = v;
+        }
     }
-    __syncthreads();
-    store_tile_rows(ht, a.hr, 32, r0 + wave * 32, a.M, lane);
+    wave_sync();
     mfma_rows<32, false>(ht + r * HS + 4 * h, W1s + r * HS + 4 * h, acc_d);
-    float *ot = Xs + wave * 32 * XS;                                        // X rows of this wave are consumed: reuse for out
     {
         const float b1 = bsm[32 + r];
+        float *op = a.out + (size_t)rb * a.ld_out + r;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) ot[acc_row(q, lane) * HS + r] = acc_s[q] + (acc_d[q] + b1);   // x_s + dx (resnet.py:54)
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            acc_s[q] = acc_s[q] + (acc_d[q] + b1);                          // x_s + dx (resnet.py:54)
+            if (rb + ro < a.M) op[(size_t)ro * a.ld_out] = acc_s[q];
+        }
     }
-    __syncthreads();
-    store_tile_rows(ot, a.out, a.ld_out, r0 + wave * 32, a.M, lane);
     if (LAST) {
+        float *ot = Xs + wave * 32 * XS;                                    // X rows of this wave are consumed: relu(out) as A operand
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ot[acc_row(q, lane) * HS + r] = acc_s[q];
+        wave_sync();
         f32x16 acc_c;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc_c[q] = 0.f;
         mfma_rows<32, true>(ot + r * HS + 4 * h, Wcs + r * HS + 4 * h, acc_c);     // fc_c(relu(net))
-        __syncthreads();                                                            // hr tile stores have been issued from ht
         const float bc = bsm[64 + r];
+        float *cp = a.c_out + (size_t)rb * 32 + r;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) ht[acc_row(q, lane) * HS + r] = acc_c[q] + bc;
-        __syncthreads();
-        store_tile_rows(ht, a.c_out, 32, r0 + wave * 32, a.M, lane);
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            if (rb + ro < a.M) cp[ro * 32] = acc_c[q] + bc;
+        }
+    }
+    __syncthreads();                     // the tiles in LDS are free for the next tile
     }
 }
 
@@ -403,7 +437,8 @@ __device__ inline void load_g_tile(const TrunkBwdArgs &a, float *Gs, float *scra
         __syncthreads();
         if (grp == 0) {
             float4 t = pval[lane];
-            for (int g = 1; g < NG; ++g) { const float4 v = pval[g * G + lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const int used = min(NG, hi - lo);                              // later groups hold zeros: adding them changes nothing
+            for (int g = 1; g < used; ++g) { const float4 v = pval[g * G + lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
             oval[side * G + lane] = t;
         }
         __syncthreads();
@@ -758,7 +793,8 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     a.net_prev = net_prev; a.ld_prev = ld_prev; a.cell = cell; a.off0 = off0;
     a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.ws = ws; a.wc = wc; a.bc = bc;
     a.M = (int)M; a.x_full = x_full; a.pooled = pooled; a.hr = hr; a.out = out; a.ld_out = ld_out; a.winner = winner; a.c_out = c_out;
-    const dim3 grid((unsigned)((M + TR - 1) / TR));
+    const int64_t n_tiles = (M + TR - 1) / TR;
+    const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));      // two resident per CU, each walks its tiles
     hipStream_t s = as_stream(stream);
     if (first) hipLaunchKernelGGL((trunk_block_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
     else if (last) hipLaunchKernelGGL((trunk_block_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
