@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2h_hip.so")
+# T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
+LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
 ABI_VERSION = 4
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t

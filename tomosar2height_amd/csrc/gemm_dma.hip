@@ -11,8 +11,8 @@
 // stored).  Numerics: still an exact fp32 fma chain per output, k visited in the permuted order inside each 16-slab.
 // Measured (N = 131072 points): 1024 -> 512 forward 1.105 -> 1.05 ms (131 TF = 83 % of the matrix peak), 256 -> 512
 // 307 -> 296 us.  The data gradient ("NN": dY rows as above, W [k][n] as a k-major DMA image read by ds_read_b32 in the
-// same k order) wins only with every fragment read of a slab issued before its MFMAs, and only for long reductions
-// (gemm_dma_applicable); interleaving the W reads with the MFMAs, or W through registers, lost 2-8 %.
+// same k order) needs every fragment read of a slab issued before its MFMAs
+// (interleaving the W reads with the MFMAs, or W through registers, lost 2-8 %).
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -68,6 +68,8 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_kernel(GemmArgs p) {
             for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
 
     if (nk > 0) issue(0, lds);
+    float4 bias_pre[TN];
+    load_bias_fragments<TN>(p.bias, p.N, n0 + wn * (TN * 32), lane, bias_pre);
     __syncthreads();
     const int half = lane >> 5, m = lane & 31, sw = (m >> 2) & 3;
     for (int kt = 0; kt < nk; ++kt) {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_kernel(GemmArgs p) {
     EpilogueArgs e;
     e.C = p.C; e.bias = p.bias; e.mask = p.mask; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldm = p.ldm;
     e.accum = p.flags & F_ACCUM; e.relu_out = p.flags & F_RELU_OUT; e.addend = p.addend; e.ldadd = p.ldadd;
-    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e);
+    store_tiles_f32<TM, TN>(acc, lds + wave * (32 * 36), lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), e, bias_pre);
 }
 
 // Data gradient ("NN"): A = dY rows (row image as above), B(k, n) = W[k][n] k-major: DMA image [16][128] (two k rows per
@@ -302,9 +304,10 @@ __global__ __launch_bounds__(NT, 4) void gemm_dma_tn_kernel(GemmArgs p) {
 }  // namespace
 
 bool gemm_dma_applicable(bool b_kc, const GemmArgs &a) {
-    // NN (data gradient): measured faster than the register-staged kernel when the reduction is long (>= 512) or at
-    // least as long as the output is wide (1024->512: 1.16 -> 1.08 ms, 512->256: 320 -> 310 us), slower by 2-3 % otherwise
-    if (!b_kc && !(a.N % 4 == 0 && a.N >= 4 && !(a.flags & F_RELU_A) && (a.K >= 512 || a.K >= a.N))) return false;
+    // NN (data gradient): with the epilogue's reads requested a pass ahead (gemm_tile.h) it is at least as fast as the
+    // register-staged kernel at every shape of the decoder (256->128: 124 -> 116 us, 512->256: 338 -> 332 us, others
+    // within 1 %); before that change it won only for long reductions
+    if (!b_kc && !(a.N % 4 == 0 && a.N >= 4 && !(a.flags & F_RELU_A))) return false;
     return a.K % BK == 0 && a.K >= BK && a.N > 64 && a.M >= 1 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
            !(a.flags & F_RELU_B) && a.k_chunk >= a.K;
 }

@@ -59,6 +59,16 @@ struct TileLoader {
 };
 
 
+// the bias fragments store_tiles_f32 will need (zeros without a bias), to be requested before the main loop
+template <int TN>
+__device__ inline void load_bias_fragments(const float *bias, int N, int col_base, int lane, float4 (&out)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col_base + j * 32 + (lane & 7) * 4;
+        out[j] = (bias && col < N) ? *reinterpret_cast<const float4 *>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // One BK-deep slab of v_mfma_f32_32x32x2_f32 on k-major LDS tiles (row strides SA / SB floats).  a_base / b_base
 // already point at this lane's first element: slab + (lane >> 5) * S + wave offset + (lane & 31).
 template <int TM, int TN, int SA, int SB, int BK>
@@ -100,41 +110,76 @@ struct EpilogueArgs {
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Each wave
 // transposes one 32x32 tile at a time through its private LDS patch (32 x 36 floats) so that global traffic (store,
 // mask load, accumulate load) is 16 bytes per lane.  row_base / col_base: first row / column of this wave's tiles.
+// bias_pre (optional): the bias fragments of this lane's TN column tiles, loaded by the caller BEFORE its main loop -- the
+// epilogue otherwise opens every tile with a dependent global load whose latency nothing hides any more.
 template <int TM, int TN>
 __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int lane, int row_base, int col_base,
-                                       const EpilogueArgs &e) {
+                                       const EpilogueArgs &e, const float4 *bias_pre = nullptr) {
     constexpr int EP = 36;
     const int er = lane >> 3, ec = (lane & 7) * 4;
+    if (!e.mask && !e.accum && !e.addend) {       // bias / ReLU only (every forward layer): nothing to read, no branches per pass
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row0 = row_base + i * 32, col = col_base + j * 32 + ec;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    patch[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[i][j][q];
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias_pre) bv = bias_pre[j];
+                else if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + col);
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = row0 + pass * 8 + er;
+                    float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (e.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (row < e.M && col < e.N) *reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col) = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row0 = row_base + i * 32, col0 = col_base + j * 32;
+            const int col = col0 + ec;
+            // the global reads of a pass (ReLU mask, accumulate target, addend) are requested one pass ahead -- those of
+            // pass 0 before the tile goes through the LDS patch -- so their latency runs under the LDS traffic and the
+            // previous pass instead of stalling every 8-row pass (one pass ahead, not all four: 128-VGPR budget)
+            float4 mk[2], old[2], add[2];
+            auto fetch = [&](int pass) {
+                const int row = row0 + pass * 8 + er;
+                const bool ok = row < e.M && col < e.N;
+                if (e.mask && ok) mk[pass & 1] = *reinterpret_cast<const float4 *>(e.mask + (size_t)row * e.ldm + col);
+                if (e.accum && ok) old[pass & 1] = *reinterpret_cast<const float4 *>(e.C + (size_t)row * e.ldc + col);
+                if (e.addend && ok) add[pass & 1] = *reinterpret_cast<const float4 *>(e.addend + (size_t)row * e.ldadd + col);
+            };
+            fetch(0);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
                 patch[((q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[i][j][q];
-            const int col = col0 + ec;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + col);
+            if (bias_pre) bv = bias_pre[j];
+            else if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + col);
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = row0 + pass * 8 + er;
+                if (pass + 1 < 4) fetch(pass + 1);
                 float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
                 if (row < e.M && col < e.N) {
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (e.mask) {
-                        float4 mk = *reinterpret_cast<const float4 *>(e.mask + (size_t)row * e.ldm + col);
-                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                        const float4 m = mk[pass & 1];
+                        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                     }
                     if (e.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    float4 *dst = reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col);
-                    if (e.accum) { float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                    if (e.addend) {
-                        float4 o = *reinterpret_cast<const float4 *>(e.addend + (size_t)row * e.ldadd + col);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *dst = v;
+                    if (e.accum) { const float4 o = old[pass & 1]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    if (e.addend) { const float4 o = add[pass & 1]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col) = v;
                 }
             }
         }
