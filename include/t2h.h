@@ -97,6 +97,13 @@ int t2h_pool_max_fwd(const float *feat, int ldf, const int32_t *off0, int B, int
                      int ldp, uint8_t *winner, t2h_stream_t stream);
 int t2h_pool_max_bwd(const float *gpooled, int ldg, const uint8_t *winner, const int32_t *off0, int B, int nbits,
                      int C, int accumulate, float *gfeat, int ldo, t2h_stream_t stream);
+/* scatter_type='mean' (pointnet.py:55-56: self.scatter = scatter_mean; no shipped config selects it): out[n] = mean of
+ * feat over the rows of n's finest-level cell -- torch_scatter.scatter_mean (sum in point order, one division by the
+ * count) followed by the gather of pointnet.py:98.  The operator is its own adjoint: the backward is the same call on the
+ * gradient, accumulate != 0 adding into out (the pooled half's gradient folded into the left half of the block input's
+ * gradient, as t2h_pool_max_bwd does).  feat != out. */
+int t2h_pool_mean(const float *feat, int ldf, const int32_t *off0, int B, int nbits, int C, int accumulate, float *out,
+                  int ldo, t2h_stream_t stream);
 /* The same two operators balanced over ROWS instead of cells, for callers that hold the per-row cell ids of
  * t2h_tile_build (cell [n_rows], values index off0): a workgroup owns 128 consecutive sorted rows, reduces the cell
  * segments inside it from LDS and the outside rows of the (at most two) cells crossing its border cooperatively, so dense

@@ -255,6 +255,49 @@ def main():
 
 
 
+def mean_pool_fixture():
+    """scatter_type='mean' (pointnet.py:55-56, 92-99; no shipped config selects it): pool_local fwd + grad at two
+    resolutions and the reduced LocalPoolPointnet of fixture (6) with mean pooling."""
+    import_reference()
+    from utils.coordinate import coordinate2index
+    from tomosar2height.encoder.pointnet import LocalPoolPointnet
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="mean", unet_type="alto",
+                            unet_kwargs=dict(depth=2, merge_mode="concat", start_filts=8), plane_resolution=16)
+    arrs = {}
+    for reso in (4, 16):
+        enc.reso_plane = reso
+        cloud = synth_cloud(300, seed=60 + reso)
+        g = torch.Generator().manual_seed(60 + reso)
+        feat = torch.randn(1, 300, 8, generator=g, requires_grad=True)
+        idx = coordinate2index(cloud[:, :, :2], reso)
+        out = enc.pool_local(idx, feat)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        arrs.update({f"xy_r{reso}": cloud[:, :, :2], f"feat_r{reso}": feat, f"index_r{reso}": idx,
+                     f"out_r{reso}": out, f"gout_r{reso}": gout, f"gfeat_r{reso}": feat.grad})
+    save("pool_local_mean", **arrs)
+
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="mean", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16)
+    det_init_(enc, seed=6)
+    cloud = synth_cloud(256, seed=40)
+    out = enc(cloud)["xy"]
+    g = torch.Generator().manual_seed(6)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    arrs = {"cloud": cloud, "out": out, "gout": gout}
+    none_grad = []
+    for k, v in enc.state_dict().items():
+        arrs["w." + k] = v
+    for k, v in enc.named_parameters():
+        if v.grad is None:
+            none_grad.append(k)
+        else:
+            arrs["g." + k] = v.grad
+    arrs["none_grad"] = np.array(none_grad)
+    save("local_pool_pointnet_reduced_mean", **arrs)
+
+
 def blend_weight_fixture():
     """(10) DSMGenerator._linear_blend_patch_weight (generator.py:85-113).  generator.py cannot be imported as a
     module here (dataset.py needs `transformations`), so the static method is compiled from the reference file where
@@ -392,6 +435,9 @@ if __name__ == "__main__":
     if "--only-aug" in sys.argv:
         tile_producer_aug_fixture()
         sys.exit(0)
+    if "--only-mean" in sys.argv:
+        mean_pool_fixture()
+        sys.exit(0)
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         main()
     if "--only-producer" not in sys.argv:
@@ -399,3 +445,5 @@ if __name__ == "__main__":
     if "--only-blend" not in sys.argv:
         tile_producer_fixture()
         tile_producer_aug_fixture()
+    if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
+        mean_pool_fixture()

@@ -103,6 +103,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_tile_build": (n, 3, 1, 10, 8, n, n, n, n, n, n, 0, n),
         "t2h_pool_max_fwd": (n, 32, n, 1, 8, 32, n, 32, n, n),
         "t2h_pool_max_bwd": (n, 32, n, n, 1, 8, 32, 0, n, 32, n),
+        "t2h_pool_mean": (n, 32, n, 1, 8, 32, 0, n, 32, n),
         "t2h_pool_rows_fwd": (n, 32, n, n, 100, 32, n, 32, n, n),
         "t2h_pool_rows_bwd": (n, 32, n, n, n, 100, 32, 0, n, 32, n),
         "t2h_segmean_fwd": (n, n, 1, 10, 8, 0, 32, n, n, 0, n),

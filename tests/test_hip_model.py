@@ -47,6 +47,25 @@ def test_local_pool_pointnet_reduced_golden():
             _close(v.grad.cpu().numpy(), g["g." + k], rel=2e-4, what=k)
 
 
+def test_local_pool_pointnet_reduced_mean_golden():
+    """scatter_type='mean' (pointnet.py:55-56; no shipped config selects it) through the whole reduced encoder."""
+    from tomosar2height_amd.encoder.pointnet import LocalPoolPointnet
+    g = load_golden("local_pool_pointnet_reduced_mean")
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="mean", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16)
+    enc.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=True)
+    enc.to(_dev())
+    out = enc(torch.from_numpy(g["cloud"]).to(_dev()))["xy"]
+    _close(out.detach().cpu().numpy(), g["out"], what="plane")
+    out.backward(torch.from_numpy(g["gout"]).to(_dev()))
+    assert [k for k, v in enc.named_parameters() if v.grad is None] == g["none_grad"].tolist()
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            _close(v.grad.cpu().numpy(), g["g." + k], rel=2e-4, what=k)
+    with pytest.raises(ValueError):
+        LocalPoolPointnet(scatter_type="median", unet_kwargs=dict(depth=3, start_filts=8), plane_resolution=16)
+
+
 @pytest.mark.parametrize("mode", ["conv", "fc"])
 @pytest.mark.parametrize("foot", [False, True])
 @pytest.mark.parametrize("img", [False, True])

@@ -120,6 +120,43 @@ def test_pool_max_golden_and_single_cell():
     assert np.array_equal(got_g, want_g) and got_g[0, 0, 0] == n and got_g[0, 1:].sum() == 0
 
 
+def _pool_mean_case(cloud, feat, reso, gout):
+    from tomosar2height_amd import ops
+    t = _tile(cloud, reso)
+    f = t.sort_rows(feat.to(_dev())).requires_grad_(True)
+    pooled = ops.pool_mean(t, f)
+    pooled.backward(t.sort_rows(gout.to(_dev())))
+    return t.unsort_rows(pooled.detach()).cpu().numpy(), t.unsort_rows(f.grad).cpu().numpy()
+
+
+def test_pool_mean_golden():
+    """scatter_type='mean' pooling (pointnet.py:55-56, 92-99) against the reference's own pool_local: the stable sort
+    keeps the point order inside a cell, so the sums -- and the means -- are the reference's bit for bit."""
+    g = load_golden("pool_local_mean")
+    for reso in (4, 16):
+        cloud = torch.cat([torch.from_numpy(g[f"xy_r{reso}"]), torch.zeros(1, 300, 1)], 2)
+        got, got_g = _pool_mean_case(cloud, torch.from_numpy(g[f"feat_r{reso}"]), reso, torch.from_numpy(g[f"gout_r{reso}"]))
+        assert np.array_equal(got, g[f"out_r{reso}"])
+        assert np.array_equal(got_g, g[f"gfeat_r{reso}"])
+
+
+@pytest.mark.parametrize("n,reso,c,batch", [(300, 4, 8, 1), (300, 16, 32, 2), (5000, 64, 32, 1), (777, 16, 12, 1),
+                                            (40000, 256, 32, 1), (3000, 32, 6, 1), (1000, 8, 512, 1)])
+def test_pool_mean_vs_oracle(n, reso, c, batch):
+    from oracle import torch_ref, c_oracle
+    g = torch.Generator().manual_seed(n + c)
+    cloud = synth_cloud(n, seed=n, batch=batch)
+    feat = torch.randn(batch, n, c, generator=g)
+    gout = torch.randn(batch, n, c, generator=g)
+    got, got_g = _pool_mean_case(cloud, feat, reso, gout)
+    idx = torch.from_numpy(c_oracle.coordinate2index(cloud.numpy(), reso))
+    f = feat.clone().requires_grad_(True)
+    want = torch_ref.pool_local(idx, f, reso, "mean")
+    want.backward(gout)
+    assert np.array_equal(got.reshape(batch, n, c), want.detach().numpy())
+    assert np.array_equal(got_g.reshape(batch, n, c), f.grad.numpy())
+
+
 @pytest.mark.parametrize("n,reso,c,level,batch", [(257, 4, 8, 0, 1), (257, 16, 8, 0, 1), (257, 32, 12, 0, 1),
                                                   (5000, 64, 32, 0, 2), (5000, 64, 64, 1, 1), (5000, 64, 128, 3, 1),
                                                   (40000, 256, 32, 0, 1), (20000, 256, 512, 3, 1), (3000, 256, 256, 8, 1)])

@@ -55,6 +55,18 @@ def test_pool_local(reso):
     np.testing.assert_allclose(gfeat, g[f"gfeat_r{reso}"], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("reso", [4, 16])
+def test_pool_local_mean(reso):
+    """scatter_type='mean' (pointnet.py:55-56): the oracle's pool_local against the reference's own call."""
+    g = load_golden("pool_local_mean")
+    feat = torch.from_numpy(g[f"feat_r{reso}"]).requires_grad_(True)
+    idx = torch.from_numpy(g[f"index_r{reso}"])
+    out = torch_ref.pool_local(idx, feat, reso, "mean")
+    np.testing.assert_array_equal(out.detach().numpy(), g[f"out_r{reso}"])
+    out.backward(torch.from_numpy(g[f"gout_r{reso}"]))
+    np.testing.assert_allclose(feat.grad.numpy(), g[f"gfeat_r{reso}"], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("reso", [4, 16, 32])
 def test_scatter_mean_plane(reso):
     g = load_golden("scatter_mean_plane")
@@ -124,6 +136,21 @@ def test_local_pool_pointnet_reduced():
     none_grad = [k for k, v in enc.named_parameters() if v.grad is None]
     assert none_grad == g["none_grad"].tolist()
     assert len(none_grad) == 8          # up_convs[depth-2].{upconv,fc_comm,fc_c}: SURVEY a9
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            np.testing.assert_allclose(v.grad.numpy(), g["g." + k], rtol=1e-4, atol=1e-5)
+
+
+def test_local_pool_pointnet_reduced_mean():
+    g = load_golden("local_pool_pointnet_reduced_mean")
+    enc = torch_ref.LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="mean", unet_type="alto",
+                                      unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8),
+                                      plane_resolution=16)
+    enc.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=True)
+    out = enc(torch.from_numpy(g["cloud"]))["xy"]
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    out.backward(torch.from_numpy(g["gout"]))
+    assert [k for k, v in enc.named_parameters() if v.grad is None] == g["none_grad"].tolist()
     for k, v in enc.named_parameters():
         if v.grad is not None:
             np.testing.assert_allclose(v.grad.numpy(), g["g." + k], rtol=1e-4, atol=1e-5)

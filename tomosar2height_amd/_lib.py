@@ -29,6 +29,7 @@ SIGNATURES = {
     "t2h_pool_winner_stride": (_i, [_i]),
     "t2h_pool_max_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "t2h_pool_max_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "t2h_pool_mean": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "t2h_pool_rows_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _vp]),
     "t2h_pool_rows_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
     "t2h_segmean_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -82,6 +82,55 @@ __global__ __launch_bounds__(kThreads) void pool_max_fwd_kernel(const float *__r
     }
 }
 
+// scatter_type='mean' (pointnet.py:55-56, 92-99): every row receives the mean of its cell's rows -- scatter_mean (a sum
+// in point order, then one division by the count) + gather.  The operator is its own adjoint, so the backward is the
+// same kernel on the gradient (accumulate: out += instead of out =).
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void pool_mean_kernel(const float *__restrict__ feat, const int32_t *__restrict__ off0,
+                                                             int64_t ncells, int C, int ldf, int ldo, int lg, int accumulate,
+                                                             float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t cellid = t >> lg;
+    if (cellid >= ncells) return;
+    int s = off0[cellid], e = off0[cellid + 1];
+    if (s == e) return;
+    const float cnt = (float)(e - s);
+    int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        float sum[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum[j] = 0.0f;
+        int n = s;
+        for (; n + 3 < e; n += 4) {            // four row loads in flight, added in row order
+            Vec<VEC> v0 = Vec<VEC>::load(feat + (size_t)n * ldf + c);
+            Vec<VEC> v1 = Vec<VEC>::load(feat + (size_t)(n + 1) * ldf + c);
+            Vec<VEC> v2 = Vec<VEC>::load(feat + (size_t)(n + 2) * ldf + c);
+            Vec<VEC> v3 = Vec<VEC>::load(feat + (size_t)(n + 3) * ldf + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                sum[j] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(sum[j], v0.v[j]), v1.v[j]), v2.v[j]), v3.v[j]);
+        }
+        for (; n < e; ++n) {
+            Vec<VEC> v = Vec<VEC>::load(feat + (size_t)n * ldf + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sum[j] = __fadd_rn(sum[j], v.v[j]);
+        }
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = __fdiv_rn(sum[j], cnt);
+        for (n = s; n < e; ++n) {
+            if (accumulate) {
+                Vec<VEC> a = Vec<VEC>::load(out + (size_t)n * ldo + c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a.v[j] = __fadd_rn(a.v[j], o.v[j]);
+                a.store(out + (size_t)n * ldo + c);
+            } else {
+                o.store(out + (size_t)n * ldo + c);
+            }
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void pool_max_bwd_kernel(const float *__restrict__ gpooled,
                                                                 const uint8_t *__restrict__ winner,
@@ -545,6 +594,11 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
 //     the extra (dummy) loads for the many empty cells cost more than the latency they hide: the walk is bound by the
 //     NUMBER of load instructions (~1.5 M wave-loads) plus ~35 M vector instructions, both proportional to the nine-fold
 //     visit, not by latency.
+//   * one wave per 4 x 4 pixel tile walking the rows of the 6 x 6 cells around it serially (row list and taps built 64
+//     rows at a time in LDS, accumulators in LDS, lane group = tap, 4-16 gradient rows in flight; bit-identical sums, a
+//     row visited by 1-4 tiles instead of 9 pixels): 138 us (r = 128, C = 128: 316 us against 74 for the per-cell
+//     partials) -- the walk is a chain of dependent LDS read-modify-writes and its length is the tile's row count,
+//     which the clustered clouds make very uneven (small buildings hold 20+ rows per cell); C = 32 took as long as 64.
 // What did pay: x * 0.5f instead of the IEEE division in unnormalize_clip (bit-identical), mostly in sample_fwd.
 
 // ------------------------------------------------------------------------------ coarse levels (many points / cell)
@@ -842,6 +896,28 @@ T2H_API int t2h_pool_max_bwd(const float *gpooled, int ldg, const uint8_t *winne
                            gpooled, winner, off0, ncells, C, ldg, ldo, g.lg, ws, accumulate, gfeat);
     }
     return check_launch("pool_max_bwd");
+}
+
+T2H_API int t2h_pool_mean(const float *feat, int ldf, const int32_t *off0, int B, int nbits, int C, int accumulate,
+                          float *out, int ldo, t2h_stream_t stream) {
+    if (!feat || !off0 || !out) return fail(T2H_ERR_ARG, "pool_mean: null pointer");
+    if (feat == out) return fail(T2H_ERR_ARG, "pool_mean: in-place call (a cell's rows are re-read while they are written)");
+    int rc = check_level("pool_mean", B, nbits, 0, C);
+    if (rc) return rc;
+    if (ldf < C || ldo < C) return fail(T2H_ERR_ARG, "pool_mean: row stride smaller than C");
+    int64_t ncells = (int64_t)B << (2 * nbits);
+    bool v4 = C % 4 == 0 && ldf % 4 == 0 && ldo % 4 == 0 && (uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0;
+    if (C % 4 == 0 && !v4) return fail(T2H_ERR_ARG, "pool_mean: rows must be 16-byte aligned when C %% 4 == 0");
+    if (v4) {
+        GroupCfg g = group_cfg<4>(C);
+        hipLaunchKernelGGL(pool_mean_kernel<4>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream), feat, off0,
+                           ncells, C, ldf, ldo, g.lg, accumulate, out);
+    } else {
+        GroupCfg g = group_cfg<1>(C);
+        hipLaunchKernelGGL(pool_mean_kernel<1>, dim3(grid_for(ncells, g.lg)), dim3(kThreads), 0, as_stream(stream), feat, off0,
+                           ncells, C, ldf, ldo, g.lg, accumulate, out);
+    }
+    return check_launch("pool_mean");
 }
 
 T2H_API int t2h_pool_rows_fwd(const float *feat, int ldf, const int32_t *cell, const int32_t *off0, int64_t n_rows, int C,

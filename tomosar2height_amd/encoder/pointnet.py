@@ -35,12 +35,9 @@ class LocalPoolPointnet(nn.Module):
         else:
             raise ValueError(f"Unknown unet_type: {unet_type}")
         self.reso_plane = plane_resolution
-        if scatter_type == "max":
-            self.scatter_type = "max"
-        elif scatter_type == "mean":
-            raise NotImplementedError("scatter_type='mean' pooling is not built (no reference config selects it)")
-        else:
+        if scatter_type not in ("max", "mean"):                                   # pointnet.py:53-58
             raise ValueError("Invalid scatter type")
+        self.scatter_type = scatter_type
         self.channels_last = False
         # check_domain=True: synchronise and raise on every forward.  Default: count on the device only; the running
         # total (out_of_domain_total) is read by Trainer at optimizer-step boundaries and by DSMGenerator per mosaic
@@ -62,8 +59,8 @@ class LocalPoolPointnet(nn.Module):
         return n
 
     def point_features(self, tile: TileIndex) -> torch.Tensor:
-        """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max-pools, fc_c."""
-        return mlp.point_trunk(tile, tile.pts, self.fc_pos, self.blocks, self.fc_c)
+        """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max- (or mean-) pools, fc_c."""
+        return mlp.point_trunk(tile, tile.pts, self.fc_pos, self.blocks, self.fc_c, self.scatter_type)
 
     def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
         """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``."""

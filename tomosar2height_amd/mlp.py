@@ -178,6 +178,14 @@ def _pool_bwd_(tile, gpooled, winner, gfeat, accumulate):
                   1 if accumulate else 0, op, ldo, _lib.stream(), nbytes=nbytes)
 
 
+def _pool_mean_(tile, src, dst, accumulate):
+    """dst (=|+=) per-cell mean of src, scatter_type='mean' (pointnet.py:55-56); its own adjoint, so also the backward."""
+    (sp, lds), (dp, ldd) = _rows(src, "pool src"), _rows(dst, "pool dst")
+    c = src.shape[1]
+    _lib.call("t2h_pool_mean", sp, lds, _lib.ptr(tile.off0), tile.B, tile.nbits, c, 1 if accumulate else 0, dp, ldd,
+              _lib.stream(), nbytes=(8 + (4 if accumulate else 0)) * c * tile.n_points + 4 * tile.n_points)
+
+
 def _empty(rows, cols, like):
     return torch.empty(rows, cols, dtype=torch.float32, device=like.device)
 
@@ -423,15 +431,16 @@ class _PointTrunk(torch.autograd.Function):
     (w_pos, b_pos, [w0, b0, w1, b1, ws] * n_blocks, w_c, b_c)."""
 
     @staticmethod
-    def forward(ctx, tile, pts, *params):
+    def forward(ctx, tile, pts, pool, *params):
         n_blocks = (len(params) - 4) // 5
+        ctx.pool = pool
         w_pos, b_pos = params[0], params[1]
         blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(n_blocks)]
         w_c, b_c = params[-2], params[-1]
         m = pts.shape[0]
         h = blocks[0][2].shape[0]
         ctx.tile, ctx.n_blocks, ctx.h = tile, n_blocks, h
-        if _fused_trunk_applicable(pts, params, n_blocks):
+        if pool == "max" and _fused_trunk_applicable(pts, params, n_blocks):
             out, nets, pooled, hrs, winners = _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
             ctx.fused = True                               # (block 0's input is recomputed from the points in the backward)
             ctx.save_for_backward(pts, *params, *nets, *pooled[1:], *hrs, *winners)
@@ -445,7 +454,9 @@ class _PointTrunk(torch.autograd.Function):
             last = i == n_blocks - 1
             nxt = _empty(m, h, pts) if last else _empty(m, 2 * h, pts)
             hrs.append(_resblock_fwd(cats[i], w0, b0, w1, b1, ws, nxt[:, :h]))     # pointnet.py:73,79
-            if not last:
+            if not last and pool == "mean":
+                _pool_mean_(tile, nxt[:, :h], nxt[:, h:], accumulate=False)        # pointnet.py:77-78, scatter_mean
+            elif not last:
                 win = torch.empty(m, _lib.load().t2h_pool_winner_stride(h), dtype=torch.uint8, device=pts.device)
                 _pool_fwd_(tile, nxt[:, :h], nxt[:, h:], win)                      # pointnet.py:77-78
                 winners.append(win)
@@ -473,7 +484,7 @@ class _PointTrunk(torch.autograd.Function):
         if ctx.fused:
             rest = saved[1 + n_params:]
             nets, pooled, hrs, winners = rest[:nb], [None, *rest[nb:2 * nb - 1]], rest[2 * nb - 1:3 * nb - 1], rest[3 * nb - 1:]
-            return (None, None, *_trunk_backward_fused(tile, pts, params, nets, pooled, hrs, winners, g_out.contiguous()))
+            return (None, None, None, *_trunk_backward_fused(tile, pts, params, nets, pooled, hrs, winners, g_out.contiguous()))
         dw_c, db_c = _wgrad(g_out, cats[-1], w_c, b_c, relu_in=True)
         g = linear_dgrad_(g_out, w_c, torch.empty_like(cats[-1]), mask=cats[-1])     # grad of the last block output
         grads = [None] * n_params
@@ -484,19 +495,24 @@ class _PointTrunk(torch.autograd.Function):
             grads[2 + 5 * i: 7 + 5 * i] = [dw0, db0, dw1, db1, dws]
             if i > 0:
                 # dx = [d net | d pooled]: fold the pool's gradient into the left half, which is then d(net_i)
-                _pool_bwd_(tile, dx[:, h:], winners[i - 1], dx[:, :h], accumulate=True)
+                if ctx.pool == "mean":
+                    _pool_mean_(tile, dx[:, h:], dx[:, :h], accumulate=True)
+                else:
+                    _pool_bwd_(tile, dx[:, h:], winners[i - 1], dx[:, :h], accumulate=True)
                 g = dx[:, :h]
             else:
                 g = dx
         grads[0], grads[1] = _wgrad(g, pts, w_pos, b_pos)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
-def point_trunk(tile, pts, fc_pos, blocks, fc_c) -> torch.Tensor:
+def point_trunk(tile, pts, fc_pos, blocks, fc_c, pool="max") -> torch.Tensor:
+    """``pool``: 'max' (scatter_max, every shipped config) or 'mean' (scatter_mean; block-by-block kernels only -- the
+    fused trunk block of csrc/trunk.hip carries the max pooling in its loader)."""
     params = [fc_pos.weight, fc_pos.bias]
     for b in blocks:
         if b.shortcut is None:
             raise NotImplementedError("trunk blocks always change width (2h -> h) and so carry a shortcut")
         params += [b.fc_0.weight, b.fc_0.bias, b.fc_1.weight, b.fc_1.bias, b.shortcut.weight]
     params += [fc_c.weight, fc_c.bias]
-    return _PointTrunk.apply(tile, pts, *params)
+    return _PointTrunk.apply(tile, pts, pool, *params)

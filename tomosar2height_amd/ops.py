@@ -92,6 +92,35 @@ def pool_max(tile: TileIndex, feat: torch.Tensor) -> torch.Tensor:
     return _PoolMax.apply(feat, tile)
 
 
+class _PoolMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, tile: TileIndex):
+        feat = _f32(feat, "pool_mean").contiguous()
+        _lib.require_device(feat, what="pool_mean")
+        n, c = feat.shape
+        if n != tile.n_points:
+            raise ValueError(f"pool_mean: {n} feature rows for a tile of {tile.n_points} points")
+        pooled = torch.empty_like(feat)
+        _lib.call("t2h_pool_mean", _lib.ptr(feat), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, 0, _lib.ptr(pooled), c,
+                  _lib.stream(), nbytes=8 * c * n + 4 * n)
+        ctx.tile, ctx.c = tile, c
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpooled):
+        gpooled = gpooled.contiguous()
+        tile, c = ctx.tile, ctx.c
+        gfeat = torch.empty_like(gpooled)
+        _lib.call("t2h_pool_mean", _lib.ptr(gpooled), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, 0, _lib.ptr(gfeat), c,
+                  _lib.stream(), nbytes=8 * c * tile.n_points + 4 * tile.n_points)
+        return gfeat, None
+
+
+def pool_mean(tile: TileIndex, feat: torch.Tensor) -> torch.Tensor:
+    """Per-cell mean at the finest level, broadcast back to every point (pointnet.py:92-99 with scatter_type='mean')."""
+    return _PoolMean.apply(feat, tile)
+
+
 # --------------------------------------------------------------------------------------- scatter_mean -> plane
 class _RasteriseMean(torch.autograd.Function):
     @staticmethod
