@@ -156,6 +156,19 @@ int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *
 int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                        int level, int C, const float *addend, float *gplane_nhwc, void *workspace,
                        size_t workspace_bytes, t2h_stream_t stream);
+/* The same backward through the transposed sampling matrix, for callers that sample one tile at one level more than once
+ * (the training step: three backwards at r = 256, two at r = 128; the points do not move in between).  build: a CSR over
+ * the pixels of level `level`, numbered in Morton order inside a tile -- offsets [t2h_sample_adjoint_offsets_len()] int32
+ * (B * r * r + 1 offsets, then scratch), entries [4 * B * N] pairs (int32 row, float weight), a pixel's entries in the
+ * order t2h_sample_bwd visits them -- from the points and the tile index.  bwd_adjoint: gplane =
+ * [addend +] S^T gout with those entries; the sums are bit-identical to t2h_sample_bwd's per-pixel gather (same order,
+ * same roundings).  Measured at N = 131072, r = 256, C = 64: see DESIGN.md section 4. */
+size_t t2h_sample_adjoint_offsets_len(int B, int nbits, int level);
+int t2h_sample_adjoint_build(const float *pts, int dim, const int32_t *off0, int B, int N, int nbits, int level,
+                             int32_t *offsets, void *entries, t2h_stream_t stream);
+int t2h_sample_bwd_adjoint(const float *gout, const int32_t *offsets, const void *entries, int B, int nbits, int level, int C,
+                           const float *addend, float *gplane_nhwc, t2h_stream_t stream);
+
 int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
                           float *gplane_nhwc, t2h_stream_t stream);
 

@@ -56,6 +56,22 @@ for C, r in ((32, 256), (64, 256), (128, 128), (256, 64), (512, 32)):
             _lib.call("t2h_sample_bwd", _lib.ptr(feat), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), 1, N, tile.nbits, lvl,
                       C, _lib.ptr(gplane), _lib.ptr(ws), ws_bytes, _lib.stream())
         rows["sample_bwd"] = (timed(bwd), 4 * C * N + 8 * N + 4 * C * r * r)
+
+        # the same product through the transposed matrix (built once per tile and level, TileIndex.sample_adjoint)
+        def build():
+            tile._adjoint.clear()
+            tile.sample_adjoint(lvl)
+        rows["adjoint build"] = (timed(build), 2 * 9 * 8 * N + 8 * r * r + 32 * N)
+        offsets, entries = tile.sample_adjoint(lvl)
+        gplane2 = torch.empty(1, r, r, C, device=dev)
+
+        def bwd_adj():
+            _lib.call("t2h_sample_bwd_adjoint", _lib.ptr(feat), _lib.ptr(offsets), _lib.ptr(entries), 1, tile.nbits, lvl, C, None,
+                      _lib.ptr(gplane2), _lib.stream())
+        rows["sample_bwd adjoint"] = (timed(bwd_adj), 4 * C * N + 32 * N + 4 * C * r * r)
+        bwd(); bwd_adj(); torch.cuda.synchronize()
+        print("   adjoint == gather/partials bitwise:", bool(torch.equal(gplane, gplane2)),
+              " max |diff| %.3g" % float((gplane - gplane2).abs().max()))
     if args.only in ("", "segmean_fwd"):
         rows["segmean_fwd"] = (timed(lambda: ops.rasterise_mean(tile, feat, r, True)), 4 * C * N + 4 * N + 4 * C * r * r)
     for k, (us, nbytes) in rows.items():

@@ -113,6 +113,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_sample_bwd": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n),
         "t2h_sample_bwd_add": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, n, 0, n),
         "t2h_sample_bwd_atomic": (n, n, 3, 1, 10, 32, 32, n, n),
+        "t2h_sample_adjoint_build": (n, 3, n, 1, 10, 8, 0, n, n, n),
+        "t2h_sample_bwd_adjoint": (n, n, n, 1, 8, 0, 32, n, n, n),
         "t2h_linear_fwd": (n, 32, n, n, n, 32, 10, 32, 32, 0, n),
         "t2h_linear_fwd_add": (n, 32, n, n, n, 32, n, 32, 10, 32, 32, 0, n),
         "t2h_linear_dgrad": (n, 32, n, n, 32, 10, 32, 32, n, 0, 0, n),

@@ -237,6 +237,46 @@ def test_sample_plane_vs_oracle(n, reso, c, level, batch, cl):
     assert torch.equal(first, p.grad)
 
 
+@pytest.mark.parametrize("n,reso,c,level,batch", [(9000, 256, 64, 0, 1), (30000, 256, 128, 1, 2), (40000, 256, 32, 0, 1),
+                                                  (3000, 32, 16, 0, 1), (131072, 256, 64, 0, 1), (300, 8, 64, 0, 3),
+                                                  (5000, 64, 12, 1, 1), (2000, 256, 20, 8, 1), (60000, 256, 256, 2, 1)])
+def test_sample_bwd_through_the_transposed_matrix_is_bit_identical_to_the_gather(n, reso, c, level, batch):
+    """t2h_sample_adjoint_build + t2h_sample_bwd_adjoint (the CSR of the transposed sampling matrix, cached per tile and
+    level) list a pixel's (row, weight) entries in the order the per-pixel gather visits them: identical bits, with and
+    without an addend; every point contributes at most four entries and the weights of a point sum to <= 1."""
+    from tomosar2height_amd import _lib
+    g = torch.Generator().manual_seed(n + c)
+    t = _tile(synth_cloud(n, seed=n + 1, batch=batch), reso)
+    r = reso >> level
+    gout = torch.randn(batch * n, c, generator=g).to(_dev())
+    addend = torch.randn(batch, r, r, c, generator=g).to(_dev())
+    offsets, entries = t.sample_adjoint(level)
+    assert t.sample_adjoint(level)[0] is offsets                       # cached
+    off = offsets[:batch * r * r + 1].cpu().numpy()
+    assert off[0] == 0 and (np.diff(off) >= 0).all() and off[-1] <= 4 * batch * n
+    ent = entries[:off[-1]].cpu().numpy()
+    w = ent[:, 1].copy().view(np.float32)
+    assert ent[:, 0].min() >= 0 and ent[:, 0].max() < batch * n and (w >= 0).all() and (w <= 1).all()
+    per_point = np.bincount(ent[:, 0], weights=w.astype(np.float64), minlength=batch * n)
+    assert per_point.max() <= 1 + 1e-5 and np.bincount(ent[:, 0], minlength=batch * n).max() <= 4
+    for add in (None, addend):
+        a = torch.full((batch, r, r, c), float("nan"), device=_dev())
+        _lib.call("t2h_sample_bwd_adjoint", _lib.ptr(gout), _lib.ptr(offsets), _lib.ptr(entries), batch, t.nbits, level, c,
+                  None if add is None else _lib.ptr(add), _lib.ptr(a), _lib.stream())
+        b = torch.full((batch, r, r, c), float("nan"), device=_dev())
+        # the reference run: float atomics are not bit-stable, so compare with the deterministic kernels -- bit for bit with
+        # the gather, to rounding with the per-cell partials the coarse levels use
+        lib = _lib.load()
+        ws_bytes = lib.t2h_sample_bwd_workspace_bytes(batch, n, t.nbits, level, c)
+        ws = _lib.workspace(ws_bytes, _dev())
+        _lib.call("t2h_sample_bwd_add", _lib.ptr(gout), _lib.ptr(t.pts), t.dim, _lib.ptr(t.off0), batch, n, t.nbits, level, c,
+                  None if add is None else _lib.ptr(add), _lib.ptr(b), _lib.ptr(ws), ws_bytes, _lib.stream())
+        if ws_bytes == 0:
+            assert torch.equal(a, b)
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
 def test_sample_plane_golden():
     from tomosar2height_amd import ops
     g = load_golden("grid_sample_points")

@@ -39,6 +39,9 @@ SIGNATURES = {
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_sample_bwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "t2h_sample_adjoint_offsets_len": (_sz, [_i, _i, _i]),
+    "t2h_sample_adjoint_build": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "t2h_sample_bwd_adjoint": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_sample_bwd_add": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_atomic": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_linear_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -601,6 +601,161 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_kernel(const float *__res
 //     which the clustered clouds make very uneven (small buildings hold 20+ rows per cell); C = 32 took as long as 64.
 // What did pay: x * 0.5f instead of the IEEE division in unnormalize_clip (bit-identical), mostly in sample_fwd.
 
+// ---------------------------------------------------------------- sample backward through the transposed matrix
+// The bilinear sample is a sparse matrix S [points x pixels] with four entries per row; its backward is S^T g.  The gather
+// above re-derives S^T on every call (nine cells scanned per pixel, taps recomputed in every lane: ~34 M wave
+// instructions at r = 256, C = 64).  The points of a tile do not move between the calls of one training step -- three
+// sample backwards at r = 256, two at r = 128 -- so S^T is built once per (tile, level) as a CSR over pixels: entries
+// (row, weight) of a pixel in exactly the order the gather visits them (cells row-major, rows sorted), which keeps the sums
+// bit-identical.  A backward is then one pass over ~4 N entries: 16-byte row loads, one multiply-add per channel.
+//   adjoint_scan_kernel<false>: entries per 16-pixel workgroup; adjoint_offsets_kernel: their exclusive prefix sum (one
+//   workgroup); adjoint_scan_kernel<true>: offsets + fill; sample_bwd_adjoint_kernel: the product.
+// 16 lanes per pixel, lane q < 9 scans the rows of neighbour cell q (a handful of rows each: short dependent-load chains,
+// 16 x the waves of a lane-per-pixel walk); the entries of a pixel are laid out q-major, rows ascending.  Pixels are
+// numbered in Morton order (gid); a workgroup owns 16 consecutive pixels.
+//   FILL = false: block_sums[blockIdx + 1] = entries of the workgroup's pixels
+//   FILL = true : offsets[gid] = first entry of pixel gid (block_sums now holds the exclusive block offsets), entries filled
+template <bool FILL>
+__global__ __launch_bounds__(kThreads) void adjoint_scan_kernel(const float *__restrict__ pts, int dim,
+                                                                const int32_t *__restrict__ off0, int64_t npix, int nbits,
+                                                                int level, int32_t *__restrict__ block_sums,
+                                                                int32_t *__restrict__ offsets, int2 *__restrict__ entries) {
+    __shared__ int pix_tot[kThreads / 16];
+    const int tid = threadIdx.x, pl = tid >> 4, q = tid & 15;
+    const int64_t gid = (int64_t)blockIdx.x * (kThreads / 16) + pl;
+    const int rbits = nbits - level, r = 1 << rbits;
+    const bool live = gid < npix;
+    const int b = (int)(gid >> (2 * rbits));
+    const uint32_t pm = (uint32_t)(gid & (((int64_t)1 << (2 * rbits)) - 1));
+    const int py = (int)compact1by1(pm >> 1), px = (int)compact1by1(pm);
+    int s = 0, e = 0;
+    if (live && q < 9) {
+        const int cy = py - 1 + q / 3, cx = px - 1 + q % 3;
+        if (cx >= 0 && cx < r && cy >= 0 && cy < r) {
+            const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)morton2((uint32_t)cx, (uint32_t)cy) << (2 * level));
+            s = off0[obase]; e = off0[obase + ((size_t)1 << (2 * level))];
+        }
+    }
+    int count = 0;
+    for (int n = s; n < e; ++n) {
+        const Taps t = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+        count += ((t.x0 == px || t.x0 + 1 == px) && (t.y0 == py || t.y0 + 1 == py)) ? 1 : 0;
+    }
+    int incl = count;                                          // prefix over the pixel's 16 lanes
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int up = __shfl_up(incl, d, 16);
+        if (q >= d) incl += up;
+    }
+    if (q == 15) pix_tot[pl] = incl;
+    __syncthreads();
+    if (!FILL) {
+        if (tid == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int i = 0; i < kThreads / 16; ++i) tot += pix_tot[i];
+            block_sums[blockIdx.x + 1] = tot;
+        }
+        return;
+    }
+    int start = block_sums[blockIdx.x];
+    for (int i = 0; i < pl; ++i) start += pix_tot[i];
+    if (live && q == 15) {
+        offsets[gid] = start;
+        if (gid == npix - 1) offsets[npix] = start + incl;
+    }
+    int at = start + incl - count;
+    for (int n = s; n < e; ++n) {
+        const Taps t = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+        if ((t.x0 == px || t.x0 + 1 == px) && (t.y0 == py || t.y0 + 1 == py)) {
+            const float wx = t.x0 == px ? t.wx0 : t.wx1, wy = t.y0 == py ? t.wy0 : t.wy1;
+            entries[at++] = make_int2(n, __float_as_int(__fmul_rn(wx, wy)));
+        }
+    }
+}
+
+// in place: offsets[0] = 0, offsets[i + 1] = counts summed up to and including pixel i  (n = number of pixels)
+__global__ __launch_bounds__(1024) void adjoint_offsets_kernel(int32_t *__restrict__ offsets, int64_t n) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry_s = 0; offsets[0] = 0; }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const int v = i < n ? offsets[i + 1] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (i < n) offsets[i + 1] = before + incl;
+        __syncthreads();
+        if (tid == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sample_bwd_adjoint_kernel(const float *__restrict__ gout,
+                                                                      const int32_t *__restrict__ offsets,
+                                                                      const int2 *__restrict__ entries, int64_t npix,
+                                                                      int rbits, int C, int lg,
+                                                                      const float *__restrict__ addend,
+                                                                      float *__restrict__ gplane) {
+    const int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t gid = t >> lg;
+    if (gid >= npix) return;
+    // pixels in Morton order inside a tile: the four pixels that read a row sit in the same or a neighbouring workgroup
+    const int64_t b = gid >> (2 * rbits);
+    const uint32_t pm = (uint32_t)(gid & (((int64_t)1 << (2 * rbits)) - 1));
+    const int py = (int)compact1by1(pm >> 1), px = (int)compact1by1(pm);
+    const int64_t pix = (b << (2 * rbits)) + ((int64_t)py << rbits) + px;
+    const int s = offsets[gid], e = offsets[gid + 1];                // the CSR is indexed by the Morton pixel number
+    const int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+        int k = s;
+        for (; k + 3 < e; k += 4) {                              // four rows in flight, added in entry order
+            const int2 e0 = entries[k], e1 = entries[k + 1], e2 = entries[k + 2], e3 = entries[k + 3];
+            const Vec<VEC> g0 = Vec<VEC>::load(gout + (size_t)e0.x * C + c);
+            const Vec<VEC> g1 = Vec<VEC>::load(gout + (size_t)e1.x * C + c);
+            const Vec<VEC> g2 = Vec<VEC>::load(gout + (size_t)e2.x * C + c);
+            const Vec<VEC> g3 = Vec<VEC>::load(gout + (size_t)e3.x * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                acc[j] = __fadd_rn(acc[j], __fmul_rn(__int_as_float(e0.y), g0.v[j]));
+                acc[j] = __fadd_rn(acc[j], __fmul_rn(__int_as_float(e1.y), g1.v[j]));
+                acc[j] = __fadd_rn(acc[j], __fmul_rn(__int_as_float(e2.y), g2.v[j]));
+                acc[j] = __fadd_rn(acc[j], __fmul_rn(__int_as_float(e3.y), g3.v[j]));
+            }
+        }
+        for (; k < e; ++k) {
+            const int2 e0 = entries[k];
+            const Vec<VEC> g0 = Vec<VEC>::load(gout + (size_t)e0.x * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(__int_as_float(e0.y), g0.v[j]));
+        }
+        Vec<VEC> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
+        const size_t at = (size_t)pix * C + c;
+        if (addend) {
+            Vec<VEC> a = Vec<VEC>::load(addend + at);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] = __fadd_rn(a.v[j], o.v[j]);
+        }
+        o.store(gplane + at);
+    }
+}
+
 // ------------------------------------------------------------------------------ coarse levels (many points / cell)
 // At coarse ALTO levels a cell holds tens to hundreds of points, so "one lane-group walks one cell" leaves the
 // chip idle and the 3x3 pixel gather re-reads every row ~9x.  Here one workgroup owns (cell, split): its rows
@@ -1067,6 +1222,49 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
           hipLaunchKernelGGL(sample_bwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                              gout, pts, dim, off0, B, nbits, level, C, g.lg, addend, gplane_nhwc); });
     return check_launch("sample_bwd");
+}
+
+T2H_API size_t t2h_sample_adjoint_offsets_len(int B, int nbits, int level) {
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits) return 0;
+    const int64_t npix = (int64_t)B << (2 * (nbits - level));
+    return (size_t)(npix + 1 + (npix + 15) / 16 + 1);
+}
+
+T2H_API int t2h_sample_adjoint_build(const float *pts, int dim, const int32_t *off0, int B, int N, int nbits, int level,
+                                     int32_t *offsets, void *entries, t2h_stream_t stream) {
+    if (!pts || !off0 || !offsets || !entries) return fail(T2H_ERR_ARG, "sample_adjoint_build: null pointer");
+    int rc = check_level("sample_adjoint_build", B, nbits, level, 1);
+    if (rc) return rc;
+    if (dim < 2 || N < 0 || (int64_t)B * N > ((int64_t)1 << 28)) return fail(T2H_ERR_ARG, "sample_adjoint_build: unsupported shape");
+    if ((uintptr_t)entries & 7) return fail(T2H_ERR_ARG, "sample_adjoint_build: entries must be 8-byte aligned");
+    const int64_t npix = (int64_t)B << (2 * (nbits - level));
+    const int64_t nblocks = (npix + 15) / 16;
+    int32_t *block_sums = offsets + npix + 1;                      // [nblocks + 1], behind the offsets proper
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(adjoint_scan_kernel<false>, dim3((unsigned)nblocks), dim3(kThreads), 0, s, pts, dim, off0, npix, nbits, level,
+                       block_sums, offsets, static_cast<int2 *>(entries));
+    hipLaunchKernelGGL(adjoint_offsets_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks);
+    hipLaunchKernelGGL(adjoint_scan_kernel<true>, dim3((unsigned)nblocks), dim3(kThreads), 0, s, pts, dim, off0, npix, nbits, level,
+                       block_sums, offsets, static_cast<int2 *>(entries));
+    return check_launch("sample_adjoint_build");
+}
+
+T2H_API int t2h_sample_bwd_adjoint(const float *gout, const int32_t *offsets, const void *entries, int B, int nbits, int level,
+                                   int C, const float *addend, float *gplane_nhwc, t2h_stream_t stream) {
+    if (!gout || !offsets || !entries || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd_adjoint: null pointer");
+    if (addend && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "sample_bwd_adjoint: addend must be 16-byte aligned");
+    int rc = check_level("sample_bwd_adjoint", B, nbits, level, C);
+    if (rc) return rc;
+    const int rbits = nbits - level;
+    const int64_t npix = (int64_t)B << (2 * rbits);
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL(sample_bwd_adjoint_kernel<4>, dim3(grid_for(npix, g.lg)), dim3(kThreads), 0, as_stream(stream), gout,
+                             offsets, static_cast<const int2 *>(entries), npix, rbits, C, g.lg, addend, gplane_nhwc); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL(sample_bwd_adjoint_kernel<1>, dim3(grid_for(npix, g.lg)), dim3(kThreads), 0, as_stream(stream), gout,
+                             offsets, static_cast<const int2 *>(entries), npix, rbits, C, g.lg, addend, gplane_nhwc); });
+    return check_launch("sample_bwd_adjoint");
 }
 
 T2H_API int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,

@@ -5,6 +5,8 @@ Reference seam: ``pool_local`` (pointnet.py:92-99), ``generate_pl
 (pointnet.py:101-111, alto.py:76-88), ``sample_plane_feature`` (alto.py:90-95), ``F.interpolate``
 (pixel.py:107).  No op here has a torch/CPU fallback.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -194,6 +196,33 @@ def rasterise_mean(tile: TileIndex, feat: torch.Tensor, reso: int, channels_last
 
 
 # --------------------------------------------------------------------------------------- grid_sample at points
+# Sample backward through the cached transposed matrix (TileIndex.sample_adjoint) where a level holds few rows per pixel
+# (N = 131072: r = 256 -- product 19-24 us against 60-80 us for the gather, build 47 us once for the level's three calls;
+# at r = 128 the product is 57 us against 73 us and no longer pays for its build); above SAMPLE_ADJOINT_MAX_ROWS rows per
+# pixel t2h_sample_bwd's gather / per-cell partials stay.  T2H_SAMPLE_ADJOINT=0 switches the path off (A/B).
+SAMPLE_ADJOINT = os.environ.get("T2H_SAMPLE_ADJOINT", "1") != "0"
+SAMPLE_ADJOINT_MAX_ROWS = float(os.environ.get("T2H_SAMPLE_ADJOINT_MAX_ROWS", "4"))
+
+
+def _sample_bwd(tile, gout, r, c, addend):
+    """gplane [B, r, r, C] = [addend +] (d sample / d plane)^T gout"""
+    level = tile.level(r)
+    gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
+    nbytes = 4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel() * (2 if addend is not None else 1)
+    if SAMPLE_ADJOINT and tile.n_points <= SAMPLE_ADJOINT_MAX_ROWS * tile.B * r * r and tile.n_points > 0:
+        offsets, entries = tile.sample_adjoint(level)
+        _lib.call("t2h_sample_bwd_adjoint", _lib.ptr(gout), _lib.ptr(offsets), _lib.ptr(entries), tile.B, tile.nbits, level, c,
+                  None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.stream(), nbytes=nbytes,
+                  tag=f"t2h_sample_bwd[C={c},r={r}]")
+        return gplane
+    ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+    ws = _lib.workspace(ws_bytes, gout.device)
+    _lib.call("t2h_sample_bwd_add", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+              tile.nbits, level, c, None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.ptr(ws),
+              ws_bytes, _lib.stream(), nbytes=nbytes, tag=f"t2h_sample_bwd[C={c},r={r}]")
+    return gplane
+
+
 class _SamplePlane(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plane, tile: TileIndex):
@@ -214,14 +243,7 @@ class _SamplePlane(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         tile, r, c = ctx.tile, ctx.r, ctx.c
-        gout = gout.contiguous()
-        gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
-        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c)
-        ws = _lib.workspace(ws_bytes, gout.device)
-        _lib.call("t2h_sample_bwd", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
-                  tile.nbits, tile.level(r), c, _lib.ptr(gplane), _lib.ptr(ws), ws_bytes, _lib.stream(),
-                  nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel(),
-                  tag=f"t2h_sample_bwd[C={c},r={r}]")
+        gplane = _sample_bwd(tile, gout.contiguous(), r, c, None)
         return from_nhwc(gplane, ctx.was_cl), None
 
 
@@ -240,16 +262,7 @@ class _SamplePlaneThru(torch.autograd.Function):
         tile, r, c = ctx.tile, ctx.r, ctx.c
         if gout is None:
             return gthru, None
-        gout = gout.contiguous()
-        addend = None if gthru is None else to_nhwc(gthru)
-        gplane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=gout.device)
-        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c)
-        ws = _lib.workspace(ws_bytes, gout.device)
-        _lib.call("t2h_sample_bwd_add", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
-                  tile.nbits, tile.level(r), c, None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.ptr(ws),
-                  ws_bytes, _lib.stream(),
-                  nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * gplane.numel() * (2 if addend is not None else 1),
-                  tag=f"t2h_sample_bwd[C={c},r={r}]")
+        gplane = _sample_bwd(tile, gout.contiguous(), r, c, None if gthru is None else to_nhwc(gthru))
         return from_nhwc(gplane, ctx.was_cl), None
 
 

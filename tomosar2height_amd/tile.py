@@ -53,6 +53,23 @@ class TileIndex:
                   _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0), _lib.ptr(self.status), _lib.ptr(ws),
                   ws_bytes, _lib.stream(), nbytes=16 * bn + 4 * cells)
         self.device = dev
+        self._adjoint = {}
+
+    def sample_adjoint(self, level: int):
+        """``(offsets, entries)`` of the transposed bilinear-sampling matrix at ALTO level ``level`` (CSR over the pixels,
+        ``t2h_sample_adjoint_build``), built on first use and kept for the tile's lifetime: every further sample backward
+        at this level is one pass over ~4 N (row, weight) entries instead of a nine-cell scan per pixel."""
+        hit = self._adjoint.get(level)
+        if hit is None:
+            npix = self.B << (2 * (self.nbits - level))
+            offsets = torch.empty(_lib.load().t2h_sample_adjoint_offsets_len(self.B, self.nbits, level), dtype=torch.int32,
+                                  device=self.device)
+            entries = torch.empty(max(4 * self.n_points, 1), 2, dtype=torch.int32, device=self.device)
+            _lib.call("t2h_sample_adjoint_build", _lib.ptr(self.pts), self.dim, _lib.ptr(self.off0), self.B, self.N, self.nbits,
+                      level, _lib.ptr(offsets), _lib.ptr(entries), _lib.stream(),
+                      nbytes=2 * 9 * 8 * self.n_points + 8 * npix + 32 * self.n_points)
+            hit = self._adjoint[level] = (offsets, entries)
+        return hit
 
     @property
     def n_points(self) -> int:
