@@ -98,6 +98,13 @@ __device__ inline void mfma_slab_f32(const float *a_base, const float *b_base, f
     }
 }
 
+// max(x, 0) as the one hardware instruction (v_max_f32 returns the other operand for a NaN, as fmaxf does)
+__device__ inline float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 struct EpilogueArgs {
     float *C;
     const float *bias, *mask;
@@ -118,6 +125,10 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
     constexpr int EP = 36;
     const int er = lane >> 3, ec = (lane & 7) * 4;
     if (!e.mask && !e.accum && !e.addend) {       // bias / ReLU only (every forward layer): nothing to read, no branches per pass
+        // A wave in its epilogue runs beside three waves per SIMD that issue MFMAs back to back and gets an issue slot only
+        // when none of them has one ready (profiles/mfma_corun_lab.hip): its duration is its instruction count.  So: one
+        // instruction per ReLU (relu1: fmaxf costs two, it first quiets the operand), the row pointer
+        // formed once per tile, and no bounds tests for tiles that lie inside the matrix.
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -129,13 +140,28 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (bias_pre) bv = bias_pre[j];
                 else if (e.bias && col < e.N) bv = *reinterpret_cast<const float4 *>(e.bias + col);
+                float *rowp = e.C + (size_t)(row0 + er) * e.ldc + col;
+                const size_t step = (size_t)8 * e.ldc;
+                float4 v[4];
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
-                    const int row = row0 + pass * 8 + er;
-                    float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (e.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (row < e.M && col < e.N) *reinterpret_cast<float4 *>(e.C + (size_t)row * e.ldc + col) = v;
+                    v[pass] = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * EP + ec);
+                    v[pass].x += bv.x; v[pass].y += bv.y; v[pass].z += bv.z; v[pass].w += bv.w;
+                }
+                if (e.relu_out) {
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        v[pass].x = relu1(v[pass].x); v[pass].y = relu1(v[pass].y);
+                        v[pass].z = relu1(v[pass].z); v[pass].w = relu1(v[pass].w);
+                    }
+                }
+                if (row0 + 32 <= e.M && col_base + j * 32 + 32 <= e.N) {       // wave-uniform: the tile lies inside the matrix
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) *reinterpret_cast<float4 *>(rowp + pass * step) = v[pass];
+                } else {
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass)
+                        if (row0 + pass * 8 + er < e.M && col < e.N) *reinterpret_cast<float4 *>(rowp + pass * step) = v[pass];
                 }
             }
         return;
