@@ -197,7 +197,7 @@ def rasterise_mean(tile: TileIndex, feat: torch.Tensor, reso: int, channels_last
 
 # --------------------------------------------------------------------------------------- grid_sample at points
 # Sample backward through the cached transposed matrix (TileIndex.sample_adjoint) where a level holds few rows per pixel
-# (N = 131072: r = 256 -- product 19-24 us against 60-80 us for the gather, build 47 us once for the level's three calls;
+# (N = 131072: r = 256 -- product 16-21 us against 60-80 us for the gather, build 47 us once for the level's three calls;
 # at r = 128 the product is 57 us against 73 us and no longer pays for its build); above SAMPLE_ADJOINT_MAX_ROWS rows per
 # pixel t2h_sample_bwd's gather / per-cell partials stay.  T2H_SAMPLE_ADJOINT=0 switches the path off (A/B).
 SAMPLE_ADJOINT = os.environ.get("T2H_SAMPLE_ADJOINT", "1") != "0"
