@@ -249,6 +249,12 @@ int t2h_maxpool2x2_nhwc_bwd_add(const float *gout, const uint8_t *which, int B, 
                                 float *gin, t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
                                    t2h_stream_t stream);
+/* nn.Upsample(mode='bilinear', scale_factor=2) -- align_corners=False, ATen's half-pixel source index -- on NHWC planes:
+ * the non-parametric up path upconv2x2(mode='upsample') puts in front of a 1x1 convolution (alto.py:23-35, unet.py).
+ * in [B, h, w, C] -> out [B, 2h, 2w, C]; the backward gathers, per input pixel, the output pixels that read it in raster
+ * order (no atomics). */
+int t2h_upsample2x_nhwc_fwd(const float *in, int B, int C, int h, int w, float *out, t2h_stream_t stream);
+int t2h_upsample2x_nhwc_bwd(const float *gout, int B, int C, int h, int w, float *gin, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3 grid convolutions as implicit GEMMs on the matrix cores (exact fp32) -- SURVEY 8f-1, second step.

@@ -103,21 +103,26 @@ class _AltoDown(nn.Module):
         return pooled, raster, after_conv, c
 
 
+def _upconv2x2(cin, cout, mode="transpose"):
+    """alto.py:23-35 / unet.py: transposed convolution, or (mode='upsample') bilinear x2 followed by a 1x1 convolution."""
+    if mode == "transpose":
+        return nn.ConvTranspose2d(cin, cout, 2, stride=2)
+    return nn.Sequential(nn.Upsample(mode="bilinear", scale_factor=2), nn.Conv2d(cin, cout, 1))
+
+
 class _AltoUp(nn.Module):
     """alto.py:141-257 (UpConv)."""
 
     def __init__(self, cin, cout, i, depth, merge_mode="concat", up_mode="transpose"):
         super().__init__()
-        if up_mode != "transpose":
-            raise NotImplementedError("oracle restates up_mode='transpose' (the only mode any config selects)")
         self.last = i == depth - 2
         self.merge_mode = merge_mode
-        self.upconv = nn.ConvTranspose2d(cin, cout, 2, stride=2)
+        self.upconv = _upconv2x2(cin, cout, up_mode)
         if self.last:
             self.upconv_noup = nn.Conv2d(cin, cout, 1)
         self.fc_comm = nn.Sequential(nn.Linear(cout, 2 * cout), nn.ReLU(), nn.Linear(2 * cout, cout))
         self.fc_c = nn.Linear(cin, cout)
-        self.conv1x1 = nn.Conv2d(cin, cout, 1) if self.last else nn.ConvTranspose2d(cin, cout, 2, stride=2)
+        self.conv1x1 = nn.Conv2d(cin, cout, 1) if self.last else _upconv2x2(cin, cout, up_mode)
         self.conv1 = nn.Conv2d(2 * cout if merge_mode == "concat" else cout, cout, 3, padding=1)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
 
@@ -190,10 +195,10 @@ class _PlainDown(nn.Module):
 
 
 class _PlainUp(nn.Module):
-    def __init__(self, cin, cout, merge_mode="concat"):
+    def __init__(self, cin, cout, merge_mode="concat", up_mode="transpose"):
         super().__init__()
         self.merge_mode = merge_mode
-        self.upconv = nn.ConvTranspose2d(cin, cout, 2, stride=2)
+        self.upconv = _upconv2x2(cin, cout, up_mode)
         self.conv1 = nn.Conv2d(2 * cout if merge_mode == "concat" else cout, cout, 3, padding=1)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
 
@@ -209,8 +214,10 @@ class PlainUNet(nn.Module):
     def __init__(self, num_classes, in_channels=3, depth=5, start_filts=64, up_mode="transpose",
                  merge_mode="concat", **kwargs):
         super().__init__()
-        if up_mode != "transpose":
-            raise NotImplementedError("oracle restates up_mode='transpose' only")
+        if up_mode not in ("transpose", "upsample"):
+            raise ValueError(f"Invalid up_mode: {up_mode}")
+        if up_mode == "upsample" and merge_mode == "add":
+            raise ValueError("up_mode 'upsample' is incompatible with merge_mode 'add'.")
         downs, ups = [], []
         outs = in_channels
         for i in range(depth):
@@ -219,7 +226,7 @@ class PlainUNet(nn.Module):
             downs.append(_PlainDown(ins, outs, pooling=i < depth - 1))
         for _ in range(depth - 1):
             ins, outs = outs, outs // 2
-            ups.append(_PlainUp(ins, outs, merge_mode))
+            ups.append(_PlainUp(ins, outs, merge_mode, up_mode))
         self.down_convs = nn.ModuleList(downs)
         self.up_convs = nn.ModuleList(ups)
         self.conv_final = nn.Conv2d(outs, num_classes, 1)

@@ -298,6 +298,47 @@ def mean_pool_fixture():
     save("local_pool_pointnet_reduced_mean", **arrs)
 
 
+def upsample_mode_fixture():
+    """up_mode='upsample' (alto.py:23-35, unet.py; no shipped config selects it): the reduced LocalPoolPointnet of fixture
+    (6) with the ALTO U-Net's non-parametric up path, and a small plain image U-Net."""
+    import_reference()
+    from tomosar2height.encoder.pointnet import LocalPoolPointnet
+    from tomosar2height.encoder.unet import UNet
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8, up_mode="upsample"),
+                            plane_resolution=16)
+    det_init_(enc, seed=6)
+    cloud = synth_cloud(256, seed=40)
+    out = enc(cloud)["xy"]
+    g = torch.Generator().manual_seed(6)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    arrs = {"cloud": cloud, "out": out, "gout": gout}
+    none_grad = []
+    for k, v in enc.state_dict().items():
+        arrs["w." + k] = v
+    for k, v in enc.named_parameters():
+        if v.grad is None:
+            none_grad.append(k)
+        else:
+            arrs["g." + k] = v.grad
+    arrs["none_grad"] = np.array(none_grad)
+    save("local_pool_pointnet_reduced_upsample", **arrs)
+
+    net = det_init_(UNet(8, in_channels=4, depth=3, start_filts=8, up_mode="upsample", merge_mode="concat"), seed=9)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 4, 16, 16, generator=g, requires_grad=True)
+    y = net(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    arrs = {"x": x, "y": y, "gy": gy, "gx": x.grad}
+    for k, v in net.state_dict().items():
+        arrs["w." + k] = v
+    for k, v in net.named_parameters():
+        arrs["g." + k] = v.grad
+    save("plain_unet_upsample", **arrs)
+
+
 def blend_weight_fixture():
     """(10) DSMGenerator._linear_blend_patch_weight (generator.py:85-113).  generator.py cannot be imported as a
     module here (dataset.py needs `transformations`), so the static method is compiled from the reference file where
@@ -438,6 +479,9 @@ if __name__ == "__main__":
     if "--only-mean" in sys.argv:
         mean_pool_fixture()
         sys.exit(0)
+    if "--only-upsample" in sys.argv:
+        upsample_mode_fixture()
+        sys.exit(0)
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         main()
     if "--only-producer" not in sys.argv:
@@ -447,3 +491,4 @@ if __name__ == "__main__":
         tile_producer_aug_fixture()
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         mean_pool_fixture()
+        upsample_mode_fixture()

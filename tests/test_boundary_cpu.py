@@ -123,6 +123,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upsample_bilinear_bwd": (n, 1, 32, 16, 16, 32, 32, n, n),
         "t2h_upsample_bilinear_nhwc_fwd": (n, n, 1, 32, 16, 16, 32, 32, n, n),
         "t2h_upsample_bilinear_nhwc_bwd": (n, 1, 32, 16, 16, 32, 32, n, n),
+        "t2h_upsample2x_nhwc_fwd": (n, 1, 32, 16, 16, n, n),
+        "t2h_upsample2x_nhwc_bwd": (n, 1, 32, 16, 16, n, n),
         "t2h_bias_relu_fwd": (n, n, 100, 32, 1, n),
         "t2h_bias_relu_bwd": (n, n, n, 100, 32, 1, 0, n, n, 0, n),
         "t2h_head1x1_fwd": (n, n, 4, n, n, 100, n, n),

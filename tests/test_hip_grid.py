@@ -104,3 +104,23 @@ def test_maxpool2x2_matches_aten_including_ties(b, c, h, w):
     y.backward(_cl(gout))
     assert torch.equal(y.detach().cpu(), yr.detach())
     assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,c,h,w", [(1, 8, 4, 4), (2, 32, 16, 8), (1, 64, 1, 1), (1, 16, 33, 5), (1, 256, 32, 32)])
+def test_upsample2x_matches_nn_upsample(b, c, h, w):
+    """grid.upsample2x == nn.Upsample(mode='bilinear', scale_factor=2) (align_corners=False), forward and backward, on CPU
+    torch as the reference (ATen's own arithmetic); odd sizes and 1 x 1 planes included."""
+    from tomosar2height_amd import grid
+    g = torch.Generator().manual_seed(b + c + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    gy = torch.randn(b, c, 2 * h, 2 * w, generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = torch.nn.Upsample(mode="bilinear", scale_factor=2)(xr)
+    want.backward(gy)
+    xd = x.to("cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    got = grid.upsample2x(xd)
+    assert got.is_contiguous(memory_format=torch.channels_last) or min(got.shape[1:]) == 1
+    got.backward(gy.to("cuda"))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)

@@ -66,6 +66,77 @@ def test_local_pool_pointnet_reduced_mean_golden():
         LocalPoolPointnet(scatter_type="median", unet_kwargs=dict(depth=3, start_filts=8), plane_resolution=16)
 
 
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_up_mode_upsample_golden(channels_last):
+    """up_mode='upsample' (alto.py:23-35, unet.py; no shipped config selects it) in both U-Nets against the reference's own
+    outputs: bilinear x2 (``t2h_upsample2x_nhwc_*``, align_corners=False) + 1x1 convolution on the GEMM kernels."""
+    import tomosar2height_amd as t2h
+    from tomosar2height_amd.encoder.pointnet import LocalPoolPointnet
+    from tomosar2height_amd.encoder.unet import UNet
+    t2h.allow_library_fallback(True).set()        # 8-channel planes: the 3x3 convolutions of this reduced model are MIOpen's
+    g = load_golden("local_pool_pointnet_reduced_upsample")
+    enc = LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                            unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8, up_mode="upsample"),
+                            plane_resolution=16)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert list(sd) == list(enc.state_dict())                     # nn.Sequential names: up_convs.N.upconv.1.weight
+    enc.load_state_dict(sd, strict=True)
+    enc.to(_dev())
+    enc.set_channels_last(channels_last)
+    out = enc(torch.from_numpy(g["cloud"]).to(_dev()))["xy"]
+    _close(out.detach().cpu().numpy(), g["out"], what="plane")
+    out.backward(torch.from_numpy(g["gout"]).to(_dev()))
+    assert [k for k, v in enc.named_parameters() if v.grad is None] == g["none_grad"].tolist()
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            _close(v.grad.cpu().numpy(), g["g." + k], rel=2e-4, what=k)
+    g = load_golden("plain_unet_upsample")
+    net = UNet(8, in_channels=4, depth=3, start_filts=8, up_mode="upsample")
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert list(sd) == list(net.state_dict())
+    net.load_state_dict(sd, strict=True)
+    net.to(_dev())
+    if hasattr(net, "set_channels_last"):
+        net.set_channels_last(channels_last)
+    x = torch.from_numpy(g["x"]).to(_dev()).requires_grad_(True)
+    y = net(x)
+    _close(y.detach().cpu().numpy(), g["y"], what="unet out")
+    y.backward(torch.from_numpy(g["gy"]).to(_dev()))
+    _close(x.grad.cpu().numpy(), g["gx"], rel=2e-4, what="unet gx")
+    for k, v in net.named_parameters():
+        _close(v.grad.cpu().numpy(), g["g." + k], rel=2e-4, what=k)
+    with pytest.raises(ValueError):
+        UNet(8, up_mode="upsample", merge_mode="add")
+
+
+def test_up_mode_upsample_runs_without_library_kernels():
+    """16-aligned widths: the whole upsample-mode U-Net (bilinear x2, 1x1 and 3x3 convolutions, pooling) on t2h kernels --
+    library fallbacks stay off and none is counted -- against the oracle's PlainUNet with the same weights."""
+    import tomosar2height_amd as t2h
+    from tomosar2height_amd.encoder.unet import UNet
+    from oracle import torch_ref
+    net = det_init_(UNet(16, in_channels=4, depth=3, start_filts=16, up_mode="upsample"), seed=11)
+    ref = torch_ref.PlainUNet(16, in_channels=4, depth=3, start_filts=16, up_mode="upsample")
+    ref.load_state_dict(net.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 4, 32, 32, generator=g)
+    gy = torch.randn(1, 16, 32, 32, generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = ref(xr)
+    want.backward(gy)
+    net.to(_dev())
+    net.set_channels_last(True)
+    before = sum(t2h.fallback_counts().values())
+    xd = x.to(_dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    got = net(xd)
+    got.backward(gy.to(_dev()))
+    assert sum(t2h.fallback_counts().values()) == before
+    _close(got.detach().cpu().numpy(), want.detach().numpy(), what="out")
+    _close(xd.grad.cpu().numpy(), xr.grad.numpy(), rel=2e-4, what="gx")
+    for (k, v), (_, vr) in zip(net.named_parameters(), ref.named_parameters()):
+        _close(v.grad.cpu().numpy(), vr.grad.numpy(), rel=2e-4, what=k)
+
+
 @pytest.mark.parametrize("mode", ["conv", "fc"])
 @pytest.mark.parametrize("foot", [False, True])
 @pytest.mark.parametrize("img", [False, True])

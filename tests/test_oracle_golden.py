@@ -156,6 +156,36 @@ def test_local_pool_pointnet_reduced_mean():
             np.testing.assert_allclose(v.grad.numpy(), g["g." + k], rtol=1e-4, atol=1e-5)
 
 
+def test_up_mode_upsample():
+    """up_mode='upsample' (alto.py:23-35, unet.py: bilinear x2 + 1x1 conv instead of the transposed convolution)."""
+    g = load_golden("local_pool_pointnet_reduced_upsample")
+    enc = torch_ref.LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                                      unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8, up_mode="upsample"),
+                                      plane_resolution=16)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert list(sd.keys()) == list(enc.state_dict().keys())
+    enc.load_state_dict(sd, strict=True)
+    out = enc(torch.from_numpy(g["cloud"]))["xy"]
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    out.backward(torch.from_numpy(g["gout"]))
+    assert [k for k, v in enc.named_parameters() if v.grad is None] == g["none_grad"].tolist()
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            np.testing.assert_allclose(v.grad.numpy(), g["g." + k], rtol=1e-4, atol=1e-5)
+    g = load_golden("plain_unet_upsample")
+    net = torch_ref.PlainUNet(8, in_channels=4, depth=3, start_filts=8, up_mode="upsample")
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert list(sd.keys()) == list(net.state_dict().keys())
+    net.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = net(x)
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-6, atol=1e-6)
+    y.backward(torch.from_numpy(g["gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        torch_ref.PlainUNet(8, up_mode="upsample", merge_mode="add")
+
+
 @pytest.mark.parametrize("mode", ["conv", "fc"])
 @pytest.mark.parametrize("foot", [False, True])
 @pytest.mark.parametrize("img", [False, True])

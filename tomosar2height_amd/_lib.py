@@ -59,6 +59,8 @@ SIGNATURES = {
     "t2h_head1x1_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_upsample_bilinear_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_upsample_bilinear_nhwc_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_upsample2x_nhwc_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_upsample2x_nhwc_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "t2h_relu_mask": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "t2h_conv3x3_fwd_workspace_bytes": (_sz, [_i] * 5),
     "t2h_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(kT) void head1x1_wgrad_kernel(HeadArgs a, const flo
 
 // ---------------------------------------------------------------------------------------------- NHWC bilinear upsample
 struct Lerp2 { int i0, i1; float l0, l1; };
-__device__ inline Lerp2 lerp_index2(float scale, int dst, int in_size) {
-    float real = __fmul_rn(scale, (float)dst);
+// half: align_corners=False source index (ATen area_pixel_compute_source_index: scale * (dst + 0.5) - 0.5, clamped at 0)
+__device__ inline Lerp2 lerp_index2(float scale, int dst, int in_size, int half = 0) {
+    float real = half ? fmaxf(__fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f), 0.0f) : __fmul_rn(scale, (float)dst);
     int a = min((int)real, in_size - 1);
     Lerp2 L;
     L.i0 = a; L.i1 = a + (a < in_size - 1 ? 1 : 0);
@@ -211,12 +212,12 @@ __device__ inline Lerp2 lerp_index2(float scale, int dst, int in_size) {
 // one lane-group (G lanes x float4) per output pixel
 __global__ __launch_bounds__(kT) void upsample_nhwc_fwd_kernel(const float *__restrict__ in, const float *__restrict__ addend,
                                                                int B, int h, int w, int H, int W, int C, int lg, float sh,
-                                                               float sw, float *__restrict__ out) {
+                                                               float sw, float *__restrict__ out, int half) {
     long long t = (long long)blockIdx.x * kT + threadIdx.x;
     long long pix = t >> lg;
     if (pix >= (long long)B * H * W) return;
     int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-    Lerp2 ly = lerp_index2(sh, y, h), lx = lerp_index2(sw, x, w);
+    Lerp2 ly = lerp_index2(sh, y, h, half), lx = lerp_index2(sw, x, w, half);
     const float *base = in + (size_t)b * h * w * C;
     const float *p00 = base + ((size_t)ly.i0 * w + lx.i0) * C, *p01 = base + ((size_t)ly.i0 * w + lx.i1) * C;
     const float *p10 = base + ((size_t)ly.i1 * w + lx.i0) * C, *p11 = base + ((size_t)ly.i1 * w + lx.i1) * C;
@@ -245,7 +246,7 @@ __device__ inline void source_range2(float scale, int i, int out_size, int &lo, 
 // one lane-group per INPUT pixel: gathers the output pixels whose taps touch it (deterministic, no atomics)
 __global__ __launch_bounds__(kT) void upsample_nhwc_bwd_kernel(const float *__restrict__ gout, int B, int h, int w, int H,
                                                                int W, int C, int lg, float sh, float sw,
-                                                               float *__restrict__ gin) {
+                                                               float *__restrict__ gin, int half) {
     long long t = (long long)blockIdx.x * kT + threadIdx.x;
     long long pix = t >> lg;
     if (pix >= (long long)B * h * w) return;
@@ -257,10 +258,10 @@ __global__ __launch_bounds__(kT) void upsample_nhwc_bwd_kernel(const float *__re
     for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int y = ylo; y <= yhi; ++y) {
-            Lerp2 ly = lerp_index2(sh, y, h);
+            Lerp2 ly = lerp_index2(sh, y, h, half);
             if (ly.i0 != iy && ly.i1 != iy) continue;
             for (int x = xlo; x <= xhi; ++x) {
-                Lerp2 lx = lerp_index2(sw, x, w);
+                Lerp2 lx = lerp_index2(sw, x, w, half);
                 if (lx.i0 != ix && lx.i1 != ix) continue;
                 float wgt = 0.f;
                 if (ly.i0 == iy && lx.i0 == ix) wgt = __fadd_rn(wgt, __fmul_rn(ly.l0, lx.l0));
@@ -470,7 +471,7 @@ T2H_API int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend,
     int lg = lg_for(C);
     long long threads = ((long long)B * H * W) << lg;
     hipLaunchKernelGGL(upsample_nhwc_fwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), in,
-                       addend, B, h, w, H, W, C, lg, sh, sw, out);
+                       addend, B, h, w, H, W, C, lg, sh, sw, out, 0);
     return check_launch("upsample_bilinear_nhwc_fwd");
 }
 
@@ -482,6 +483,27 @@ T2H_API int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int 
     int lg = lg_for(C);
     long long threads = ((long long)B * h * w) << lg;
     hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream),
-                       gout, B, h, w, H, W, C, lg, sh, sw, gin);
+                       gout, B, h, w, H, W, C, lg, sh, sw, gin, 0);
     return check_launch("upsample_bilinear_nhwc_bwd");
+}
+
+// nn.Upsample(mode='bilinear', scale_factor=2) (align_corners=False): the non-parametric up path of upconv2x2(mode='upsample')
+T2H_API int t2h_upsample2x_nhwc_fwd(const float *in, int B, int C, int h, int w, float *out, t2h_stream_t stream) {
+    if (!in || !out || B < 1 || C < 4 || C % 4 || h < 1 || w < 1 || h > 16384 || w > 16384)
+        return fail(T2H_ERR_ARG, "upsample2x_nhwc_fwd: bad argument (C %% 4 == 0 required)");
+    int lg = lg_for(C);
+    long long threads = ((long long)B * 2 * h * 2 * w) << lg;
+    hipLaunchKernelGGL(upsample_nhwc_fwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), in,
+                       (const float *)nullptr, B, h, w, 2 * h, 2 * w, C, lg, 0.5f, 0.5f, out, 1);
+    return check_launch("upsample2x_nhwc_fwd");
+}
+
+T2H_API int t2h_upsample2x_nhwc_bwd(const float *gout, int B, int C, int h, int w, float *gin, t2h_stream_t stream) {
+    if (!gout || !gin || B < 1 || C < 4 || C % 4 || h < 1 || w < 1 || h > 16384 || w > 16384)
+        return fail(T2H_ERR_ARG, "upsample2x_nhwc_bwd: bad argument (C %% 4 == 0 required)");
+    int lg = lg_for(C);
+    long long threads = ((long long)B * h * w) << lg;
+    hipLaunchKernelGGL(upsample_nhwc_bwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream),
+                       gout, B, h, w, 2 * h, 2 * w, C, lg, 0.5f, 0.5f, gin, 1);
+    return check_launch("upsample2x_nhwc_bwd");
 }

@@ -30,9 +30,11 @@ def conv1x1(in_channels, out_channels):
 
 
 def upconv2x2(in_channels, out_channels, mode="transpose"):
-    if mode != "transpose":
-        raise NotImplementedError("only up_mode='transpose' is built (the only mode any reference config selects)")
-    return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+    """alto.py:23-35: a 2x2 stride-2 transposed convolution, or (mode='upsample', no shipped config) bilinear x2 + 1x1 conv
+    with the reference's ``nn.Sequential`` parameter names (``.1.weight`` / ``.1.bias``)."""
+    if mode == "transpose":
+        return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+    return nn.Sequential(nn.Upsample(mode="bilinear", scale_factor=2), conv1x1(in_channels, out_channels))
 
 
 def _comm_layers(channels):
@@ -61,6 +63,8 @@ class _PointGridLevel(nn.Module):
             return conv(x) if addend is None else addend + conv(x)
         if isinstance(conv, nn.ConvTranspose2d):
             return grid.upconv2x2(x, conv, addend)
+        if isinstance(conv, nn.Sequential):                       # upconv2x2(mode='upsample')
+            return grid.upsample_conv1x1(x, conv, addend)
         return grid.conv1x1(x, conv, addend)
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):

@@ -39,15 +39,21 @@ class DownConv(_Level):
 class UpConv(_Level):
     def __init__(self, in_channels, out_channels, merge_mode="concat", up_mode="transpose"):
         super().__init__()
-        if up_mode != "transpose":
-            raise NotImplementedError("only up_mode='transpose' is built")
         self.merge_mode = merge_mode
-        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+        if up_mode == "transpose":                                # unet.py upconv2x2
+            self.upconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+        else:
+            self.upconv = nn.Sequential(nn.Upsample(mode="bilinear", scale_factor=2), nn.Conv2d(in_channels, out_channels, 1))
         self.conv1 = nn.Conv2d(2 * out_channels if merge_mode == "concat" else out_channels, out_channels, 3, padding=1)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
 
     def forward(self, from_down, from_up):
-        up = grid.upconv2x2(from_up, self.upconv) if self.channels_last else self.upconv(from_up)
+        if not self.channels_last:
+            up = self.upconv(from_up)
+        elif isinstance(self.upconv, nn.Sequential):
+            up = grid.upsample_conv1x1(from_up, self.upconv)
+        else:
+            up = grid.upconv2x2(from_up, self.upconv)
         x = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
         return self._conv_pair(x)
 

@@ -643,6 +643,43 @@ class _UpsampleCL(torch.autograd.Function):
         return gin, None, (g if ctx.has_addend else None)
 
 
+class _Upsample2x(torch.autograd.Function):
+    """nn.Upsample(mode='bilinear', scale_factor=2) (align_corners=False) on channels_last planes: upconv2x2(mode='upsample'),
+    alto.py:23-35 / unet.py."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _as_cl(x)
+        b, c, h, w = x.shape
+        out = _empty_cl(b, c, 2 * h, 2 * w, x.device)
+        _lib.call("t2h_upsample2x_nhwc_fwd", _lib.ptr(x), b, c, h, w, _lib.ptr(out), _lib.stream(),
+                  nbytes=4 * (x.numel() + out.numel()))
+        ctx.shape = (b, c, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, h, w = ctx.shape
+        g = _as_cl(g)
+        gin = _empty_cl(b, c, h, w, g.device)
+        _lib.call("t2h_upsample2x_nhwc_bwd", _lib.ptr(g), b, c, h, w, _lib.ptr(gin), _lib.stream(),
+                  nbytes=4 * (g.numel() + gin.numel()))
+        return gin
+
+
+def upsample2x(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 4 or x.shape[1] % 4 or not x.is_cuda or x.dtype != torch.float32:
+        _lib.library_fallback("nn.Upsample(scale_factor=2) on a plane with C % 4 != 0 (ATen)")
+        return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear")
+    return _Upsample2x.apply(x)
+
+
+def upsample_conv1x1(x: torch.Tensor, seq, addend: torch.Tensor = None) -> torch.Tensor:
+    """``seq(x)`` or ``addend + seq(x)`` for ``nn.Sequential(nn.Upsample(bilinear, x2), conv1x1)`` -- upconv2x2 with
+    mode='upsample' (alto.py:31-35)."""
+    return conv1x1(upsample2x(x), seq[1], addend)
+
+
 def upsample_bilinear_cl(x: torch.Tensor, size: int, addend: torch.Tensor = None) -> torch.Tensor:
     if x.shape[1] % 4 or not x.is_cuda:
         raise ValueError("upsample_bilinear_cl needs a device tensor with C % 4 == 0")
