@@ -442,7 +442,9 @@ def main():
             "dtype": {"fp32": "f32", "bf16": "f32 tensors, bf16-operand MFMA in the per-point GEMMs",
                       "bf16x3": "f32 tensors, per-point GEMM products via exact 3-way bf16 split (6 bf16 MFMAs)"}[args.mlp_precision],
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Berlin cloud-only, fp32, B=1 tile, "
+            "config": {"workload": ("BASELINE.json configs[2]: Berlin cloud+image" if args.use_image
+                                    else "BASELINE.json configs[1]: Berlin cloud-only")
+                                   + f", {args.mlp_precision} per-point GEMMs, B=1 tile, "
                                    f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
                                    f"optimize_every={args.optimize_every}",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every,
