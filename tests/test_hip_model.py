@@ -308,6 +308,33 @@ def test_full_size_properties():
     _close(h3.cpu().numpy(), h1.cpu().numpy(), what="point-order invariance")
 
 
+def test_full_size_backward_is_exactly_linear_in_the_upstream_gradient():
+    """BASELINE.json config 2 (N = 131072), whole backward: the gradient of sum(h * 2w) is bit for bit twice the gradient of
+    sum(h * w) -- doubling commutes with every rounding on the path (products, sums, the fixed-order reductions, the
+    transposed-matrix sample backward, the fused trunk), so any race, stale workspace or uninitialised read breaks it --
+    and a repeated backward reproduces the first."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import berlin_tile
+    model = det_init_(TomoSAR2Height(berlin_config()), seed=3).to(_dev())
+    model.set_channels_last(True)
+    cloud = berlin_tile(6)["inputs"].to(_dev())
+    w = torch.randn(1, 512, 512, 1, generator=torch.Generator().manual_seed(1)).to(_dev())
+
+    def grads(scale):
+        model.zero_grad(set_to_none=True)
+        h, _ = model(input_cloud=cloud)
+        (h * (w * scale)).sum().backward()
+        return {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    g1, g2, g1b = grads(1.0), grads(2.0), grads(1.0)
+    assert len(g1) > 100
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g1b[k]), f"{k}: two identical backwards differ"
+        assert torch.equal(g2[k], 2.0 * g1[k]), f"{k}: backward is not linear in the upstream gradient"
+
+
 def test_direct_grad_accumulation_matches_autograd():
     """From the second optimizer window on, Trainer lets the wgrad kernels accumulate straight into the flat
     gradient bucket; the accumulated gradients must equal plain autograd accumulation."""

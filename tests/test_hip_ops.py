@@ -441,3 +441,33 @@ def test_maxpool_thru_sums_the_two_gradients_bit_exactly():
     assert grid.maxpool2x2_thru(x1)[1].stride() == x1.stride()
     torch.autograd.backward([pooled, thru * 1.0], [gp, gother])
     assert torch.equal(a.grad, b.grad) and torch.equal(pooled, grid.maxpool2x2(x))
+
+
+@pytest.mark.parametrize("c,r", [(32, 256), (64, 256), (128, 128), (256, 64), (512, 32)])
+def test_full_size_point_grid_ops_are_adjoint_pairs(c, r):
+    """BASELINE.json config 2 sizes (N = 131072, every ALTO level shape): each linear operator and its hand-written
+    backward satisfy <A x, y> == <x, A^T y> (float64 dot products) -- bilinear sample / its transposed-matrix or per-cell
+    backward, mean rasterisation / its gather, mean pooling (its own adjoint)."""
+    from tomosar2height_amd import ops
+    from tomosar2height_amd.synthetic import berlin_tile
+    g = torch.Generator().manual_seed(c + r)
+    t = _tile(berlin_tile(3)["inputs"], 256)
+    n = t.n_points
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+
+    def check(fn, x, y_shape, what):
+        x = x.to(_dev()).requires_grad_(True)
+        out = fn(x)
+        y = torch.randn(y_shape, generator=g).to(_dev())
+        out.backward(y)
+        lhs, rhs = dot(out.detach(), y), dot(x.detach(), x.grad)
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-3, (what, lhs, rhs)
+
+    plane = torch.randn(1, c, r, r, generator=g).contiguous(memory_format=torch.channels_last)
+    check(lambda p: ops.sample_plane(t, p), plane, (n, c), "sample_plane")
+    feat = torch.randn(n, c, generator=g)
+    check(lambda f: ops.rasterise_mean(t, f, r, True), feat, (1, c, r, r), "rasterise_mean")
+    if r == 256:
+        check(lambda f: ops.pool_mean(t, f), feat, (n, c), "pool_mean")
