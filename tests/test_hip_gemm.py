@@ -150,3 +150,29 @@ def test_bf16x3_mode_is_fp32_grade(m, k, n):
             mlp.set_precision("fp32")
     for e32, e3 in zip(errs["fp32"], errs["bf16x3"]):
         assert e3 < 2e-5 and e3 <= 4 * e32 + 2e-7, (errs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(512, 1024), (1024, 512), (256, 512), (128, 256), (64, 128), (32, 32)])
+def test_full_size_linear_kernels_satisfy_the_bilinear_identities(k, n):
+    """BASELINE.json config 2 rows (M = 131072): with y = x W^T, <y, g> == <x, dgrad(g)> == <W, wgrad(g, x)> in float64 --
+    forward, data-gradient and weight-gradient kernels of one layer agree with each other at the full problem size (the
+    small-size tests pin each of them against torch)."""
+    from tomosar2height_amd import mlp
+    m = 131072
+    gen = torch.Generator().manual_seed(k + n)
+    x = torch.randn(m, k, generator=gen).cuda()
+    w = (torch.randn(n, k, generator=gen) / k ** 0.5).cuda()
+    g = torch.randn(m, n, generator=gen).cuda()
+    y = torch.empty(m, n, device="cuda")
+    mlp.linear_fwd_(x, w, None, y)
+    dx = mlp.linear_dgrad_(g, w, torch.empty_like(x))
+    dw = torch.empty_like(w)
+    mlp.linear_wgrad_(g, x, dw, None)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+
+    a, b, c = dot(y, g), dot(x, dx), dot(w, dw)
+    scale = max(abs(a), 1.0)
+    assert abs(a - b) <= 2e-5 * scale + 1e-2 and abs(a - c) <= 2e-5 * scale + 1e-2, (a, b, c)
