@@ -1,7 +1,7 @@
 // Ablation lab behind DESIGN.md section 4 ("standalone ablation of the 512 -> 1024 forward loop"): one file, one variant
 // per -D flag, no torch.  Not part of the product (profiles/ is evidence, csrc/ is what ships).
 //
-//   for v in BASE PIPE NO_GLOBAL NO_LDS_WRITE NO_BARRIER NO_LDS_READ ROWL FULLLINE FULLA SPLITW GLDS GLDS2 GLDS3 GLDS4; do
+//   for v in BASE PIPE NO_GLOBAL NO_LDS_WRITE NO_BARRIER NO_LDS_READ ROWL FULLLINE FULLA SPLITW GLDS GLDS2 GLDS3 GLDS4 GLDS5; do
 //     hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -D$v -DGLDS_MINW=4 -DVARIANT="\"$v\"" \
 //           profiles/gemm_lab.hip -o lab_$v && ./lab_$v; done
 //
@@ -16,6 +16,8 @@
 //   GLDS2     + all fragment reads of a slab before its first MFMA (= csrc/gemm_dma.hip)          122.8
 //   GLDS3     GLDS2 on a 256 x 128 tile with 8 waves (2 workgroups / CU)                          118-120
 //   GLDS4     GLDS2 with s_setprio(1) around the MFMA cluster                                     111.6
+//   GLDS5     three LDS stages + a second fragment register set: a wave reads slab kt+1's fragments
+//             under its own MFMAs of slab kt (155 VGPRs -> 3 waves / SIMD, 3 workgroups / CU)         114 (GLDS2 that day: 121)
 // (MI355X, M = 131072, K = 512, N = 1024, random data; combine -DNO_LDS_WRITE -DNO_BARRIER -DNO_GLOBAL [-DNO_LDS_READ]
 // for the "only LDS reads + MFMA" (133) and "only MFMA" (140) points.)
 #include <hip/hip_runtime.h>
@@ -490,6 +492,99 @@ __global__ __launch_bounds__(NT, 4) void k_nt7(Args p) {
     }
 }
 #define k_nt k_nt7
+#endif
+#ifdef GLDS5
+// GLDS2 restructured so that a wave overlaps its own LDS fragment reads with its own MFMAs: three LDS stages, the
+// fragments of slab kt+1 are read into a second register set right after the barrier and BEFORE the MFMAs of slab kt
+// are issued; ~150 VGPRs -> 3 waves / SIMD, 48 KB LDS -> 3 workgroups / CU.
+#ifndef GLDS5_MINW
+#define GLDS5_MINW 3
+#endif
+struct Frag { float4 a[2][TM], b[2][TN]; };
+__global__ __launch_bounds__(NT, GLDS5_MINW) void k_nt8(Args p) {
+    __shared__ __attribute__((aligned(1024))) float lds[3 * 2 * 128 * 16];
+    constexpr int STG = 2 * 128 * 16, OPB = 128 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n; xcd(tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.f;
+    const int nk = p.K / BK;
+    const float *ga[2], *gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int blk = wave * 2 + j, row = blk * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        ga[j] = p.A + (size_t)(m0 + row) * p.K + c * 4;
+        gb[j] = p.B + (size_t)(n0 + row) * p.K + c * 4;
+    }
+    auto issue = [&](int kt) {
+        float *st = lds + (kt % 3) * STG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int blk = wave * 2 + j;
+            __builtin_amdgcn_global_load_lds((glb_void *)(ga[j] + kt * BK), (lds_void *)(st + blk * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(gb[j] + kt * BK), (lds_void *)(st + OPB + blk * 256), 16, 0, 0);
+        }
+    };
+    const int half = lane >> 5, m = lane & 31, sw = (m >> 2) & 3;
+    const int off0 = ((half ^ sw) * 4), off1 = (((2 + half) ^ sw) * 4);
+    auto read = [&](int kt, Frag &f) {
+        const float *st = lds + (kt % 3) * STG;
+        const float *ar = st + (wm * 64 + m) * 16, *br = st + OPB + (wn * 64 + m) * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { f.a[0][i] = *reinterpret_cast<const float4 *>(ar + i * 32 * 16 + off0); f.a[1][i] = *reinterpret_cast<const float4 *>(ar + i * 32 * 16 + off1); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { f.b[0][j] = *reinterpret_cast<const float4 *>(br + j * 32 * 16 + off0); f.b[1][j] = *reinterpret_cast<const float4 *>(br + j * 32 * 16 + off1); }
+    };
+    auto mma = [&](const Frag &f) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float av = e == 0 ? f.a[g][i].x : e == 1 ? f.a[g][i].y : e == 2 ? f.a[g][i].z : f.a[g][i].w;
+                        float bv = e == 0 ? f.b[g][j].x : e == 1 ? f.b[g][j].y : e == 2 ? f.b[g][j].z : f.b[g][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+    };
+    Frag f0, f1;
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read(0, f0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // slab kt + 1 was issued either in the prologue (kt == 0) or by step(kt - 1)
+        {
+            const int k = kt;
+            if (k + 2 < nk) { issue(k + 2); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (k + 1 < nk) read(k + 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kt + 1 < nk) {
+            const int k = kt + 1;
+            if (k + 2 < nk) { issue(k + 2); asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (k + 1 < nk) read(k + 1, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int z = 0; z < 16; ++z) {
+        int row = m0 + wm * 64 + i * 32 + (z & 3) + 8 * (z >> 2) + 4 * (lane >> 5), col = n0 + wn * 64 + j * 32 + (lane & 31);
+        p.C[(size_t)row * p.N + col] = acc[i][j][z];
+    }
+}
+#define k_nt k_nt8
 #endif
 #ifdef GLDS3
 // LDS-DMA staging: global_load_lds_dwordx4 into a lane-linear [row][16] image, XOR-swizzled through the SOURCE address,
