@@ -894,8 +894,10 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
                     float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
                     float w = __fmul_rn(wx, wy);
                     float4 &a = acc[sy * 3 + sx];
-                    a.x = __fadd_rn(a.x, __fmul_rn(w, g.x)); a.y = __fadd_rn(a.y, __fmul_rn(w, g.y));
-                    a.z = __fadd_rn(a.z, __fmul_rn(w, g.z)); a.w = __fadd_rn(a.w, __fmul_rn(w, g.w));
+                    // fused multiply-add: this kernel is VALU-bound (nine slots per row), and its partial sums are
+                    // re-associated against the reference's order anyway (tolerance-checked, not bit-compared)
+                    a.x = __fmaf_rn(w, g.x, a.x); a.y = __fmaf_rn(w, g.y, a.y);
+                    a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
                 }
             }
         }
