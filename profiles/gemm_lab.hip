@@ -1,7 +1,7 @@
 // Ablation lab behind DESIGN.md section 4 ("standalone ablation of the 512 -> 1024 forward loop"): one file, one variant
 // per -D flag, no torch.  Not part of the product (profiles/ is evidence, csrc/ is what ships).
 //
-//   for v in BASE PIPE NO_GLOBAL NO_LDS_WRITE NO_BARRIER NO_LDS_READ ROWL FULLLINE FULLA SPLITW GLDS GLDS2 GLDS3 GLDS4 GLDS5; do
+//   for v in BASE PIPE NO_GLOBAL NO_LDS_WRITE NO_BARRIER NO_LDS_READ ROWL FULLLINE FULLA SPLITW GLDS GLDS2 GLDS3 GLDS4 GLDS5 GLDS6; do
 //     hipcc -w --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -D$v -DGLDS_MINW=4 -DVARIANT="\"$v\"" \
 //           profiles/gemm_lab.hip -o lab_$v && ./lab_$v; done
 //
@@ -18,6 +18,8 @@
 //   GLDS4     GLDS2 with s_setprio(1) around the MFMA cluster                                     111.6
 //   GLDS5     three LDS stages + a second fragment register set: a wave reads slab kt+1's fragments
 //             under its own MFMAs of slab kt (155 VGPRs -> 3 waves / SIMD, 3 workgroups / CU)         114 (GLDS2 that day: 121)
+//   GLDS6     GLDS2 persistent: 1024 resident workgroups walk the tiles, the next tile's first slab is
+//             requested before the current tile's stores (the four workgroups of a CU stay in lock-step)  110 (GLDS2: 122)
 // (MI355X, M = 131072, K = 512, N = 1024, random data; combine -DNO_LDS_WRITE -DNO_BARRIER -DNO_GLOBAL [-DNO_LDS_READ]
 // for the "only LDS reads + MFMA" (133) and "only MFMA" (140) points.)
 #include <hip/hip_runtime.h>
@@ -586,6 +588,87 @@ __global__ __launch_bounds__(NT, GLDS5_MINW) void k_nt8(Args p) {
 }
 #define k_nt k_nt8
 #endif
+#ifdef GLDS6
+// GLDS2 as a persistent kernel: 1024 resident workgroups walk the tiles (same XCD-aware order, stride = grid size) and
+// request the next tile's first slab BEFORE the epilogue of the current one, so the prologue latency of every tile but
+// the first runs under the previous tile's stores.
+__global__ __launch_bounds__(NT, 4) void k_nt9(Args p) {
+    __shared__ __attribute__((aligned(1024))) float lds[2 * 2 * 128 * 16];
+    constexpr int STG = 2 * 128 * 16, OPB = 128 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const unsigned tiles_n = p.N / BN, ntiles = tiles_n * (p.M / BM);
+    const unsigned nb = gridDim.x;
+    const int nk = p.K / BK;
+    const int half = lane >> 5, m = lane & 31, sw = (m >> 2) & 3;
+    auto tile_of = [&](unsigned t, int &m0, int &n0) {       // XCD-aware order over ALL tiles, as xcd() does per launch
+        const unsigned q = ntiles / 8, r = ntiles % 8, x = t % 8, i = t / 8;
+        const unsigned u = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+        n0 = (u % tiles_n) * BN; m0 = (u / tiles_n) * BM;
+    };
+    auto issue = [&](int m0, int n0, int kt, int stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int blk = wave * 2 + j, row = blk * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+            const float *ga = p.A + (size_t)(m0 + row) * p.K + kt * BK + c * 4;
+            const float *gb = p.B + (size_t)(n0 + row) * p.K + kt * BK + c * 4;
+            __builtin_amdgcn_global_load_lds((glb_void *)ga, (lds_void *)(lds + stage * STG + blk * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)gb, (lds_void *)(lds + stage * STG + OPB + blk * 256), 16, 0, 0);
+        }
+    };
+    unsigned t = blockIdx.x;
+    int m0, n0;
+    if (t >= ntiles) return;
+    tile_of(t, m0, n0);
+    issue(m0, n0, 0, 0);
+    for (;;) {
+        f32x16 acc[TM][TN];
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.f;
+        __syncthreads();                                     // slab 0 of this tile has landed (vmcnt(0) + barrier)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue(m0, n0, kt + 1, cur ^ 1);
+            const float *ar = lds + cur * STG + (wm * 64 + m) * 16;
+            const float *br = lds + cur * STG + OPB + (wn * 64 + m) * 16;
+            float4 a4[2][TM], b4[2][TN];
+            {
+                const int off = ((half ^ sw) * 4);
+                for (int i = 0; i < TM; ++i) a4[0][i] = *reinterpret_cast<const float4 *>(ar + i * 32 * 16 + off);
+                for (int j = 0; j < TN; ++j) b4[0][j] = *reinterpret_cast<const float4 *>(br + j * 32 * 16 + off);
+            }
+            {
+                const int off = (((2 + half) ^ sw) * 4);
+                for (int i = 0; i < TM; ++i) a4[1][i] = *reinterpret_cast<const float4 *>(ar + i * 32 * 16 + off);
+                for (int j = 0; j < TN; ++j) b4[1][j] = *reinterpret_cast<const float4 *>(br + j * 32 * 16 + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) {
+                        float av = e == 0 ? a4[g][i].x : e == 1 ? a4[g][i].y : e == 2 ? a4[g][i].z : a4[g][i].w;
+                        float bv = e == 0 ? b4[g][j].x : e == 1 ? b4[g][j].y : e == 2 ? b4[g][j].z : b4[g][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (kt + 1 < nk) __syncthreads();
+        }
+        // next tile: its first slab goes to stage 0 -- nk is even, so the last slab of this tile was read from stage 1 and
+        // stage 0 was last read one barrier ago
+        const int pm0 = m0, pn0 = n0;
+        t += nb;
+        const bool more = t < ntiles;
+        if (more) { tile_of(t, m0, n0); issue(m0, n0, 0, 0); }
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int z = 0; z < 16; ++z) {
+            int row = pm0 + wm * 64 + i * 32 + (z & 3) + 8 * (z >> 2) + 4 * (lane >> 5), col = pn0 + wn * 64 + j * 32 + (lane & 31);
+            p.C[(size_t)row * p.N + col] = acc[i][j][z];
+        }
+        if (!more) break;
+    }
+}
+#define k_nt k_nt9
+#define PERSISTENT_GRID 1024
+#endif
 #ifdef GLDS3
 // LDS-DMA staging: global_load_lds_dwordx4 into a lane-linear [row][16] image, XOR-swizzled through the SOURCE address,
 // fragments by ds_read_b128 with a k permutation (lane half h, group g reads k = 4*(2g+h) .. +3)
@@ -666,7 +749,11 @@ int main() {
 #define TILE_M BM
 #define WG_THREADS NT
 #endif
+#ifdef PERSISTENT_GRID
+    dim3 grid(PERSISTENT_GRID, 1);
+#else
     dim3 grid(N / BN, M / TILE_M);
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_nt, grid, dim3(WG_THREADS), 0, 0, a);
     hipDeviceSynchronize();
