@@ -2,7 +2,9 @@
 // ~400 vector / LDS instructions) takes 2.3 us when its workgroup has the CU to itself and 12-17 us beside three
 // main-loop workgroups (in-kernel stamps); neither dropping its stores nor s_setprio changed that.
 // This lab times a "victim" wave running a fixed instruction stream beside 0 / 1 / 3 "aggressor" waves per SIMD that
-// issue v_mfma_f32_32x32x2_f32 (or 16x16x4) back to back.
+// issue v_mfma_f32_32x32x2_f32 (or 16x16x4) back to back.  Result (MI355X): beside 0 or 1 such wave the victim is
+// unaffected; beside 3 it finishes when they do, whatever it executes -- VALU, LDS, global stores or plain scalar adds --
+// and whatever its s_setprio: the wave as a whole is not scheduled.
 //   hipcc --offload-arch=gfx950 -O3 -o scratch/mfma_corun_lab profiles/mfma_corun_lab.hip && scratch/mfma_corun_lab
 #include <hip/hip_runtime.h>
 #pragma clang diagnostic ignored "-Wunused-value"
@@ -14,7 +16,7 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-enum Victim { V_VALU = 0, V_LDS_READ = 1, V_LDS_WRITE = 2, V_MIXED = 3, V_VALU_DEP = 4 };
+enum Victim { V_VALU = 0, V_LDS_READ = 1, V_LDS_WRITE = 2, V_MIXED = 3, V_VALU_DEP = 4, V_VMEM_STORE = 5, V_SALU = 6 };
 
 // waves 0..3: victims (one per SIMD); waves 4..: aggressors.  out[block * 4 + wave] = victim cycles
 template <int AGG_SHAPE>
@@ -73,6 +75,15 @@ __global__ void corun(const float *in, float *sink, unsigned long long *cycles, 
         } else if (victim == V_LDS_WRITE) {        // 64 ds_write_b32
 #pragma unroll
             for (int r = 0; r < 64; ++r) *reinterpret_cast<volatile float *>(lds + ((lane + r * 68) & 8191)) = x[r & 7];
+        } else if (victim == V_VMEM_STORE) {       // 32 global_store_dword, addresses = one VGPR pair + immediate offsets
+            float *dst = sink + (size_t)blockIdx.x * blockDim.x + tid;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) asm volatile("global_store_dword %0, %1, off offset:%2" :: "v"(dst), "v"(x[r & 7]), "n"(r * 64) : "memory");
+        } else if (victim == V_SALU) {             // 64 scalar adds
+            int sa = it;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sa));
+            if (sa == -1) x[0] += 1.f;
         } else {                                   // epilogue-like: 16 ds_write_b32, then 4 x (ds_read_b128, wait, 12 VALU)
 #pragma unroll
             for (int r = 0; r < 16; ++r) *reinterpret_cast<volatile float *>(lds + wave * 1152 + ((lane & 31) + r * 36 + (lane >> 5) * 144) % 1152) = x[r & 7];
@@ -102,15 +113,16 @@ int main() {
     float *in, *sink;
     unsigned long long *cyc;
     hipMalloc(&in, 8192 * sizeof(float));
-    hipMalloc(&sink, blocks * 1024 * sizeof(float));
+    hipMalloc(&sink, (blocks * 1024 + 4096) * sizeof(float));
     hipMalloc(&cyc, blocks * 4 * sizeof(unsigned long long));
     std::vector<float> h(8192);
     for (auto &v : h) v = (float)rand() / RAND_MAX - 0.5f;
     hipMemcpy(in, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
-    const char *names[] = {"64 indep v_fma", "16 ds_read_b128+wait", "64 ds_write_b32", "epilogue-like tile", "64 dependent v_fma"};
-    const int instrs[] = {64, 16, 64, 16 + 4 * 13, 64};
+    const char *names[] = {"64 indep v_fma", "16 ds_read_b128+wait", "64 ds_write_b32", "epilogue-like tile", "64 dependent v_fma",
+                           "32 global_store_dword", "64 s_add_i32"};
+    const int instrs[] = {64, 16, 64, 16 + 4 * 13, 64, 32, 64};
     const int victim_iters = 64;
-    for (int victim : {0, 4, 1, 2, 3}) {
+    for (int victim : {0, 4, 1, 2, 3, 5, 6}) {
         for (int shape : {32, 16}) {
             for (int agg : {0, 1, 3}) {
                 if (agg == 0 && shape == 16) continue;
