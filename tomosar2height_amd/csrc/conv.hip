@@ -408,8 +408,11 @@ RowsPlan rows_plan(long long M, int N, int K) {
     const long long tiles = ((M + 127) / 128) * ((N + r.bn - 1) / r.bn);
     const int nk = K / BK;
     int splits = 1;
-    if (tiles < 512) {                               // fewer tiles than two per CU: split the reduction (~512 workgroups;
-        splits = (int)((512 + tiles - 1) / tiles);   // 256 / 768 / 1024 measured within 3 % of each other)
+    // fewer tiles than two per CU: split the reduction.  ~512 workgroups for planes from 256 x 256 up (768 / 1024 there:
+    // +10-30 % slower), ~768 for the smaller ones (128->128 at 128^2: 65 -> 60 us; 256 / 384: slower)
+    const long long tgt = M <= 16384 ? 768 : 512;
+    if (tiles < tgt) {
+        splits = (int)((tgt + tiles - 1) / tiles);
         const int max_splits = nk / 8 > 1 ? nk / 8 : 1;   // at least 8 slabs per split
         if (splits > max_splits) splits = max_splits;
         if (splits > 32) splits = 32;
