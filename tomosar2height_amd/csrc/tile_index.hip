@@ -77,16 +77,16 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
         if (idx < N) atomicAdd(&h[(keys[(size_t)b * N + idx] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    blockhist[((size_t)b * 256 + tid) * nblk + blk] = h[tid];
+    blockhist[((size_t)b * nblk + blk) * 256 + tid] = h[tid];        // [tile][workgroup][digit]: coalesced here and in the scan
 }
 
 // ---- radix pass 2/3: exclusive scan over (digit, workgroup), one workgroup per tile of the batch ------------
 __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ blockhist, int nblk) {
     __shared__ uint32_t tot[256];
     int b = blockIdx.x, tid = threadIdx.x;
-    uint32_t *p = blockhist + ((size_t)b * 256 + tid) * nblk;
+    uint32_t *p = blockhist + (size_t)b * nblk * 256 + tid;          // digit tid of workgroup j at p[j * 256]
     uint32_t s = 0;
-    for (int j = 0; j < nblk; ++j) { uint32_t v = p[j]; p[j] = s; s += v; }
+    for (int j = 0; j < nblk; ++j) { uint32_t v = p[(size_t)j * 256]; p[(size_t)j * 256] = s; s += v; }
     tot[tid] = s;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 256 digit totals
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ b
         __syncthreads();
     }
     uint32_t excl = tot[tid] - s;
-    for (int j = 0; j < nblk; ++j) p[j] += excl;
+    for (int j = 0; j < nblk; ++j) p[(size_t)j * 256] += excl;
 }
 
 // ---- radix pass 3/3: stable scatter --------------------------------------------------------------------
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
     }
     __syncthreads();
     {   // thread tid == digit: turn per-wave counts into global destinations
-        uint32_t g = blockhist[((size_t)b * 256 + tid) * nblk + blk];
+        uint32_t g = blockhist[((size_t)b * nblk + blk) * 256 + tid];
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) { uint32_t c = wc[w][tid]; wc[w][tid] = g; g += c; }
     }
