@@ -72,20 +72,22 @@ __global__ __launch_bounds__(kT) void bias_relu_bwd_kernel(const float *__restri
     }
 }
 
-// out[c] = [out[c] +] sum_b partial[b][c], b ascending in 16 interleaved lanes then lane order (fixed tree)
+// out[c] = [out[c] +] sum_b partial[b][c], b ascending in 64 interleaved lanes then lane order (fixed tree).  4 channels
+// per workgroup: with 16 (and 16 row lanes) the 289-channel head had 19 workgroups walking 64 rows each -- 25 us.
+constexpr int kRedCh = 4, kRedLanes = kT / kRedCh;
 __global__ __launch_bounds__(kT) void reduce_rows_kernel(const float *__restrict__ partial, int nblocks, int C,
                                                          int accumulate, float *__restrict__ out) {
     __shared__ float red[kT];
-    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-    int c = blockIdx.x * 16 + el;
+    const int el = threadIdx.x & (kRedCh - 1), q = threadIdx.x / kRedCh;
+    int c = blockIdx.x * kRedCh + el;
     float s = 0.f;
     if (c < C)
-        for (int b = q; b < nblocks; b += 16) s += partial[(size_t)b * C + c];
+        for (int b = q; b < nblocks; b += kRedLanes) s += partial[(size_t)b * C + c];
     red[threadIdx.x] = s;
     __syncthreads();
     if (q == 0 && c < C) {
         float t = red[el];
-        for (int k = 1; k < 16; ++k) t += red[k * 16 + el];
+        for (int k = 1; k < kRedLanes; ++k) t += red[k * kRedCh + el];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -374,7 +376,7 @@ T2H_API int t2h_bias_relu_bwd(const float *g, const float *y, float *g_masked, i
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3(nblocks), dim3(kT), 0, as_stream(stream), g, y, g_masked, (long long)P, C,
                        lg_for(C), relu, partial);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(kT), 0, as_stream(stream), partial, nblocks, C, accumulate,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + kRedCh - 1) / kRedCh), dim3(kT), 0, as_stream(stream), partial, nblocks, C, accumulate,
                        dbias);
     return check_launch("bias_relu_bwd");
 }
@@ -426,7 +428,7 @@ T2H_API int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *
     // columns [0, Ctot) -> dw, column Ctot -> dbias; row stride Ctot + 4
     // reduce_rows_kernel expects a dense [nblocks][C] matrix: treat the padded row as C = Ctot + 4 into a scratch tail
     float *tail = partial + (size_t)nblocks * (a.Ctot + 4);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((a.Ctot + 4 + 15) / 16), dim3(kT), 0, s, partial, nblocks, a.Ctot + 4, 0, tail);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((a.Ctot + 4 + kRedCh - 1) / kRedCh), dim3(kT), 0, s, partial, nblocks, a.Ctot + 4, 0, tail);
     rc = check_launch("head1x1_bwd");
     if (rc) return rc;
     if (hipMemcpyAsync(dw, tail, (size_t)a.Ctot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
