@@ -8,13 +8,16 @@
 
 A "step" is one tile through ``Trainer.train_step``: forward, L1 loss, backward, and -- every
 ``optimize_every``/world tiles per rank -- one RCCL all-reduce(SUM) of the flat gradient bucket + AdamW step
-(reference: trainer.py:47-89, optimize_every = 64).  Tiles are resident in HBM before the timed region.
+(reference: trainer.py:47-89, optimize_every = 64).  Tiles are resident in HBM before the timed region
+(``--from-producer``: the CHUNK is resident and every tile is cropped / normalised / augmented on the device in the loop).
 Weak scaling: every rank runs K tiles; value = world * K / max-over-ranks(time).
 
 Legs, in this order (rank 0 prints ONE compact JSON line at the very end, nothing after it):
   1. warm-up (W tiles), then the TIMED region: exactly K tile-steps, no per-launch instrumentation.  The accumulation
      phase is aligned so that the K-th tile ends an optimizer step: the region holds ceil(K / (optimize_every/world))
      all-reduce + AdamW steps -- never fewer per tile than the reference's one per 64 tiles.
+  1b. sustained leg (untimed for `value`): ``--sustain-s`` seconds of back-to-back tile-steps, one HIP event per step
+     -> ``sustained`` (ms/step over seconds, first vs last quartile of the per-step GPU times).
   2. profile leg (untimed): ``--profile-steps`` more tile-steps with two HIP events around every C-ABI launch, on the
      stream the kernels run on -> per-kernel table (written to ``--kernel-table``, not printed) and the ``roofline``
      objects: launches are aggregated per DEVICE KERNEL SYMBOL (t2h_last_kernel_name), the way
@@ -63,7 +66,7 @@ def parse():
     ap.add_argument("--cpu-max-threads", type=int, default=64, help="thread cap of the all-cores CPU leg")
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=5)
-    ap.add_argument("--cpu-budget-s", type=float, default=120.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0,
                     help="stop adding timed CPU repetitions once the whole CPU leg has taken this long (>= 1 timed step "
                          "per thread setting is always taken)")
     ap.add_argument("--mlp-precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
@@ -86,18 +89,28 @@ def parse():
                          "the same tiles accumulated by one rank alone; reports max_rel_diff, allreduce_ms, rccl_ranks.  "
                          "-1 (default): on whenever N > 1 (it runs after the timed region and costs < 1 s), 0 / 1: off / on")
     ap.add_argument("--fused-optimizer", type=int, default=1, help="1 = t2h flat-bucket AdamW kernel, 0 = torch.optim.AdamW")
+    ap.add_argument("--sustain-s", type=float, default=6.0,
+                    help="after the timed region: this many seconds of back-to-back tile-steps (one HIP event per step, nothing "
+                         "else) -> sustained_ms_per_step and first / last quartile step time; never part of `value`.  0 = off")
+    ap.add_argument("--from-producer", action="store_true",
+                    help="every tile of every leg is cropped / normalised / augmented / raster-patched on the device by "
+                         "producer.TileSource from a synthetic chunk resident in HBM (dataset.py:201-330) inside the loop, "
+                         "instead of cycling --tile-pool prepared tiles; N varies per tile around --points")
+    ap.add_argument("--chunk-tiles", type=int, default=3, help="--from-producer: the chunk is this many 512 m tiles per side")
     return ap.parse_args()
 
 
 def pmc_traffic():
     """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under
-    profiles/ by profiles/collect_pmc.py for the N = 131072 workload; {} if not collected."""
+    profiles/ by profiles/collect_pmc.py for the N = 131072 workload.  NOT measured in this run (PMC collection needs
+    rocprofv3 around the process): returns (bytes per launch by kernel, provenance string); ({}, None) if not collected."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("bytes_per_launch", {})
+            d = json.load(f)
+        return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json (rocprofv3 --pmc passes of profile {d.get('tag', '?')}, not this run)"
     except (OSError, ValueError):
-        return {}
+        return {}, None
 
 
 def cpu_baseline(args):
@@ -138,10 +151,10 @@ def cpu_baseline(args):
                      f"warm-up, oracle torch restatement, {main['median_s']} s/step, {main['cores']} threads "
                      f"(reference default) on a {host_cores}-core host"}
     if host_cores > main["cores"]:
-        # "all cores", bounded: one timed step, no further warm-up (the model is warm), and at most 64 threads -- with
-        # every hardware thread of a 256-thread host torch's CPU path needed 164 s per tile-step (r02a), 19x slower than
-        # with 8 threads; `cores` states what was used
-        allc = leg(min(host_cores, args.cpu_max_threads), 0, 1)
+        # "all cores", bounded: median of 3 timed steps after one warm-up at that thread count (the thread pool is
+        # re-created), at most 64 threads -- with every hardware thread of a 256-thread host torch's CPU path needed 164 s
+        # per tile-step (r02a), 19x slower than with 8 threads; `cores` states what was used.  --cpu-budget-s still bounds it
+        allc = leg(min(host_cores, args.cpu_max_threads), 1, 3)
         out["all_cores"] = {k: allc[k] for k in ("value", "cores", "median_s", "timed_steps")}
         out["all_cores"]["host_cores"] = host_cores
     out["leg_s"] = round(time.perf_counter() - t_leg, 1)
@@ -306,14 +319,41 @@ def check_dp(args, world, rank, dev, group, model, make_trainer):
     return out
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as a CHILD ``torch.distributed.run`` (never
+    exec: nothing here has touched the GPU yet, and nothing will in this process), pass the command line through, stream
+    the children's stderr, and re-print rank 0's JSON line as the last thing on stdout.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher in the environment: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)       # stderr: inherited (streams)
+    line = None
+    for out_line in child.stdout:
+        if out_line.startswith("{"):
+            line = out_line.rstrip("\n")            # the ranks print one JSON line (rank 0); keep the last one seen
+        else:
+            sys.stderr.write(out_line)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU path to benchmark)")
@@ -365,18 +405,44 @@ def main():
     opt, opt_name = make_optimizer()
     trainer = make_trainer(opt, args.optimize_every, group)
 
-    tiles = []
-    for i in range(args.tile_pool):
-        t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy, with_image=args.use_image)
-        tiles.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
+    tiles, source, anchors = [], None, None
+    if args.from_producer:
+        # the step right before the path: a chunk cloud (float64 world coordinates) + DSM raster (+ image)
+        # resident in HBM; every tile of every leg is cropped / normalised / augmented / patched on the device in the loop
+        import numpy as np
+        from tomosar2height_amd.producer import RasterPatcher, TileProducer, TileSource
+        from tomosar2height_amd.synthetic import berlin_chunk
+        ch = berlin_chunk(seed=100 + rank, tiles_per_side=args.chunk_tiles, n_points=args.points,
+                          clustered=not args.uniform_xy, with_image=args.use_image)
+        source = TileSource(TileProducer(ch["points"].to(dev), z_bound=ch["z_bound"]),
+                            RasterPatcher(ch["dsm"].to(dev), ch["left"], ch["top"]),
+                            RasterPatcher(ch["image"].to(dev), ch["left"], ch["top"]) if args.use_image else None,
+                            flip_augm=True, rotate_augm=True, rng=np.random.RandomState(7 + rank))
+        span = 512.0 * (args.chunk_tiles - 1)
+        anchors = np.floor(np.random.RandomState(11 + rank).uniform(0, span, (4096, 2))) + np.array([ch["left"], ch["bottom"]])
+    else:
+        for i in range(args.tile_pool):
+            t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy, with_image=args.use_image)
+            tiles.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
 
-    state = {"i": 0, "optimizer_steps": 0}
+    state = {"i": 0, "optimizer_steps": 0, "points": 0}
 
-    def run(n_steps):
+    def next_tile():
+        if source is None:
+            return tiles[state["i"] % len(tiles)]
+        t = source.get(anchors[state["i"] % len(anchors)])
+        state["points"] += t["inputs"].shape[1]
+        return t
+
+    def run(n_steps, events=None):
         for _ in range(n_steps):
-            if trainer.train_step(tiles[state["i"] % len(tiles)]):
+            if trainer.train_step(next_tile()):
                 state["optimizer_steps"] += 1
             state["i"] += 1
+            if events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                events.append(ev)
 
     def fence():
         torch.cuda.synchronize()
@@ -397,16 +463,40 @@ def main():
     le = trainer.local_every
     trainer.accumulated_steps = (le - args.steps % le) % le
     fence()
-    steps_before = state["optimizer_steps"]
+    steps_before, points_before = state["optimizer_steps"], state["points"]
     t0 = time.perf_counter()
     run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     timed_optimizer_steps = state["optimizer_steps"] - steps_before
+    timed_points = state["points"] - points_before
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- leg 1b: sustained run (never part of `value`): does the rate of the short timed region hold over seconds?
+    sustained = None
+    if args.sustain_s > 0 and not args.hip_graph:
+        n_sus = max(8, int(round(args.sustain_s / (elapsed / args.steps))))       # same count on every rank (elapsed is the max)
+        evs = [torch.cuda.Event(enable_timing=True)]
+        fence()
+        evs[0].record()
+        ts0 = time.perf_counter()
+        run(n_sus, evs)
+        fence()
+        sus_elapsed = time.perf_counter() - ts0
+        if world > 1:
+            tmax = torch.tensor([sus_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sus_elapsed = float(tmax.item())
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_sus)]           # GPU time between consecutive step ends
+        q = max(1, n_sus // 4)
+        sustained = {"steps": n_sus, "seconds": round(sus_elapsed, 2), "ms_per_step": round(1e3 * sus_elapsed / n_sus, 3),
+                     "tiles_per_s": round(world * n_sus / sus_elapsed, 3),
+                     "first_quartile_ms": round(sum(per[:q]) / q, 3), "last_quartile_ms": round(sum(per[-q:]) / q, 3),
+                     "median_ms": round(statistics.median(per), 3), "max_ms": round(max(per), 3),
+                     "optimizer_steps": n_sus // trainer.local_every}
 
     # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
     timeline = None
@@ -458,13 +548,17 @@ def main():
                        "library_fallbacks": getattr(grid, "fallback_count", lambda: None)(),
                        "hip_graph": bool(args.hip_graph)},
         }
+        if args.mlp_precision != "fp32":
+            from tomosar2height_amd import mlp
+            out["config"]["trunk_precision"] = mlp.trunk_precision()
         if timeline is not None:
             tags, syms = kernel_tables(timeline, args.profile_steps)
-            traffic = pmc_traffic() if args.points == 131072 else {}
+            traffic, traffic_src = pmc_traffic() if (args.points == 131072 and not args.from_producer) else ({}, None)
             named = {k["kernel"]: k for k in tags}
             if syms:
                 out["roofline"] = roof(syms[0], traffic.get(syms[0]["kernel"]))       # the kernel symbol with the largest time share
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
+                out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
                 out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps; "
                                           "class totals: sum(algorithmic flops or bytes) / sum(duration)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
@@ -473,6 +567,9 @@ def main():
                 out["roofline_top_symbols"] = [{"kernel": s["kernel"][:60], "ms_per_step": s["ms_per_step"], "frac": s["frac"],
                                                 "bound": s["bound"]} for s in syms[:6]]
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in tags), 3)
+                # > 1: the per-launch event pairs of the profile leg over-read the kernels (their sum exceeds the whole
+                # un-instrumented step), so `roofline.achieved` / `frac` are conservative by about this factor
+                out["event_inflation"] = round(out["t2h_kernels_ms_per_step"] / ms_per_step, 4)
                 out["t2h_launches_per_step"] = round(sum(k["launches_per_step"] for k in tags), 1)
             try:
                 os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
@@ -482,6 +579,14 @@ def main():
                 out["config"]["kernel_table"] = args.kernel_table
             except OSError as e:
                 out["config"]["kernel_table"] = f"not written: {e}"
+        if sustained is not None:
+            out["sustained"] = sustained
+            out["sustained_ms_per_step"] = sustained["ms_per_step"]
+        if args.from_producer:
+            out["config"]["tile_source"] = (f"producer.TileSource in the loop: crop + normalise + rot/flip augmentation + DSM patch "
+                                            f"per tile from a {args.chunk_tiles}x{args.chunk_tiles}-tile chunk resident in HBM; "
+                                            f"mean N = {timed_points / max(args.steps, 1):.0f} points/tile in the timed region")
+            out["config"]["workload"] += ", tiles from the device tile producer (dataset.py:201-330)"
         if dp is not None:
             out["check_dp"] = dp
         if world == 1 and not args.skip_cpu_baseline:

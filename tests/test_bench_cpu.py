@@ -48,3 +48,26 @@ def test_printed_line_stays_compact():
            "cpu_baseline": {"value": 0.05, "unit": "tiles/s", "cores": 8, "kind": "port", "sample": "y" * 200,
                             "all_cores": {"value": 0.05, "cores": 128, "median_s": 20.0, "timed_steps": 3}}}
     assert len(json.dumps(out)) < 4096
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver calls it: the ranks must be started as a child torch.distributed.run
+    (here, without a GPU, each rank then refuses to run -- which proves they were started, with the command line
+    passed through, and that their exit code is propagated)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1" in r.stderr
+    assert "--gpus 2 --steps 2 --warmup 1" in r.stderr
+    assert r.stderr.count("no GPU visible") == 2 and "must be launched with" not in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_mismatched_world_size_is_refused():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4 does not match --gpus 2" in r.stderr

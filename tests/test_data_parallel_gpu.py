@@ -73,3 +73,22 @@ def test_bench_two_ranks_check_dp_line_is_compact():
     assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]      # on by default for N > 1
     assert d["config"]["rccl_ranks"] == 0 and d["config"]["collective"] == "gloo"             # (RCCL needs one GPU per rank)
     assert "roofline" in d and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_two_without_a_launcher():
+    """`python bench.py --gpus 2 ...` exactly as the round driver starts it (no torchrun on the command line): bench.py
+    starts its own ranks as a child process and re-prints rank 0's line last."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4",
+           "--warmup", "1", "--points", "8192", "--optimize-every", "4", "--profile-steps", "2", "--sustain-s", "0",
+           "--kernel-table", os.path.join(ROOT, "gpurun_out", "bench_kernels_test.json")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"--- stdout\n{r.stdout[-4000:]}\n--- stderr\n{r.stderr[-6000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]) and len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]
+    assert d["config"]["optimizer_steps_in_timed_region"] == 2

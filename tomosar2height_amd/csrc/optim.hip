@@ -4,8 +4,10 @@
 // moments in two flat buffers of the same layout, and a device-resident table maps 4096-element chunks to tensors, so one
 // streaming pass reads p, g, m, v and writes p, m, v (28 B / parameter: 306 MB for Berlin cloud-only, HBM bound).
 //
-// Arithmetic = torch/optim/adamw.py (single-tensor form, amsgrad = maximize = False), one rounding per operation, no
-// contraction (the library is built with -ffp-contract=off):
+// Arithmetic follows torch/optim/adamw.py (single-tensor form, amsgrad = maximize = False), one rounding per operation, no
+// contraction (the library is built with -ffp-contract=off).  It matches torch TO ROUNDING, not bit for bit: ATen's device
+// `tensor / python_scalar` multiplies by the fp32 reciprocal of the scalar, the IEEE division sqrt(v) / sqrt(bc2) below can
+// differ from that by one ulp (tests/test_hip_optim.py: 2e-6 relative):
 //     p  = p * (1 - lr * wd)
 //     m  = m + (g - m) * (1 - beta1)                      (Tensor.lerp_, weight < 0.5 branch)
 //     v  = v * beta2 + (1 - beta2) * g * g                (mul_ then addcmul_)

@@ -283,10 +283,12 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     } else {
         pool_into_tile(a, Xs, Hsm, r0, r1, tid);
     }
+    // copy-outs: every wave copies ITS OWN 32 rows (the rows its GEMMs read and, in the LAST variant, later overwrite with
+    // relu(out)), so no other wave ever reads rows that their owner may already be rewriting
     if (!FIRST && a.pooled) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const int idx = tid + f * 256, row = idx >> 3, c = (idx & 7) * 4;
+            const int idx = lane + f * 64, row = wave * 32 + (idx >> 3), c = (idx & 7) * 4;
             if (r0 + row < r1)
                 *reinterpret_cast<float4 *>(a.pooled + (size_t)(r0 + row) * 32 + c) = *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
         }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
     if (a.x_full) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            const int idx = tid + f * 256, row = idx >> 4, c = (idx & 15) * 4;
+            const int idx = lane + f * 64, row = wave * 32 + (idx >> 4), c = (idx & 15) * 4;
             if (r0 + row < r1)
                 *reinterpret_cast<float4 *>(a.x_full + (size_t)(r0 + row) * 64 + c) = *reinterpret_cast<const float4 *>(Xs + row * XS + c);
         }

@@ -270,10 +270,8 @@ def conv3x3_chain(x: torch.Tensor, convs, relu_last: bool = True) -> torch.Tenso
     convs = list(convs)
     # conv i applies the ReLU mask of its input in its data gradient (mask_input) iff it runs on the implicit-GEMM kernels;
     # its producer (also a small-Cin first layer) then skips its own ReLU backward (grad_premasked)
-    cin, masks = x.shape[1], []
-    for c in convs:
-        probe = x if c.in_channels == x.shape[1] else x.new_empty((x.shape[0], c.in_channels, x.shape[2], x.shape[3]))
-        masks.append(conv3x3_supported(probe, c))
+    # (the predicate reads only x's rank / device / dtype / plane size, which a 3x3-s1-p1 chain preserves -- no probe tensor)
+    masks = [conv3x3_supported(x, c) for c in convs]
     own = [masks[i] or conv3x3_small_supported(x, c) for i, c in enumerate(convs)]
     for i, conv in enumerate(convs):
         last = i == len(convs) - 1

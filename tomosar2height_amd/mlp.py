@@ -24,7 +24,10 @@ def set_precision(name: str):
     """'fp32' (default; exact fp32 MFMA, BASELINE.json configs[1]) or 'bf16' (operands rounded to bf16 while staging,
     fp32 accumulate, fp32 tensors in HBM: configs[2] "bf16 MLP GEMMs on MFMA") or 'bf16x3' (opt-in: fp32-grade products
     from an exact 3-way bf16 split of both operands, six bf16 MFMAs per product).  Process-wide; applies to the forward
-    and backward GEMMs of every per-point layer (fc_pos, K = 3, always stays fp32)."""
+    and backward GEMMs of the ALTO per-point layers (alto.py:63-69) and of the block-by-block trunk.  The FUSED PointNet
+    trunk (csrc/trunk.hip, the default for the shipped widths; 1.3 % of the per-point flops) and fc_pos (K = 3) always
+    compute in exact fp32 -- more accurate than the mode asks for, never less; ``trunk_precision()`` reports what a
+    forward will use, and bench.py prints it."""
     global _MODE
     if name not in ("fp32", "bf16", "bf16x3"):
         raise ValueError("precision must be 'fp32', 'bf16' or 'bf16x3'")
@@ -33,6 +36,11 @@ def set_precision(name: str):
 
 def get_precision() -> str:
     return _MODE
+
+
+def trunk_precision() -> str:
+    """Arithmetic of the PointNet trunk GEMMs under the current mode: the fused block kernel has one (exact fp32) form."""
+    return "fp32 (fused trunk block kernel)" if (FUSED_TRUNK or _MODE == "fp32") else _MODE
 
 
 def _pflag() -> int:

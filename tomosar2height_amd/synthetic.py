@@ -43,3 +43,33 @@ def berlin_tile(seed: int, n_points: int = DEFAULT_POINTS, n_buildings: int = 16
     if with_image:
         tile["image"] = torch.from_numpy(rng.normal(0, 1, (1, 3, 512, 512)).astype(np.float32))
     return tile
+
+
+def berlin_chunk(seed: int, tiles_per_side: int = 3, n_points: int = DEFAULT_POINTS, clustered: bool = True,
+                 with_image: bool = False, left: float = 390000.0, bottom: float = 5810000.0, z0: float = 30.0):
+    """A synthetic CHUNK in the form ``TomoSARDataset`` holds one in RAM (reference dataset.py:95-140): the point cloud
+    in float64 world coordinates (metres, UTM-sized offsets -- the reason the reference normalises in float64,
+    dataset.py:232), a north-up DSM raster at 1 m / pixel and optionally a normalised image raster.  It is
+    ``tiles_per_side``^2 Berlin-shaped tiles side by side, so any 512 m window holds about ``n_points`` points.
+    Returns the pieces ``producer.TileProducer`` / ``RasterPatcher`` take."""
+    k = int(tiles_per_side)
+    rng = np.random.RandomState(seed)
+    pts, side = [], 512 * k
+    dsm = np.zeros((side, side), np.float32)                       # built south row first, flipped to north-up below
+    img = np.zeros((3, side, side), np.float64) if with_image else None
+    for j in range(k):
+        for i in range(k):
+            t = berlin_tile(seed * 1000 + j * k + i, n_points=n_points, clustered=clustered, with_image=with_image)
+            p = t["inputs"][0].numpy().astype(np.float64)
+            pts.append(np.stack([left + 512.0 * (i + p[:, 0]), bottom + 512.0 * (j + p[:, 1]),
+                                 z0 + Z_SPAN_BERLIN * p[:, 2]], 1))
+            dsm[512 * j:512 * (j + 1), 512 * i:512 * (i + 1)] = t["dsm"][0].numpy()
+            if with_image:
+                img[:, 512 * j:512 * (j + 1), 512 * i:512 * (i + 1)] = t["image"][0].numpy()
+    pts = np.concatenate(pts, 0)
+    pts = pts[rng.permutation(pts.shape[0])]
+    out = {"points": torch.from_numpy(pts), "dsm": torch.from_numpy(np.ascontiguousarray(dsm[::-1])),
+           "left": left, "bottom": bottom, "top": bottom + float(side), "z_bound": (-33.7, 156.5)}
+    if with_image:
+        out["image"] = torch.from_numpy(np.ascontiguousarray(img[:, ::-1]))
+    return out

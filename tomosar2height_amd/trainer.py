@@ -203,14 +203,22 @@ class Trainer:
             self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
         if self.on_reduced is not None:
             self.on_reduced(self.bucket.flat)
+        if self.check_domain and hasattr(self.model, "out_of_domain_total"):
+            # before the optimizer consumes anything: a caller that catches the error continues from the weights, moments
+            # and learning rate of the last good step, with empty accumulators
+            bad = self.model.out_of_domain_total()
+            if self.world > 1:
+                # every rank must take the same branch (the all-reduce above has already happened on all of them)
+                flag = torch.tensor([float(bad)], device=self.bucket.flat.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+                bad = int(flag.item())
+            if bad:
+                self._reset_accumulators()
+                raise ValueError(f"{bad} input point(s) of the last {self.optimize_every} tile(s) had x or y outside [0, 1) "
+                                 "(or NaN): normalise / crop the tiles as dataset.py:270-278 does")
         self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()                                         # train.py:188-190: once per iteration
-        if self.check_domain and hasattr(self.model, "out_of_domain_total"):
-            bad = self.model.out_of_domain_total()
-            if bad:
-                raise ValueError(f"{bad} input point(s) of the last {self.local_every} tile(s) had x or y outside [0, 1) "
-                                 "(or NaN): normalise / crop the tiles as dataset.py:270-278 does")
         with torch.no_grad():
             denom = self.optimize_every
             acc = self.accumulated_loss
@@ -223,6 +231,9 @@ class Trainer:
                 acc, acc_d = packed[0], {"loss_ce": packed[1], "loss_l1": packed[2]}
             self.last_avg_loss = acc / denom
             self.last_avg_loss_dict = {k: v / denom for k, v in acc_d.items()}
+        self._reset_accumulators()
+
+    def _reset_accumulators(self):
         self.accumulated_loss = 0.0
         self.accumulated_steps = 0
         self.accumulated_loss_dict = {k: 0.0 for k in self.accumulated_loss_dict}
