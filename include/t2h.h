@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 4
+#define T2H_ABI_VERSION 5
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -146,6 +146,12 @@ int t2h_segmean_bwd_add(const float *gplane_nhwc, const int32_t *cell, const int
  *                         gplane must be zeroed by the caller. */
 int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                    t2h_stream_t stream);
+/* max(sample, 0): the hidden activations relu(fc_comm.0(sampled)) of alto.py:121-123 / 245-248 when fc_comm.0 was applied
+ * to the plane's PIXELS first (nn.Linear commutes with the bilinear interpolation, whose tap weights sum to 1 under
+ * padding_mode='border', align_corners=True):  relu(W0 sample(P) + b0) == relu(sample(P W0^T + b0)).  `plane_nhwc` is then the
+ * [B, r, r, 2C] plane P W0^T + b0; where N >> r^2 this replaces an [N, C] x [C, 2C] product by an [r^2, C] x [C, 2C] one. */
+int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
+                        t2h_stream_t stream);
 size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C);
 int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                    int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,

@@ -467,7 +467,9 @@ __device__ inline Taps make_taps(float x01, float y01, int r) {
     return t;
 }
 
-template <int VEC>
+// RELU: out = max(sample, 0) -- the hidden layer of fc_comm when its first Linear was applied on the grid
+// (t2h_sample_fwd_relu)
+template <int VEC, bool RELU = false>
 __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__restrict__ plane,
                                                               const float *__restrict__ pts, int dim, int64_t npts,
                                                               int N, int r, int C, int lg, float *__restrict__ out) {
@@ -505,6 +507,10 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
             v = Vec<VEC>::load(p11 + c);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(acc.v[j], __fmul_rn(v.v[j], se));
+        }
+        if (RELU) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = fmaxf(acc.v[j], 0.0f);
         }
         acc.store(out + (size_t)n * C + c);
     }
@@ -997,11 +1003,14 @@ static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C, int min
     int64_t cells = (int64_t)1 << (2 * (nbits - level));
     if ((int64_t)N < (int64_t)min_pts_per_cell * cells) return p;
     p.use = true;
-    int64_t want = (4096 + B * cells - 1) / (B * cells);            // aim at >= 4096 workgroups
-    p.S = (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
     int cc = cell_chunk_channels(C);
     p.chunks = (C + cc - 1) / cc;
     p.lgG = group_log2(cc, 4);
+    // aim at >= 4096 workgroups; the channel chunks of a cell are workgroups of their own, so wide rows need fewer row
+    // splits -- and every split costs a 9-slot partial row per cell to write and re-read (C = 512, r = 32: 4 -> 2 splits)
+    const int64_t wgs = (int64_t)B * cells * p.chunks;
+    int64_t want = (4096 + wgs - 1) / wgs;
+    p.S = (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
     return p;
 }
 
@@ -1196,6 +1205,22 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
           hipLaunchKernelGGL(sample_fwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
                              plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });
     return check_launch("sample_fwd");
+}
+
+T2H_API int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
+                                t2h_stream_t stream) {
+    if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd_relu: null pointer");
+    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_fwd_relu: unsupported shape");
+    int64_t npts = (int64_t)B * N;
+    if (npts == 0) return T2H_OK;
+    T2H_DISPATCH_VEC(C,
+        { GroupCfg g = group_cfg<4>(C);
+          hipLaunchKernelGGL((sample_fwd_kernel<4, true>), dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); },
+        { GroupCfg g = group_cfg<1>(C);
+          hipLaunchKernelGGL((sample_fwd_kernel<1, true>), dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });
+    return check_launch("sample_fwd_relu");
 }
 
 T2H_API int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,

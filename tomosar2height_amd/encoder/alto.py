@@ -70,10 +70,16 @@ class _PointGridLevel(nn.Module):
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
         """-> (raster, c, plane): the returned ``plane`` is the input plane for its further consumers (its gradient is then
         summed inside the sample backward kernel, ops.sample_plane_thru)."""
-        sampled, plane = ops.sample_plane_thru(tile, plane)                       # alto.py:121-122 / 245-246
         fa, fb = self.fc_comm[0], self.fc_comm[2]
-        c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
-                         self.fc_c.weight, self.fc_c.bias)                       # alto.py:123-128 / 248-253
+        if mlp.grid_first_applicable(tile, plane.shape[2], plane.shape[1]):
+            # coarse levels (many points per pixel): fc_comm.0 on the pixels, its 2C-wide result interpolated straight into
+            # the hidden activations -- see mlp._CommMLPGridFirst
+            c, plane = mlp.comm_mlp_grid_first(tile, plane, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
+                                               self.fc_c.weight, self.fc_c.bias)
+        else:
+            sampled, plane = ops.sample_plane_thru(tile, plane)                   # alto.py:121-122 / 245-246
+            c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
+                             self.fc_c.weight, self.fc_c.bias)                   # alto.py:123-128 / 248-253
         # alto.py:130 / 255; `c` also feeds the next level's fc_c: its two gradients are summed in the rasterisation's backward
         raster, c = ops.rasterise_mean_thru(tile, c, plane.shape[2], self.channels_last)
         return raster, c, plane

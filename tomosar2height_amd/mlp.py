@@ -322,6 +322,94 @@ def comm_mlp(sampled, w_a, b_a, w_b, b_b, c_last, w_c, b_c) -> torch.Tensor:
                           w_a, b_a, w_b, b_b, w_c, b_c)
 
 
+# ------------------------------------------------------------------------------------------------ grid-first point update
+# relu(fc_comm.0(sample(P))) == relu(sample(fc_comm.0(P))): an nn.Linear commutes with the bilinear interpolation of
+# alto.py:90-95 because the interpolation is a linear map over pixels whose four tap weights sum to 1 (padding_mode='border',
+# align_corners=True) -- so the bias passes through as well.  Where a level has far fewer pixels than the tile has points
+# (Berlin, N = 131072: r = 32 -> 128 points per pixel, r = 64 -> 32, r = 128 -> 8) the first Linear of fc_comm therefore runs
+# on the [r^2, C] pixel rows instead of the [N, C] point rows, the sample kernel interpolates the 2C-wide result straight into
+# the hidden activations (ReLU in its store), and `sampled` [N, C] never exists.  In the backward the sample's adjoint brings
+# the masked hidden gradient back to the pixels, where fc_comm.0's weight / bias / data gradients are again [r^2]-row
+# products.  Same function, different association of the fp32 sums (1e-6 relative); per level it removes one of the three
+# per-point GEMM triples (forward, data gradient, weight gradient).  GRID_FIRST_MIN_RATIO = points per pixel from which the
+# path is taken (0 switches it off: A/B).
+GRID_FIRST_MIN_RATIO = float(os.environ.get("T2H_GRID_FIRST_MIN_RATIO", "4"))
+
+
+def grid_first_applicable(tile, r: int, c: int) -> bool:
+    return (GRID_FIRST_MIN_RATIO > 0 and c % 4 == 0 and tile.n_points >= GRID_FIRST_MIN_RATIO * tile.B * r * r
+            and tile.R % r == 0)
+
+
+def hidden_from_plane(tile, plane_rows, r, w_a, b_a):
+    """h = relu(sample(P W_a^T + b_a)) -> [N, 2C]; ``plane_rows`` = the [B r r, C] pixel rows of the NHWC plane."""
+    q = _empty(plane_rows.shape[0], w_a.shape[0], plane_rows)
+    linear_fwd_(plane_rows, w_a, b_a, q)                                       # fc_comm.0 on the pixels
+    h = _empty(tile.n_points, w_a.shape[0], plane_rows)
+    c2 = w_a.shape[0]
+    _lib.call("t2h_sample_fwd_relu", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
+              _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q.numel(),
+              tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
+    return h
+
+
+class _CommMLPGridFirst(torch.autograd.Function):
+    """``(c, plane)`` with c = fc_comm.2(relu(fc_comm.0(sample(plane)))) + fc_c(c_last) (alto.py:121-128, 245-253), fc_comm.0
+    applied on the grid (see above).  The second output is the plane itself for its other consumers (the next level's residual
+    convolution): their gradient ``gthru`` is added to this node's plane gradient here instead of by an autograd pass."""
+
+    @staticmethod
+    def forward(ctx, plane, c_last, wa, ba, wb, bb, wc, bc, tile):
+        from . import ops
+        ctx.was_cl = ops._is_channels_last(plane)
+        p = ops.to_nhwc(plane)
+        _lib.require_device(p, what="comm_mlp_grid_first")
+        b, r, _, c = p.shape
+        rows = p.reshape(b * r * r, c)
+        h = hidden_from_plane(tile, rows, r, wa, ba)
+        out = _empty(tile.n_points, wb.shape[0], rows)
+        linear_fwd_(h, wb, bb, out)
+        if c_last is not None:
+            linear_fwd_(c_last, wc, bc, out, accumulate=True)
+        ctx.has_last = c_last is not None
+        ctx.tile, ctx.r = tile, r
+        ctx.save_for_backward(rows, c_last, h, wa, ba, wb, bb, wc, bc)
+        return out, ops._alias(plane)
+
+    @staticmethod
+    def backward(ctx, g, gthru):
+        from . import ops
+        rows, c_last, h, wa, ba, wb, bb, wc, bc = ctx.saved_tensors
+        tile, r = ctx.tile, ctx.r
+        if g is None:
+            return gthru, None, None, None, None, None, None, None, None
+        g = g.contiguous()
+        dwb, dbb = _wgrad(g, h, wb, bb)
+        dh = linear_dgrad_(g, wb, torch.empty_like(h), mask=h)                  # through fc_comm.2 and the ReLU
+        dq = ops._sample_bwd(tile, dh, r, h.shape[1], None).reshape(rows.shape[0], h.shape[1])    # S^T dh: [B r r, 2C]
+        dwa, dba = _wgrad(dq, rows, wa, ba)                                     # column sums of dq == of dh (taps sum to 1)
+        dplane = None
+        if ctx.needs_input_grad[0]:
+            drows = linear_dgrad_(dq, wa, torch.empty_like(rows))
+            dplane = drows.reshape(tile.B, r, r, rows.shape[1])
+            if gthru is not None:
+                dplane = dplane + ops.to_nhwc(gthru)                            # [r^2, C]: small next to the per-point tensors
+            dplane = ops.from_nhwc(dplane, ctx.was_cl)
+        elif gthru is not None:
+            dplane = gthru
+        dlast = dwc = dbc = None
+        if ctx.has_last:
+            dwc, dbc = _wgrad(g, c_last, wc, bc)
+            if ctx.needs_input_grad[1]:
+                dlast = linear_dgrad_(g, wc, torch.empty_like(c_last))
+        return dplane, dlast, dwa, dba, dwb, dbb, dwc, dbc, None
+
+
+def comm_mlp_grid_first(tile, plane, w_a, b_a, w_b, b_b, c_last, w_c, b_c):
+    """-> (c [N, C], plane): use the returned plane for every further consumer of the input plane."""
+    return _CommMLPGridFirst.apply(plane, None if c_last is None else c_last.contiguous(), w_a, b_a, w_b, b_b, w_c, b_c, tile)
+
+
 # ------------------------------------------------------------------------------------------------ PointNet trunk
 FUSED_TRUNK = os.environ.get("T2H_FUSED_TRUNK", "1") != "0"      # A/B switch: 0 = one GEMM launch per Linear + pool kernels
 
