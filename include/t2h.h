@@ -126,6 +126,18 @@ int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nb
                     float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N,
                     int nbits, int level, int C, float *gfeat, t2h_stream_t stream);
+/* Per-cell SUMS instead of means (same kernels, no division), their 2x2 pooling to the next coarser resolution (a cell is
+ * the union of its four children: plane [B, r, r, C] -> [B, r/2, r/2, C]) and the joint backward of sums taken at up to four
+ * resolutions of the same rows: gfeat[n] = (mask[n] > 0 ?) sum_q gplane_q[cell_{level_q}(n)] (+ addend[n]).
+ * They serve the "deferred point features" form of the ALTO point update (alto.py:121-130, 245-255): the per-point features
+ * c_k = fc_comm.2(h_k) + fc_c(c_{k-1}) are linear in the hidden activations h_j (j <= k), and so is their scatter_mean, hence
+ *   scatter_mean(c_k) = ( sum_j cellsum_r(h_j) A_{k,j}^T ) / count + const_k        (A_{k,j} = Wc_k .. Wc_{j+1} W1_j)
+ * is formed on the r^2 pixels from per-cell sums of the hidden activations and c_k itself is never computed on the N points. */
+int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                   float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream);
+int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B, int N,
+                         int nbits, int C, const float *mask, const float *addend, float *gfeat, t2h_stream_t stream);
 /* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
  * rasterisation and the next level's fc_c (alto.py:123-130), so their gradient is a sum of two -- formed here instead of
  * by an extra elementwise pass (gfeat may alias addend). */

@@ -384,3 +384,45 @@ def test_grid_first_exchange_equals_point_first(c, r):
         l2 = ((got - want).norm() / (want.norm() + 1e-300)).item()
         lim = (1e-5, 1e-5) if k == "out" else (1e-2, 3e-3)
         assert mx <= lim[0] and l2 <= lim[1], f"{k}: max {mx:.2e}, L2 {l2:.2e}"
+
+
+# ------------------------------------------------------------------------------------------------ deferred point features
+def test_deferred_point_features_equal_the_point_wise_chain():
+    """The whole Berlin point encoder at the benchmarked size, deferred form (deferred.py: no per-point c from the first
+    256-channel level on) against the point-wise chain (T2H_DEFER_MIN_CHANNELS = 0) with the same weights and tile: the
+    output plane to 1e-5, every parameter gradient at the mask-flip resolution (1e-2 max-normalised / 3e-3 L2)."""
+    from tomosar2height_amd import deferred
+    from tomosar2height_amd.encoder.pointnet import LocalPoolPointnet
+    from tomosar2height_amd.synthetic import berlin_tile
+    dev = _dev()
+    enc = det_init_(LocalPoolPointnet(feature_dim=32, dim=3, hidden_dim=32, scatter_type="max", unet_type="alto",
+                                      unet_kwargs=dict(depth=5, merge_mode="concat", start_filts=32), plane_resolution=256),
+                    seed=51).to(dev)
+    enc.set_channels_last(True)
+    cloud = berlin_tile(seed=3)["inputs"].to(dev)
+    gout = _rand((1, 32, 256, 256), 7)
+    res = {}
+    old = deferred.DEFER_MIN_CHANNELS
+    try:
+        for mode, thr in (("deferred", 256), ("pointwise", 0)):
+            deferred.DEFER_MIN_CHANNELS = thr
+            enc.zero_grad(set_to_none=True)
+            out = enc(cloud)["xy"]
+            out.backward(gout)
+            res[mode] = (out.detach().clone(), {k: v.grad.clone() for k, v in enc.named_parameters() if v.grad is not None})
+    finally:
+        deferred.DEFER_MIN_CHANNELS = old
+    (o1, g1), (o0, g0) = res["deferred"], res["pointwise"]
+    assert g1.keys() == g0.keys()
+    err = ((o1 - o0).abs().max() / o0.abs().max()).item()
+    assert err <= 1e-5, f"plane: {err:.2e}"
+    worst = []
+    for k in g0:
+        a, b = g1[k].to(D), g0[k].to(D)
+        mx = ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
+        l2 = ((a - b).norm() / (b.norm() + 1e-300)).item()
+        worst.append((mx, l2, k))
+    worst.sort(reverse=True)
+    print(f"[deferred vs point-wise] plane {err:.2e}; worst gradients:", [(f"{m:.1e}", f"{l:.1e}", k) for m, l, k in worst[:4]])
+    for mx, l2, k in worst:
+        assert mx <= 1e-2 and l2 <= 3e-3, f"{k}: max {mx:.2e}, L2 {l2:.2e}"

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float *__restr
 
 // ------------------------------------------------------------------------------------------------- segmean
 // One group per level-k cell, cells enumerated in Morton order (neighbouring groups read neighbouring rows).
-template <int VEC>
+// MEAN = false: the plain per-cell SUM (t2h_segsum_fwd)
+template <int VEC, bool MEAN = true>
 __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__restrict__ feat,
                                                                const int32_t *__restrict__ off0, int B, int nbits,
                                                                int level, int C, int lg, float *__restrict__ plane) {
@@ -413,9 +414,76 @@ __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__re
         }
         Vec<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = __fdiv_rn(sum[j], inv_den);
+        for (int j = 0; j < VEC; ++j) o.v[j] = MEAN ? __fdiv_rn(sum[j], inv_den) : sum[j];
         o.store(orow + c);
     }
+}
+
+// Gradient of per-cell sums taken at several resolutions of the same rows (t2h_segsum_bwd_multi): one group per point,
+// gfeat[n] = (mask[n] > 0 ?) sum_l gplane_l[cell_l(n)] (+ addend[n]); planes in the order given (a fixed summation order).
+struct MultiPlanes { const float *g[4]; int level[4]; int n; };
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes mp, const int32_t *__restrict__ cell,
+                                                                    int64_t npts, int nbits, int C, int lg,
+                                                                    const float *__restrict__ mask,
+                                                                    const float *__restrict__ addend,
+                                                                    float *__restrict__ gfeat) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t n = t >> lg;
+    if (n >= npts) return;
+    const uint32_t code = (uint32_t)cell[n];
+    const uint32_t b = code >> (2 * nbits), m = code & ((1u << (2 * nbits)) - 1u);
+    const uint32_t x0 = compact1by1(m), y0 = compact1by1(m >> 1);             // finest-level cell coordinates
+    const float *rows[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        rows[q] = nullptr;
+        if (q < mp.n) {
+            const int l = mp.level[q], r = 1 << (nbits - l);
+            rows[q] = mp.g[q] + (((size_t)b * r + (y0 >> l)) * r + (x0 >> l)) * C;
+        }
+    }
+    const int span = VEC << lg;
+    for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
+        Vec<VEC> acc = Vec<VEC>::load(rows[0] + c);
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (q < mp.n) {
+                Vec<VEC> g = Vec<VEC>::load(rows[q] + c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(acc.v[j], g.v[j]);
+            }
+        if (mask) {
+            Vec<VEC> h = Vec<VEC>::load(mask + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = h.v[j] > 0.0f ? acc.v[j] : 0.0f;
+        }
+        if (addend) {
+            Vec<VEC> o = Vec<VEC>::load(addend + (size_t)n * C + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.v[j] = __fadd_rn(o.v[j], acc.v[j]);
+        }
+        acc.store(gfeat + (size_t)n * C + c);
+    }
+}
+
+// coarse[b, y, x, :] = fine[b, 2y, 2x, :] + fine[b, 2y, 2x+1, :] + fine[b, 2y+1, 2x, :] + fine[b, 2y+1, 2x+1, :]  (NHWC, float4 lanes):
+// the per-cell sums of resolution r / 2 from those of resolution r (a cell is the union of its four children)
+__global__ __launch_bounds__(kThreads) void plane_sumpool2x2_kernel(const float *__restrict__ fine, int64_t total4, int rc,
+                                                                   int C4, float *__restrict__ coarse) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (t >= total4) return;
+    const int c4 = (int)(t % C4);
+    const int64_t pix = t / C4;
+    const int x = (int)(pix % rc), y = (int)((pix / rc) % rc);
+    const int64_t b = pix / ((int64_t)rc * rc);
+    const int rf = 2 * rc;
+    const float4 *f = reinterpret_cast<const float4 *>(fine) + ((b * rf + 2 * y) * rf + 2 * x) * (int64_t)C4 + c4;
+    const float4 a = f[0], bq = f[C4], cq = f[(int64_t)rf * C4], d = f[(int64_t)rf * C4 + C4];
+    float4 o;
+    o.x = (a.x + bq.x) + (cq.x + d.x); o.y = (a.y + bq.y) + (cq.y + d.y);
+    o.z = (a.z + bq.z) + (cq.z + d.z); o.w = (a.w + bq.w) + (cq.w + d.w);
+    reinterpret_cast<float4 *>(coarse)[t] = o;
 }
 
 // One group per point: gfeat[n] = gplane[cell_k(n)] / count.
@@ -838,7 +906,7 @@ __global__ __launch_bounds__(kCellThreads) void segmean_cells_kernel(const float
 __global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float *__restrict__ partial,
                                                                    const int32_t *__restrict__ off0, int B, int nbits,
                                                                    int level, int C, int lg, int S,
-                                                                   float *__restrict__ plane) {
+                                                                   float *__restrict__ plane, int mean = 1) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t gid = t >> lg;
     const int rbits = nbits - level;
@@ -857,8 +925,10 @@ __global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float 
             float4 u = *reinterpret_cast<const float4 *>(partial + ((size_t)gid * S + sp) * C + c);
             acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
         }
-        acc.x = __fdiv_rn(acc.x, den); acc.y = __fdiv_rn(acc.y, den);
-        acc.z = __fdiv_rn(acc.z, den); acc.w = __fdiv_rn(acc.w, den);
+        if (mean) {
+            acc.x = __fdiv_rn(acc.x, den); acc.y = __fdiv_rn(acc.y, den);
+            acc.z = __fdiv_rn(acc.z, den); acc.w = __fdiv_rn(acc.w, den);
+        }
         *reinterpret_cast<float4 *>(orow + c) = acc;
     }
 }
@@ -1136,8 +1206,8 @@ T2H_API int t2h_pool_rows_bwd(const float *gpooled, int ldg, const uint8_t *winn
     return check_launch("pool_rows_bwd");
 }
 
-T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
-                            float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+static int segreduce_fwd(bool mean, const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                         float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!feat || !off0 || !plane_nhwc) return fail(T2H_ERR_ARG, "segmean_fwd: null pointer");
     int rc = check_level("segmean_fwd", B, nbits, level, C);
     if (rc) return rc;
@@ -1154,17 +1224,75 @@ T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N
                            partial);
         GroupCfg g = group_cfg<4>(C);
         hipLaunchKernelGGL(segmean_finalize_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                           partial, off0, B, nbits, level, C, g.lg, cp.S, plane_nhwc);
+                           partial, off0, B, nbits, level, C, g.lg, cp.S, plane_nhwc, mean ? 1 : 0);
         return check_launch("segmean_fwd(coarse)");
     }
+    if (mean) {
+        T2H_DISPATCH_VEC(C,
+            { GroupCfg g = group_cfg<4>(C);
+              hipLaunchKernelGGL(segmean_fwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+            { GroupCfg g = group_cfg<1>(C);
+              hipLaunchKernelGGL(segmean_fwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
+    } else {
+        T2H_DISPATCH_VEC(C,
+            { GroupCfg g = group_cfg<4>(C);
+              hipLaunchKernelGGL((segmean_fwd_kernel<4, false>), dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+            { GroupCfg g = group_cfg<1>(C);
+              hipLaunchKernelGGL((segmean_fwd_kernel<1, false>), dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
+    }
+    return check_launch("segmean_fwd");
+}
+
+T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                            float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    return segreduce_fwd(true, feat, off0, B, N, nbits, level, C, plane_nhwc, workspace, workspace_bytes, stream);
+}
+
+T2H_API int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
+                           float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    return segreduce_fwd(false, feat, off0, B, N, nbits, level, C, plane_nhwc, workspace, workspace_bytes, stream);
+}
+
+T2H_API int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream) {
+    if (!fine_nhwc || !coarse_nhwc) return fail(T2H_ERR_ARG, "plane_sumpool2x2: null pointer");
+    if (B < 1 || r_fine < 2 || (r_fine & 1) || C < 4 || C % 4 != 0 || ((uintptr_t)fine_nhwc & 15) || ((uintptr_t)coarse_nhwc & 15))
+        return fail(T2H_ERR_ARG, "plane_sumpool2x2: needs an even resolution, C %% 4 == 0 and 16-byte aligned planes");
+    const int rc = r_fine / 2;
+    const int64_t total4 = (int64_t)B * rc * rc * (C / 4);
+    hipLaunchKernelGGL(plane_sumpool2x2_kernel, dim3((unsigned)((total4 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       as_stream(stream), fine_nhwc, total4, rc, C / 4, coarse_nhwc);
+    return check_launch("plane_sumpool2x2");
+}
+
+T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B,
+                                 int N, int nbits, int C, const float *mask, const float *addend, float *gfeat,
+                                 t2h_stream_t stream) {
+    if (!gplanes_nhwc || !levels || !cell || !gfeat) return fail(T2H_ERR_ARG, "segsum_bwd_multi: null pointer");
+    if (n_planes < 1 || n_planes > 4) return fail(T2H_ERR_ARG, "segsum_bwd_multi: 1..4 planes, got %d", n_planes);
+    if (B < 1 || N < 0 || nbits < 1 || nbits > T2H_MAX_NBITS || C < 1) return fail(T2H_ERR_ARG, "segsum_bwd_multi: unsupported shape");
+    MultiPlanes mp{};
+    mp.n = n_planes;
+    for (int q = 0; q < n_planes; ++q) {
+        if (!gplanes_nhwc[q] || levels[q] < 0 || levels[q] > nbits) return fail(T2H_ERR_ARG, "segsum_bwd_multi: bad plane %d", q);
+        if (C % 4 == 0 && ((uintptr_t)gplanes_nhwc[q] & 15)) return fail(T2H_ERR_ARG, "segsum_bwd_multi: planes must be 16-byte aligned");
+        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q];
+    }
+    if (C % 4 == 0 && ((mask && ((uintptr_t)mask & 15)) || (addend && ((uintptr_t)addend & 15)) || ((uintptr_t)gfeat & 15)))
+        return fail(T2H_ERR_ARG, "segsum_bwd_multi: rows must be 16-byte aligned");
+    const int64_t npts = (int64_t)B * N;
+    if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
-          hipLaunchKernelGGL(segmean_fwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+          hipLaunchKernelGGL(segsum_bwd_multi_kernel<4>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             mp, cell, npts, nbits, C, g.lg, mask, addend, gfeat); },
         { GroupCfg g = group_cfg<1>(C);
-          hipLaunchKernelGGL(segmean_fwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
-    return check_launch("segmean_fwd");
+          hipLaunchKernelGGL(segsum_bwd_multi_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                             mp, cell, npts, nbits, C, g.lg, mask, addend, gfeat); });
+    return check_launch("segsum_bwd_multi");
 }
 
 T2H_API int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N, int nbits,

@@ -1,0 +1,235 @@
+"""Deferred point features: the ALTO point update (reference alto.py:121-130, 245-255) without per-point features.
+
+The reference keeps a per-point feature vector c_k through the U-Net levels,
+
+    h_k = relu(fc_comm.0(sample(plane_k)))            [N, 2 C_k]      (alto.py:121-123)
+    c_k = fc_comm.2(h_k) + fc_c(c_{k-1})              [N, C_k]        (alto.py:123-128)
+    raster_k = scatter_mean(c_k)                      [r_k^2, C_k]    (alto.py:130)
+
+and nothing but Linear layers ever touches c: it is consumed by the next level's fc_c and by scatter_mean, both linear.  So
+
+    c_k      = sum_{j <= k} h_j A_{k,j}^T + c_base A_{k,base}^T + const_k,      A_{k,j} = Wc_k ... Wc_{j+1} W1_j
+    raster_k = ( sum_j cellsum_{r_k}(h_j) A_{k,j}^T + cellsum_{r_k}(c_base) A_{k,base}^T ) / count + [count > 0] const_k
+
+where cellsum_r is the per-cell SUM at resolution r.  The products run on the r_k^2 pixels instead of the N points, the
+composed matrices A (at most 1024 x 512) are themselves tiny products, and c_k is never formed.  What stays per point is
+what is non-linear: the hidden activations h_j (written once by ``t2h_sample_fwd_relu``, read once by ``t2h_segsum_fwd``;
+their sums at the coarser resolutions come from 2x2 pooling of the finest one) and, in the backward, their masked gradient
+(one ``t2h_segsum_bwd_multi`` gather from the <= 4 resolutions, read once by the sample adjoint).
+
+Same function as the reference's chain, re-associated (fp32: 1e-6 relative; pinned by the full-size oracle comparison and
+the float64 / same-mask checks of tests/test_hip_masks.py).  ``base`` is the last per-point feature tensor of the levels
+that run point-wise (narrow levels, where the per-point products are cheap): deferral starts at the first level with at
+least ``DEFER_MIN_CHANNELS`` channels on which the grid-first exchange applies (T2H_DEFER_MIN_CHANNELS, 0 = off).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib, mlp, ops
+
+DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
+
+
+# ------------------------------------------------------------------------------------------------ per-cell sums
+def _segsum(tile, rows, level):
+    """[N, C] rows -> [B r r, C] per-cell sums at ALTO level ``level`` (r = R >> level)."""
+    n, c = rows.shape
+    r = tile.R >> level
+    plane = torch.empty(tile.B * r * r, c, dtype=torch.float32, device=rows.device)
+    ws_bytes = _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+    ws = _lib.workspace(ws_bytes, rows.device)
+    _lib.call("t2h_segsum_fwd", _lib.ptr(rows), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c, _lib.ptr(plane),
+              _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(),
+              tag=f"t2h_segsum_fwd[C={c},r={r}]")
+    return plane
+
+
+def _sumpool(tile, fine, level_fine):
+    """per-cell sums at level ``level_fine`` -> level_fine + 1 (half the resolution)."""
+    c = fine.shape[1]
+    r = tile.R >> level_fine
+    coarse = torch.empty(tile.B * (r // 2) * (r // 2), c, dtype=torch.float32, device=fine.device)
+    _lib.call("t2h_plane_sumpool2x2", _lib.ptr(fine), tile.B, r, c, _lib.ptr(coarse), _lib.stream(),
+              nbytes=4 * (fine.numel() + coarse.numel()), tag=f"t2h_plane_sumpool2x2[C={c}]")
+    return coarse
+
+
+def cell_sums(tile, rows, levels):
+    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows, the
+    others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
+    out = {}
+    cur, cur_level = _segsum(tile, rows, levels[0]), levels[0]
+    out[cur_level] = cur
+    for lv in levels[1:]:
+        while cur_level < lv:
+            cur, cur_level = _sumpool(tile, cur, cur_level), cur_level + 1
+        out[lv] = cur
+    return [out[lv] for lv in levels]
+
+
+def _gather(tile, grads, levels, c, mask=None):
+    """d rows [N, C] = (mask > 0 ?) sum over the given levels of gplane_l[cell_l(n)]  (adjoint of ``cell_sums``)."""
+    planes = [(g.contiguous(), lv) for g, lv in zip(grads, levels) if g is not None]
+    out = torch.empty(tile.n_points, c, dtype=torch.float32, device=tile.device)
+    if not planes:
+        return out.zero_()
+    arr = (ctypes.c_void_p * len(planes))(*[p.data_ptr() for p, _ in planes])
+    lvs = (ctypes.c_int * len(planes))(*[lv for _, lv in planes])
+    _lib.call("t2h_segsum_bwd_multi", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lvs, ctypes.c_void_p), len(planes),
+              _lib.ptr(tile.cell), tile.B, tile.N, tile.nbits, c, None if mask is None else _lib.ptr(mask), None,
+              _lib.ptr(out), _lib.stream(),
+              nbytes=4 * c * tile.n_points * (2 if mask is not None else 1) + 4 * tile.n_points + sum(4 * p.numel() for p, _ in planes),
+              tag=f"t2h_segsum_bwd_multi[C={c},n={len(planes)}]")
+    return out
+
+
+class _HiddenSums(torch.autograd.Function):
+    """Q = fc_comm.0 applied to the plane's pixels ([B r r, 2C] rows) -> per-cell sums of h = relu(sample(Q)) at ``levels``.
+    h [N, 2C] lives only inside this node (saved for the mask); backward: gather + mask in one pass, then the sample adjoint."""
+
+    @staticmethod
+    def forward(ctx, q_rows, tile, r, levels):
+        q_rows = q_rows.contiguous()
+        c2 = q_rows.shape[1]
+        h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
+        _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
+                  _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
+                  tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
+        ctx.tile, ctx.r, ctx.levels, ctx.c2 = tile, r, tuple(levels), c2
+        ctx.save_for_backward(h)
+        return tuple(cell_sums(tile, h, list(levels)))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (h,) = ctx.saved_tensors
+        tile, r, c2 = ctx.tile, ctx.r, ctx.c2
+        dh = _gather(tile, grads, ctx.levels, c2, mask=h)
+        dq = ops._sample_bwd(tile, dh, r, c2, None).reshape(tile.B * r * r, c2)
+        return dq, None, None, None
+
+
+class _PointSums(torch.autograd.Function):
+    """Per-cell sums of a per-point feature tensor [N, C] at ``levels`` (the last point-wise level's c, or the trunk's)."""
+
+    @staticmethod
+    def forward(ctx, rows, tile, levels):
+        rows = rows.contiguous()
+        ctx.tile, ctx.levels, ctx.c = tile, tuple(levels), rows.shape[1]
+        return tuple(cell_sums(tile, rows, list(levels)))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return _gather(ctx.tile, grads, ctx.levels, ctx.c), None, None
+
+
+# ------------------------------------------------------------------------------------------------ small dense pieces
+class _MatmulNN(torch.autograd.Function):
+    """x [m, k] @ a [k, n] on the fp32 MFMA kernels (composition of the Linear weights: Wc_k @ A_{k-1,j})."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        x, a = x.contiguous(), a.contiguous()
+        out = torch.empty(x.shape[0], a.shape[1], dtype=torch.float32, device=x.device)
+        mlp.linear_dgrad_(x, a, out)                      # "dx = dy w" is exactly x @ a
+        ctx.save_for_backward(x, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a = ctx.saved_tensors
+        g = g.contiguous()
+        dx = da = None
+        if ctx.needs_input_grad[0]:
+            dx = mlp.linear_fwd_(g, a, None, torch.empty_like(x))             # g @ a^T
+        if ctx.needs_input_grad[1]:
+            da = torch.empty_like(a)
+            mlp.linear_wgrad_(x, g, da, None)                                  # x^T g
+        return dx, da
+
+
+def matmul_nn(x, a):
+    return _MatmulNN.apply(x, a)
+
+
+class _SumLinear(torch.autograd.Function):
+    """sum_j x_j @ w_j^T for row blocks x_j [m, K_j] and weights w_j [n, K_j], accumulated by the GEMM epilogues (no concat of
+    the x_j, no elementwise adds).  args = (x_0, w_0, x_1, w_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, *xw):
+        xs, ws = [t.contiguous() for t in xw[0::2]], [t.contiguous() for t in xw[1::2]]
+        out = torch.empty(xs[0].shape[0], ws[0].shape[0], dtype=torch.float32, device=xs[0].device)
+        for j, (x, w) in enumerate(zip(xs, ws)):
+            mlp.linear_fwd_(x, w, None, out, accumulate=j > 0)
+        ctx.save_for_backward(*xs, *ws)
+        ctx.n = len(xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        xs, ws = saved[:ctx.n], saved[ctx.n:]
+        g = g.contiguous()
+        grads = []
+        for j, (x, w) in enumerate(zip(xs, ws)):
+            dx = mlp.linear_dgrad_(g, w, torch.empty_like(x)) if ctx.needs_input_grad[2 * j] else None
+            dw = None
+            if ctx.needs_input_grad[2 * j + 1]:
+                dw = torch.empty_like(w)
+                mlp.linear_wgrad_(g, x, dw, None)
+            grads += [dx, dw]
+        return tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ state
+def counts(tile, level):
+    """(1 / max(count, 1), [count > 0]) as [B r r, 1] float columns for ALTO level ``level`` (cached on the tile)."""
+    cache = tile.__dict__.setdefault("_cell_counts", {})
+    if not cache:
+        ones = torch.ones(tile.n_points, 4, dtype=torch.float32, device=tile.device)
+        levels = list(range(0, tile.nbits))
+        for lv, s in zip(levels, cell_sums(tile, ones, levels)):
+            cnt = s[:, :1].contiguous()                   # sums of ones: exact integers in fp32
+            cache[lv] = (1.0 / cnt.clamp_min(1.0), (cnt > 0).to(torch.float32))
+    return cache[level]
+
+
+class Deferred:
+    """c_k = sum_j src_j A_j^T + const, never materialised.  ``sources``: dicts with ``sums`` {level: [B r r, K_j] rows} and
+    ``wt`` = A_j as an nn.Linear-layout matrix [C_k, K_j] (None = identity: the base tensor before the first fc_c)."""
+
+    def __init__(self, tile, later_levels, base_rows):
+        self.tile = tile
+        self.sources = []
+        self.const = None                                 # [1, C_k] row or None (zero)
+        sums = _PointSums.apply(base_rows, tile, tuple(sorted(set(later_levels))))
+        self.sources.append({"sums": dict(zip(sorted(set(later_levels)), sums)), "wt": None})
+
+    def advance(self, q_rows, r, later_levels, fc_b, fc_c):
+        """One level: compose the maps with this level's fc_c, add the level's hidden activations as a source (their fc_comm.2
+        is the new source's map), return the level's raster rows [B r r, C_k].  ``later_levels`` = ALTO levels of this and
+        every later exchange (what the new source will be rasterised at)."""
+        tile = self.tile
+        wc, bc, w1, b1 = fc_c.weight, fc_c.bias, fc_b.weight, fc_b.bias
+        for s in self.sources:
+            s["wt"] = wc if s["wt"] is None else matmul_nn(wc, s["wt"])       # A_{k,j} = Wc_k A_{k-1,j}
+        if self.const is None:
+            self.const = (bc + b1).reshape(1, -1)
+        else:
+            self.const = mlp.linear(self.const, wc, bc) + b1.reshape(1, -1)   # const_k = const_{k-1} Wc_k^T + bc_k + b1_k
+        levels = tuple(sorted(set(later_levels)))
+        sums = _HiddenSums.apply(q_rows, tile, r, levels)
+        self.sources.append({"sums": dict(zip(levels, sums)), "wt": w1})
+        lv = tile.level(r)
+        args = []
+        for s in self.sources:
+            args += [s["sums"][lv], s["wt"]]
+        acc = _SumLinear.apply(*args)
+        inv_cnt, nonempty = counts(tile, lv)
+        return acc * inv_cnt + nonempty * self.const      # scatter_mean: mean over the cell, 0 for an empty cell
+
+
+def applicable(tile, r: int, c: int) -> bool:
+    return DEFER_MIN_CHANNELS > 0 and c >= DEFER_MIN_CHANNELS and mlp.grid_first_applicable(tile, r, c)

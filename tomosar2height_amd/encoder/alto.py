@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
-from .. import grid, mlp, ops
+from .. import deferred, grid, mlp, ops
 from ..tile import TileIndex
 
 
@@ -67,11 +67,22 @@ class _PointGridLevel(nn.Module):
             return grid.upsample_conv1x1(x, conv, addend)
         return grid.conv1x1(x, conv, addend)
 
-    def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last):
+    def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last, later_res=None):
         """-> (raster, c, plane): the returned ``plane`` is the input plane for its further consumers (its gradient is then
-        summed inside the sample backward kernel, ops.sample_plane_thru)."""
+        summed inside the sample backward kernel, ops.sample_plane_thru).  ``later_res``: plane resolutions of this and every
+        later point<->grid exchange of the U-Net; with it the wide levels run in the deferred form (deferred.py): ``c`` is then
+        a ``deferred.Deferred`` -- the per-point features as a linear map of the hidden activations, never materialised."""
         fa, fb = self.fc_comm[0], self.fc_comm[2]
-        if mlp.grid_first_applicable(tile, plane.shape[2], plane.shape[1]):
+        r, ch = plane.shape[2], plane.shape[1]
+        if isinstance(c_last, deferred.Deferred) or (later_res is not None and torch.is_tensor(c_last)
+                                                     and deferred.applicable(tile, r, ch)):
+            levels = [tile.level(x) for x in later_res]
+            state = c_last if isinstance(c_last, deferred.Deferred) else deferred.Deferred(tile, levels, c_last)
+            rows = plane.permute(0, 2, 3, 1).reshape(-1, ch)                      # the pixels as rows (a view if channels_last)
+            q = mlp.linear(rows, fa.weight, fa.bias)                              # fc_comm.0 on the pixels (alto.py:123)
+            raster = state.advance(q, r, levels, fb, self.fc_c).reshape(plane.shape[0], r, r, ch).permute(0, 3, 1, 2)
+            return (raster if self.channels_last else raster.contiguous()), state, plane
+        if mlp.grid_first_applicable(tile, r, ch):
             # coarse levels (many points per pixel): fc_comm.0 on the pixels, its 2C-wide result interpolated straight into
             # the hidden activations -- see mlp._CommMLPGridFirst
             c, plane = mlp.comm_mlp_grid_first(tile, plane, fa.weight, fa.bias, fb.weight, fb.bias, c_last,
@@ -102,13 +113,13 @@ class DownConv(_PointGridLevel):
         if i > 0:
             self.conv1x1 = conv1x1(in_channels, out_channels)
 
-    def forward(self, tile: TileIndex, grid_in, prev_conv=None, c_last=None):
+    def forward(self, tile: TileIndex, grid_in, prev_conv=None, c_last=None, later_res=None):
         g = self._conv_pair(grid_in)
         if prev_conv is not None:
             # alto.py:104-114: levels 2..depth-1 see the pooled previous conv output, level 1 the unpooled one
             res_in = self._pool(prev_conv) if 2 <= self.downsample < self.depth else prev_conv
             g = self._conv1x1(self.conv1x1, res_in, addend=g)
-        raster, c, g = self._exchange(tile, g, c_last)
+        raster, c, g = self._exchange(tile, g, c_last, later_res)
         if self.pooling and self.channels_last:         # raster is also the skip connection: one fused gradient sum
             pooled, raster = grid.maxpool2x2_thru(raster, self.pool)
         else:
@@ -136,7 +147,7 @@ class UpConv(_PointGridLevel):
         self.conv1 = conv3x3(2 * out_channels if merge_mode == "concat" else out_channels, out_channels)
         self.conv2 = conv3x3(out_channels, out_channels)
 
-    def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last):
+    def forward(self, tile: TileIndex, from_down, from_up, prev_conv, c_last, later_res=None):
         up = self._conv1x1(self.upconv_noup if self.is_last else self.upconv, from_up)            # alto.py:215-218
         g = torch.cat((up, from_down), 1) if self.merge_mode == "concat" else up + from_down
         g = self._conv_pair(g)
@@ -144,7 +155,7 @@ class UpConv(_PointGridLevel):
             g = self._conv1x1(self.conv1x1, prev_conv, addend=g)                    # alto.py:233-236
         if self.is_last:                                                            # alto.py:241-242
             return g, g, c_last
-        raster, c, g = self._exchange(tile, g, c_last)
+        raster, c, g = self._exchange(tile, g, c_last, later_res)
         return raster, g, c
 
 
@@ -198,11 +209,24 @@ class UNet(nn.Module):
 
     def forward_sorted(self, tile: TileIndex, plane: torch.Tensor, c_sorted: torch.Tensor) -> torch.Tensor:
         skips, prev_conv, c = [], None, c_sorted
+        # plane resolution of every point<->grid exchange, in order (the deferred form needs to know where the hidden
+        # activations of a level will be rasterised later): down levels, then every up level but the last (alto.py:241-242)
+        res, r = [], plane.shape[2]
         for down in self.down_convs:
-            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c)
+            res.append(r)
+            r = r // 2 if down.pooling else r
+        for up in self.up_convs:
+            if not up.is_last:
+                r *= 2
+                res.append(r)
+        pos = 0
+        for down in self.down_convs:
+            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, res[pos:])
             skips.append(raster)
+            pos += 1
         for i, up in enumerate(self.up_convs):
-            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c)
+            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, res[pos:])
+            pos += 1
         if self.down_convs[0].channels_last:
             return grid.conv1x1(plane, self.conv_final)
         return self.conv_final(plane)
