@@ -127,7 +127,7 @@ int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nb
 int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t *off0, int B, int N,
                     int nbits, int level, int C, float *gfeat, t2h_stream_t stream);
 /* Per-cell SUMS instead of means (same kernels, no division), their 2x2 pooling to the next coarser resolution (a cell is
- * the union of its four children: plane [B, r, r, C] -> [B, r/2, r/2, C]) and the joint backward of sums taken at up to four
+ * the union of its four children: plane [B, r, r, C] -> [B, r/2, r/2, C]) and the joint backward of sums taken at up to eight
  * resolutions of the same rows: gfeat[n] = (mask[n] > 0 ?) sum_q gplane_q[cell_{level_q}(n)] (+ addend[n]).
  * They serve the "deferred point features" form of the ALTO point update (alto.py:121-130, 245-255): the per-point features
  * c_k = fc_comm.2(h_k) + fc_c(c_{k-1}) are linear in the hidden activations h_j (j <= k), and so is their scatter_mean, hence

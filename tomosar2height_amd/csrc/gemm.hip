@@ -415,6 +415,18 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
     if (mode == 1 && a.N > 64) return launch_gemm_split(mode, true, B_KC, a, 1, s, what);
     if (mode == 2) return launch_rows_p<B_KC, 2>(a, s, what);
     if (mode == 1) return launch_rows_p<B_KC, 1>(a, s, what);
+    // Few rows (the grid-side products of the deferred ALTO point update: 1024 .. 16384 pixel rows; the composed weight
+    // products): 128 x 128 tiles would leave most of the 256 CUs idle behind a long serial reduction -- the launch is
+    // latency-bound, so take the smallest tiles that still give every CU a workgroup (results do not depend on the tiling:
+    // every output is the same k-ordered fma chain)
+    if (mode == 0 && a.N > 64) {
+        const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        if (t128 < 192) {
+            const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+            if (t64 >= 192) return launch_gemm<64, 64, 2, 2, true, B_KC, 16, true, 1, 0>(a, 1, s, what);
+            return launch_gemm<32, 32, 1, 1, true, B_KC, 16, true, 1, 0>(a, 1, s, what);
+        }
+    }
     static const bool use_dma = !(getenv("T2H_GEMM_DMA") && getenv("T2H_GEMM_DMA")[0] == '0');
     // (r02 A/B: 128 x 64 tiles for the 128- / 256-wide layers -- twice the workgroups, VERDICT r01 item 6 -- lose 5-14 % on
     // the forward and gain 10 % only on the data gradient into 256 columns from a 128-long reduction; not adopted)

@@ -419,9 +419,10 @@ __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__re
     }
 }
 
-// Gradient of per-cell sums taken at several resolutions of the same rows (t2h_segsum_bwd_multi): one group per point,
+// Gradient of per-cell sums taken at several (<= 8) resolutions of the same rows (t2h_segsum_bwd_multi): one group per point,
 // gfeat[n] = (mask[n] > 0 ?) sum_l gplane_l[cell_l(n)] (+ addend[n]); planes in the order given (a fixed summation order).
-struct MultiPlanes { const float *g[4]; int level[4]; int n; };
+constexpr int kMaxMultiPlanes = 8;
+struct MultiPlanes { const float *g[kMaxMultiPlanes]; int level[kMaxMultiPlanes]; int n; };
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes mp, const int32_t *__restrict__ cell,
                                                                     int64_t npts, int nbits, int C, int lg,
@@ -434,9 +435,9 @@ __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes 
     const uint32_t code = (uint32_t)cell[n];
     const uint32_t b = code >> (2 * nbits), m = code & ((1u << (2 * nbits)) - 1u);
     const uint32_t x0 = compact1by1(m), y0 = compact1by1(m >> 1);             // finest-level cell coordinates
-    const float *rows[4];
+    const float *rows[kMaxMultiPlanes];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kMaxMultiPlanes; ++q) {
         rows[q] = nullptr;
         if (q < mp.n) {
             const int l = mp.level[q], r = 1 << (nbits - l);
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes 
     for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
         Vec<VEC> acc = Vec<VEC>::load(rows[0] + c);
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < kMaxMultiPlanes; ++q)
             if (q < mp.n) {
                 Vec<VEC> g = Vec<VEC>::load(rows[q] + c);
 #pragma unroll
@@ -1272,7 +1273,8 @@ T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *le
                                  int N, int nbits, int C, const float *mask, const float *addend, float *gfeat,
                                  t2h_stream_t stream) {
     if (!gplanes_nhwc || !levels || !cell || !gfeat) return fail(T2H_ERR_ARG, "segsum_bwd_multi: null pointer");
-    if (n_planes < 1 || n_planes > 4) return fail(T2H_ERR_ARG, "segsum_bwd_multi: 1..4 planes, got %d", n_planes);
+    if (n_planes < 1 || n_planes > kMaxMultiPlanes)
+        return fail(T2H_ERR_ARG, "segsum_bwd_multi: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
     if (B < 1 || N < 0 || nbits < 1 || nbits > T2H_MAX_NBITS || C < 1) return fail(T2H_ERR_ARG, "segsum_bwd_multi: unsupported shape");
     MultiPlanes mp{};
     mp.n = n_planes;
