@@ -138,6 +138,13 @@ int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbi
 int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream);
 int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B, int N,
                          int nbits, int C, const float *mask, const float *addend, float *gfeat, t2h_stream_t stream);
+/* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
+ * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
+ * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */
+int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell,
+                             const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                             int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
+                             t2h_stream_t stream);
 /* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
  * rasterisation and the next level's fc_c (alto.py:123-130), so their gradient is a sum of two -- formed here instead of
  * by an extra elementwise pass (gfeat may alias addend). */

@@ -936,11 +936,17 @@ __global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float 
 
 // grid_sample backward, stage 1: per (cell, split) the contributions of its rows to the 3x3 pixels around the
 // cell (slot = (py-cy+1)*3 + (px-cx+1)); every gradient row is read exactly once.
+// FUSED: the gradient row is not read from `gout` but formed on the fly as (mask[n] > 0 ?) sum_q mp.g[q][cell_q(n)] -- the
+// adjoint of the per-cell sums of the hidden activations (t2h_segsum_bwd_multi) folded into this kernel's row load, so the
+// [N, C] hidden gradient is never written or re-read (t2h_sample_bwd_from_sums)
+template <bool FUSED>
 __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const float *__restrict__ gout,
                                                                         const float *__restrict__ pts, int dim,
                                                                         const int32_t *__restrict__ off0, int nbits,
                                                                         int level, int C, int lgG, int S,
-                                                                        float *__restrict__ partial) {
+                                                                        float *__restrict__ partial, MultiPlanes mp,
+                                                                        const int32_t *__restrict__ cell,
+                                                                        const float *__restrict__ mask) {
     extern __shared__ float4 red[];                       // [P][G]
     const int G = 1 << lgG, P = kCellThreads >> lgG;
     int lane_c = threadIdx.x & (G - 1), slot = threadIdx.x >> lgG;
@@ -961,7 +967,26 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
     if (c < C) {
         for (int n = lo + slot; n < hi; n += P) {
             Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-            float4 g = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
+            float4 g;
+            if (FUSED) {
+                const uint32_t code = (uint32_t)cell[n];
+                const uint32_t fb = code >> (2 * nbits), fm = code & ((1u << (2 * nbits)) - 1u);
+                const uint32_t fx = compact1by1(fm), fy = compact1by1(fm >> 1);
+                const float4 hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + c);
+                g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < kMaxMultiPlanes; ++q)
+                    if (q < mp.n) {
+                        const int l = mp.level[q], rq = 1 << (nbits - l);
+                        const float4 u = *reinterpret_cast<const float4 *>(mp.g[q] + (((size_t)fb * rq + (fy >> l)) * rq + (fx >> l)) * C + c);
+                        if (q == 0) g = u;
+                        else { g.x = __fadd_rn(g.x, u.x); g.y = __fadd_rn(g.y, u.y); g.z = __fadd_rn(g.z, u.z); g.w = __fadd_rn(g.w, u.w); }
+                    }
+                g.x = hm.x > 0.f ? g.x : 0.f; g.y = hm.y > 0.f ? g.y : 0.f;
+                g.z = hm.z > 0.f ? g.z : 0.f; g.w = hm.w > 0.f ? g.w : 0.f;
+            } else {
+                g = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
+            }
             int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;           // slot column/row of the north-west tap: 0 or 1
 #pragma unroll
             for (int sy = 0; sy < 3; ++sy) {
@@ -1337,6 +1362,43 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
     return check_launch("sample_fwd");
 }
 
+T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell,
+                                     const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                                     int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
+                                     t2h_stream_t stream) {
+    if (!gplanes_nhwc || !levels || !cell || !mask || !pts || !off0 || !gplane_nhwc)
+        return fail(T2H_ERR_ARG, "sample_bwd_from_sums: null pointer");
+    if (n_planes < 1 || n_planes > kMaxMultiPlanes)
+        return fail(T2H_ERR_ARG, "sample_bwd_from_sums: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
+    int rc = check_level("sample_bwd_from_sums", B, nbits, level, C);
+    if (rc) return rc;
+    if (dim < 2 || N < 0 || C % 4 != 0 || ((uintptr_t)mask & 15)) return fail(T2H_ERR_ARG, "sample_bwd_from_sums: unsupported shape");
+    CoarsePlan cp = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
+    if (!cp.use)
+        return fail(T2H_ERR_ARG, "sample_bwd_from_sums: level %d holds too few points per cell for the per-cell partials "
+                                 "(t2h_sample_bwd_workspace_bytes == 0): use t2h_segsum_bwd_multi + t2h_sample_bwd", level);
+    size_t need = t2h_sample_bwd_workspace_bytes(B, N, nbits, level, C);
+    if (!workspace || workspace_bytes < need)
+        return fail(T2H_ERR_WORKSPACE, "sample_bwd_from_sums: workspace %zu < %zu bytes", workspace_bytes, need);
+    MultiPlanes mp{};
+    mp.n = n_planes;
+    for (int q = 0; q < n_planes; ++q) {
+        if (!gplanes_nhwc[q] || levels[q] < 0 || levels[q] > nbits || ((uintptr_t)gplanes_nhwc[q] & 15))
+            return fail(T2H_ERR_ARG, "sample_bwd_from_sums: bad plane %d", q);
+        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q];
+    }
+    int64_t groups = (int64_t)B << (2 * (nbits - level));
+    float *partial = static_cast<float *>(workspace);
+    int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
+    hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+                       (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
+                       partial, mp, cell, mask);
+    GroupCfg g = group_cfg<4>(C);
+    hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
+                       partial, B, nbits - level, C, g.lg, cp.S, nullptr, gplane_nhwc);
+    return check_launch("sample_bwd_from_sums");
+}
+
 T2H_API int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                                 t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd_relu: null pointer");
@@ -1375,9 +1437,9 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
             return fail(T2H_ERR_WORKSPACE, "sample_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         float *partial = static_cast<float *>(workspace);
         int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
-        hipLaunchKernelGGL(sample_bwd_cells_kernel, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+        hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                            (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
-                           cp.lgG, cp.S, partial);
+                           cp.lgG, cp.S, partial, MultiPlanes{}, nullptr, nullptr);
         GroupCfg g = group_cfg<4>(C);
         hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                            partial, B, nbits - level, C, g.lg, cp.S, addend, gplane_nhwc);

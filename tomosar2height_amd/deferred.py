@@ -30,6 +30,7 @@ import torch
 from . import _lib, mlp, ops
 
 DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
+FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
@@ -105,6 +106,21 @@ class _HiddenSums(torch.autograd.Function):
     def backward(ctx, *grads):
         (h,) = ctx.saved_tensors
         tile, r, c2 = ctx.tile, ctx.r, ctx.c2
+        level = tile.level(r)
+        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
+        planes = [(g.contiguous(), lv) for g, lv in zip(grads, ctx.levels) if g is not None]
+        if FUSED_SAMPLE_BWD and ws_bytes > 0 and planes and c2 % 4 == 0:
+            # coarse level: gather + mask inside the sample adjoint's row load, dh [N, 2C] is never written
+            arr = (ctypes.c_void_p * len(planes))(*[p.data_ptr() for p, _ in planes])
+            lvs = (ctypes.c_int * len(planes))(*[lv for _, lv in planes])
+            ws = _lib.workspace(ws_bytes, h.device)
+            dq = torch.empty(tile.B * r * r, c2, dtype=torch.float32, device=h.device)
+            _lib.call("t2h_sample_bwd_from_sums", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lvs, ctypes.c_void_p), len(planes),
+                      _lib.ptr(tile.cell), _lib.ptr(h), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+                      tile.nbits, level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, _lib.stream(),
+                      nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * dq.numel() + sum(4 * p.numel() for p, _ in planes),
+                      tag=f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
+            return dq, None, None, None
         dh = _gather(tile, grads, ctx.levels, c2, mask=h)
         dq = ops._sample_bwd(tile, dh, r, c2, None).reshape(tile.B * r * r, c2)
         return dq, None, None, None
