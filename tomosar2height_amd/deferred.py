@@ -31,6 +31,7 @@ from . import _lib, mlp, ops
 
 DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
 FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
+FUSED_SAMPLE_FWD = os.environ.get("T2H_FUSED_SAMPLE_FWD", "1") != "0"      # A/B: 0 = separate sample + per-cell sums
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
@@ -57,11 +58,11 @@ def _sumpool(tile, fine, level_fine):
     return coarse
 
 
-def cell_sums(tile, rows, levels):
-    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows, the
-    others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
+def cell_sums(tile, rows, levels, finest=None):
+    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows (or
+    given: ``finest``), the others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
     out = {}
-    cur, cur_level = _segsum(tile, rows, levels[0]), levels[0]
+    cur, cur_level = (_segsum(tile, rows, levels[0]) if finest is None else finest), levels[0]
     out[cur_level] = cur
     for lv in levels[1:]:
         while cur_level < lv:
@@ -95,12 +96,24 @@ class _HiddenSums(torch.autograd.Function):
         q_rows = q_rows.contiguous()
         c2 = q_rows.shape[1]
         h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
+        ctx.tile, ctx.r, ctx.levels, ctx.c2 = tile, r, tuple(levels), c2
+        ctx.save_for_backward(h)
+        levels = list(levels)
+        l0 = levels[0]
+        if (FUSED_SAMPLE_FWD and c2 % 4 == 0
+                and _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, l0, c2) == 0):
+            # interpolate, ReLU and the finest level's per-cell sums in one pass: h is written once and not read back
+            r0 = tile.R >> l0
+            s0 = torch.empty(tile.B * r0 * r0, c2, dtype=torch.float32, device=q_rows.device)
+            _lib.call("t2h_sample_relu_segsum_fwd", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+                      tile.N, tile.nbits, l0, r, c2, _lib.ptr(h), _lib.ptr(s0), _lib.stream(),
+                      nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * q_rows.numel() + 4 * s0.numel(),
+                      tag=f"t2h_sample_relu_segsum_fwd[C={c2},r={r}]")
+            return tuple(cell_sums(tile, h, levels, finest=s0))
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
                   _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
                   tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
-        ctx.tile, ctx.r, ctx.levels, ctx.c2 = tile, r, tuple(levels), c2
-        ctx.save_for_backward(h)
-        return tuple(cell_sums(tile, h, list(levels)))
+        return tuple(cell_sums(tile, h, levels))
 
     @staticmethod
     def backward(ctx, *grads):
@@ -140,63 +153,40 @@ class _PointSums(torch.autograd.Function):
         return _gather(ctx.tile, grads, ctx.levels, ctx.c), None, None
 
 
-# ------------------------------------------------------------------------------------------------ small dense pieces
-class _MatmulNN(torch.autograd.Function):
-    """x [m, k] @ a [k, n] on the fp32 MFMA kernels (composition of the Linear weights: Wc_k @ A_{k-1,j})."""
+# ------------------------------------------------------------------------------------------------ grid-side products
+class _SumMatmulNN(torch.autograd.Function):
+    """sum_j x_j @ A[off_j : off_j + K_j] for row blocks x_j [m, K_j] and ONE stacked matrix A [sum K_j, n] (the composed maps
+    of all sources, stacked by rows): accumulated by the GEMM epilogues -- no concat of the x_j, no elementwise adds, and the
+    gradient of A is written block by block into one buffer.  args = (A, x_0, x_1, ...)."""
 
     @staticmethod
-    def forward(ctx, x, a):
-        x, a = x.contiguous(), a.contiguous()
-        out = torch.empty(x.shape[0], a.shape[1], dtype=torch.float32, device=x.device)
-        mlp.linear_dgrad_(x, a, out)                      # "dx = dy w" is exactly x @ a
-        ctx.save_for_backward(x, a)
+    def forward(ctx, a_all, *xs):
+        a_all = a_all.contiguous()
+        xs = [x.contiguous() for x in xs]
+        out = torch.empty(xs[0].shape[0], a_all.shape[1], dtype=torch.float32, device=a_all.device)
+        off = 0
+        for j, x in enumerate(xs):
+            mlp.linear_dgrad_(x, a_all[off:off + x.shape[1]], out, accumulate=j > 0)        # "dx = dy w" is x @ A_j
+            off += x.shape[1]
+        if off != a_all.shape[0]:
+            raise ValueError(f"_SumMatmulNN: the blocks cover {off} of A's {a_all.shape[0]} rows")
+        ctx.save_for_backward(a_all, *xs)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, a = ctx.saved_tensors
+        a_all, *xs = ctx.saved_tensors
         g = g.contiguous()
-        dx = da = None
-        if ctx.needs_input_grad[0]:
-            dx = mlp.linear_fwd_(g, a, None, torch.empty_like(x))             # g @ a^T
-        if ctx.needs_input_grad[1]:
-            da = torch.empty_like(a)
-            mlp.linear_wgrad_(x, g, da, None)                                  # x^T g
-        return dx, da
-
-
-def matmul_nn(x, a):
-    return _MatmulNN.apply(x, a)
-
-
-class _SumLinear(torch.autograd.Function):
-    """sum_j x_j @ w_j^T for row blocks x_j [m, K_j] and weights w_j [n, K_j], accumulated by the GEMM epilogues (no concat of
-    the x_j, no elementwise adds).  args = (x_0, w_0, x_1, w_1, ...)."""
-
-    @staticmethod
-    def forward(ctx, *xw):
-        xs, ws = [t.contiguous() for t in xw[0::2]], [t.contiguous() for t in xw[1::2]]
-        out = torch.empty(xs[0].shape[0], ws[0].shape[0], dtype=torch.float32, device=xs[0].device)
-        for j, (x, w) in enumerate(zip(xs, ws)):
-            mlp.linear_fwd_(x, w, None, out, accumulate=j > 0)
-        ctx.save_for_backward(*xs, *ws)
-        ctx.n = len(xs)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        saved = ctx.saved_tensors
-        xs, ws = saved[:ctx.n], saved[ctx.n:]
-        g = g.contiguous()
-        grads = []
-        for j, (x, w) in enumerate(zip(xs, ws)):
-            dx = mlp.linear_dgrad_(g, w, torch.empty_like(x)) if ctx.needs_input_grad[2 * j] else None
-            dw = None
-            if ctx.needs_input_grad[2 * j + 1]:
-                dw = torch.empty_like(w)
-                mlp.linear_wgrad_(g, x, dw, None)
-            grads += [dx, dw]
-        return tuple(grads)
+        da = torch.empty_like(a_all) if ctx.needs_input_grad[0] else None
+        dxs, off = [], 0
+        for j, x in enumerate(xs):
+            k = x.shape[1]
+            blk = a_all[off:off + k]
+            dxs.append(mlp.linear_fwd_(g, blk, None, torch.empty_like(x)) if ctx.needs_input_grad[1 + j] else None)   # g @ A_j^T
+            if da is not None:
+                mlp.linear_wgrad_(x, g, da[off:off + k], None)                               # x_j^T g
+            off += k
+        return (da, *dxs)
 
 
 # ------------------------------------------------------------------------------------------------ state
@@ -213,15 +203,16 @@ def counts(tile, level):
 
 
 class Deferred:
-    """c_k = sum_j src_j A_j^T + const, never materialised.  ``sources``: dicts with ``sums`` {level: [B r r, K_j] rows} and
-    ``wt`` = A_j as an nn.Linear-layout matrix [C_k, K_j] (None = identity: the base tensor before the first fc_c)."""
+    """c_k = sum_j src_j A_j + const, never materialised.  ``sums``: per source {level: [B r r, K_j] per-cell sums};
+    ``a_all`` [sum K_j, C_k]: the maps A_j = (Wc_k ... Wc_{j+1} W1_j)^T of all sources stacked by rows, so that one product
+    per level composes them all with the level's fc_c (None until the first level: the base tensor's map is the identity)."""
 
     def __init__(self, tile, later_levels, base_rows):
         self.tile = tile
-        self.sources = []
+        levels = tuple(sorted(set(later_levels)))
+        self.sums = [dict(zip(levels, _PointSums.apply(base_rows, tile, levels)))]
+        self.a_all = None
         self.const = None                                 # [1, C_k] row or None (zero)
-        sums = _PointSums.apply(base_rows, tile, tuple(sorted(set(later_levels))))
-        self.sources.append({"sums": dict(zip(sorted(set(later_levels)), sums)), "wt": None})
 
     def advance(self, q_rows, r, later_levels, fc_b, fc_c):
         """One level: compose the maps with this level's fc_c, add the level's hidden activations as a source (their fc_comm.2
@@ -229,20 +220,17 @@ class Deferred:
         every later exchange (what the new source will be rasterised at)."""
         tile = self.tile
         wc, bc, w1, b1 = fc_c.weight, fc_c.bias, fc_b.weight, fc_b.bias
-        for s in self.sources:
-            s["wt"] = wc if s["wt"] is None else matmul_nn(wc, s["wt"])       # A_{k,j} = Wc_k A_{k-1,j}
+        # A_{k,j} = A_{k-1,j} Wc_k^T for every earlier source at once; the base tensor enters through Wc_k itself
+        prev = wc.t().contiguous() if self.a_all is None else mlp.linear(self.a_all, wc, None)
+        self.a_all = torch.cat([prev, w1.t().contiguous()], 0)
         if self.const is None:
             self.const = (bc + b1).reshape(1, -1)
         else:
             self.const = mlp.linear(self.const, wc, bc) + b1.reshape(1, -1)   # const_k = const_{k-1} Wc_k^T + bc_k + b1_k
         levels = tuple(sorted(set(later_levels)))
-        sums = _HiddenSums.apply(q_rows, tile, r, levels)
-        self.sources.append({"sums": dict(zip(levels, sums)), "wt": w1})
+        self.sums.append(dict(zip(levels, _HiddenSums.apply(q_rows, tile, r, levels))))
         lv = tile.level(r)
-        args = []
-        for s in self.sources:
-            args += [s["sums"][lv], s["wt"]]
-        acc = _SumLinear.apply(*args)
+        acc = _SumMatmulNN.apply(self.a_all, *[s[lv] for s in self.sums])
         inv_cnt, nonempty = counts(tile, lv)
         return acc * inv_cnt + nonempty * self.const      # scatter_mean: mean over the cell, 0 for an empty cell
 
