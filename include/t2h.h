@@ -138,11 +138,6 @@ int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbi
 int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream);
 int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B, int N,
                          int nbits, int C, const float *mask, const float *addend, float *gfeat, t2h_stream_t stream);
-/* t2h_sample_fwd_relu and t2h_segsum_fwd (at `level`) in one pass over the cells: out [B*N, C] = relu(sample(plane)) and
- * sums [B, R >> level, R >> level, C] = its per-cell sums; the hidden rows are written once and not read back.  One lane
- * group per cell, i.e. only for levels without the coarse split (t2h_segmean_workspace_bytes == 0).  Same bits as the pair. */
-int t2h_sample_relu_segsum_fwd(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
-                               int level, int r, int C, float *out, float *sums_nhwc, t2h_stream_t stream);
 /* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */

@@ -39,7 +39,6 @@ SIGNATURES = {
     "t2h_segsum_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_plane_sumpool2x2": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_segsum_bwd_multi": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "t2h_sample_relu_segsum_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_sample_bwd_from_sums": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_fwd_relu": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

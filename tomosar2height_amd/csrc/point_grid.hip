@@ -585,57 +585,6 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
     }
 }
 
-// sample_fwd_kernel<.., RELU> and the per-cell SUM of its output rows in one pass (t2h_sample_relu_segsum_fwd): one group per
-// level-`level` cell walks the cell's rows, interpolates each (same arithmetic, same order as sample_fwd_kernel), stores the
-// hidden row and keeps the running sum in registers -- the [N, C] hidden activations are written once and not read back.
-__global__ __launch_bounds__(kThreads) void sample_relu_segsum_kernel(const float *__restrict__ plane,
-                                                                     const float *__restrict__ pts, int dim,
-                                                                     const int32_t *__restrict__ off0, int B, int nbits,
-                                                                     int level, int r, int C, int lg,
-                                                                     float *__restrict__ out, float *__restrict__ sums) {
-    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    int64_t gid = t >> lg;
-    const int rbits = nbits - level;
-    const int64_t cells_per_tile = (int64_t)1 << (2 * rbits);
-    if (gid >= (int64_t)B * cells_per_tile) return;
-    const int b = (int)(gid >> (2 * rbits));
-    const uint32_t mk = (uint32_t)(gid & (cells_per_tile - 1));
-    const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
-    const int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
-    const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1), rs = 1 << rbits;
-    float *srow = sums + (((size_t)b * rs + cy) * rs + cx) * C;
-    const float *base = plane + (size_t)b * r * r * C;
-    const int span = 4 << lg;
-    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += span) {
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int n = s; n < e; ++n) {
-            Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-            const float nw = __fmul_rn(tp.wx0, tp.wy0), ne = __fmul_rn(tp.wx1, tp.wy0);
-            const float sw = __fmul_rn(tp.wx0, tp.wy1), se = __fmul_rn(tp.wx1, tp.wy1);
-            const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
-            const float *p00 = base + ((size_t)tp.y0 * r + tp.x0) * C + c;
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            // the four taps requested together (taps outside the plane carry weight 0 and are simply not added, as in ATen)
-            const float4 v00 = *reinterpret_cast<const float4 *>(p00);
-            const float4 v01 = x1ok ? *reinterpret_cast<const float4 *>(p00 + C) : zero;
-            const float4 v10 = y1ok ? *reinterpret_cast<const float4 *>(p00 + (size_t)r * C) : zero;
-            const float4 v11 = (x1ok && y1ok) ? *reinterpret_cast<const float4 *>(p00 + (size_t)r * C + C) : zero;
-            float4 a;
-            a.x = __fmul_rn(v00.x, nw); a.y = __fmul_rn(v00.y, nw); a.z = __fmul_rn(v00.z, nw); a.w = __fmul_rn(v00.w, nw);
-            if (x1ok) { a.x = __fadd_rn(a.x, __fmul_rn(v01.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v01.y, ne));
-                        a.z = __fadd_rn(a.z, __fmul_rn(v01.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v01.w, ne)); }
-            if (y1ok) { a.x = __fadd_rn(a.x, __fmul_rn(v10.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v10.y, sw));
-                        a.z = __fadd_rn(a.z, __fmul_rn(v10.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v10.w, sw)); }
-            if (x1ok && y1ok) { a.x = __fadd_rn(a.x, __fmul_rn(v11.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v11.y, se));
-                                a.z = __fadd_rn(a.z, __fmul_rn(v11.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v11.w, se)); }
-            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-            *reinterpret_cast<float4 *>(out + (size_t)n * C + c) = a;
-            sum.x += a.x; sum.y += a.y; sum.z += a.z; sum.w += a.w;
-        }
-        *reinterpret_cast<float4 *>(srow + c) = sum;
-    }
-}
-
 // Deterministic backward: one group per pixel; a point of cell (cx,cy) only touches pixels
 // {cx-1..cx+1} x {cy-1..cy+1} (px = x*(r-1) lies in (cx-1, cx+1)), so pixel (px,py) gathers from the
 // 3x3 cells around it.  Cells are visited row-major, points in sorted order: a fixed summation order.
@@ -1016,9 +965,9 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
 #pragma unroll
     for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C) {
-        for (int n = lo + slot; n < hi; n += P) {
-            Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
-            float4 g;
+        // a row's value: its gradient row, or (FUSED) the gathered + masked sum of the per-cell-sum gradients
+        auto fetch = [&](int n, Taps &tp, float4 &g) {
+            tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
             if (FUSED) {
                 const uint32_t code = (uint32_t)cell[n];
                 const uint32_t fb = code >> (2 * nbits), fm = code & ((1u << (2 * nbits)) - 1u);
@@ -1038,7 +987,9 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
             } else {
                 g = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
             }
-            int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;           // slot column/row of the north-west tap: 0 or 1
+        };
+        auto accumulate = [&](const Taps &tp, const float4 &g) {
+            const int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;     // slot column/row of the north-west tap: 0 or 1
 #pragma unroll
             for (int sy = 0; sy < 3; ++sy) {
                 float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
@@ -1053,6 +1004,23 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
                     a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
                 }
             }
+        };
+        // two rows in flight per slot: the loads of the second row (points, cell code, planes, mask) are requested before
+        // the first row's 36 multiply-adds; rows are accumulated in the same order as a one-row loop
+        int n = lo + slot;
+        for (; n + P < hi; n += 2 * P) {
+            Taps t0, t1;
+            float4 g0, g1;
+            fetch(n, t0, g0);
+            fetch(n + P, t1, g1);
+            accumulate(t0, g0);
+            accumulate(t1, g1);
+        }
+        if (n < hi) {
+            Taps t0;
+            float4 g0;
+            fetch(n, t0, g0);
+            accumulate(t0, g0);
         }
     }
     float *pbase = partial + ((size_t)cellrow * S + sp) * 9 * C;
@@ -1411,23 +1379,6 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
           hipLaunchKernelGGL(sample_fwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
                              plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });
     return check_launch("sample_fwd");
-}
-
-T2H_API int t2h_sample_relu_segsum_fwd(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
-                                       int nbits, int level, int r, int C, float *out, float *sums_nhwc, t2h_stream_t stream) {
-    if (!plane_nhwc || !pts || !off0 || !out || !sums_nhwc) return fail(T2H_ERR_ARG, "sample_relu_segsum_fwd: null pointer");
-    int rc = check_level("sample_relu_segsum_fwd", B, nbits, level, C);
-    if (rc) return rc;
-    if (dim < 2 || N < 0 || r < 1 || C % 4 != 0 || ((uintptr_t)plane_nhwc & 15) || ((uintptr_t)out & 15) || ((uintptr_t)sums_nhwc & 15))
-        return fail(T2H_ERR_ARG, "sample_relu_segsum_fwd: needs C %% 4 == 0 and 16-byte aligned rows");
-    if (coarse_plan(B, N, nbits, level, C).use)
-        return fail(T2H_ERR_ARG, "sample_relu_segsum_fwd: level %d holds too many points per cell for one lane group per cell "
-                                 "(t2h_segmean_workspace_bytes > 0): use t2h_sample_fwd_relu + t2h_segsum_fwd", level);
-    const int64_t groups = (int64_t)B << (2 * (nbits - level));
-    GroupCfg g = group_cfg<4>(C);
-    hipLaunchKernelGGL(sample_relu_segsum_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                       plane_nhwc, pts, dim, off0, B, nbits, level, r, C, g.lg, out, sums_nhwc);
-    return check_launch("sample_relu_segsum_fwd");
 }
 
 T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell,

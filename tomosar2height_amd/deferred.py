@@ -31,7 +31,6 @@ from . import _lib, mlp, ops
 
 DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
 FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
-FUSED_SAMPLE_FWD = os.environ.get("T2H_FUSED_SAMPLE_FWD", "1") != "0"      # A/B: 0 = separate sample + per-cell sums
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
@@ -58,11 +57,11 @@ def _sumpool(tile, fine, level_fine):
     return coarse
 
 
-def cell_sums(tile, rows, levels, finest=None):
-    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows (or
-    given: ``finest``), the others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
+def cell_sums(tile, rows, levels):
+    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows, the
+    others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
     out = {}
-    cur, cur_level = (_segsum(tile, rows, levels[0]) if finest is None else finest), levels[0]
+    cur, cur_level = _segsum(tile, rows, levels[0]), levels[0]
     out[cur_level] = cur
     for lv in levels[1:]:
         while cur_level < lv:
@@ -98,22 +97,12 @@ class _HiddenSums(torch.autograd.Function):
         h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
         ctx.tile, ctx.r, ctx.levels, ctx.c2 = tile, r, tuple(levels), c2
         ctx.save_for_backward(h)
-        levels = list(levels)
-        l0 = levels[0]
-        if (FUSED_SAMPLE_FWD and c2 % 4 == 0
-                and _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, l0, c2) == 0):
-            # interpolate, ReLU and the finest level's per-cell sums in one pass: h is written once and not read back
-            r0 = tile.R >> l0
-            s0 = torch.empty(tile.B * r0 * r0, c2, dtype=torch.float32, device=q_rows.device)
-            _lib.call("t2h_sample_relu_segsum_fwd", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
-                      tile.N, tile.nbits, l0, r, c2, _lib.ptr(h), _lib.ptr(s0), _lib.stream(),
-                      nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * q_rows.numel() + 4 * s0.numel(),
-                      tag=f"t2h_sample_relu_segsum_fwd[C={c2},r={r}]")
-            return tuple(cell_sums(tile, h, levels, finest=s0))
+        # (interpolation + ReLU + the finest level's per-cell sums in ONE pass over the cells was built and measured in r03:
+        # 414 us against 162 + 210 us at C = 1024 -- a cell's rows in sequence expose the tap loads' latency -- and dropped)
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
                   _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
                   tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
-        return tuple(cell_sums(tile, h, levels))
+        return tuple(cell_sums(tile, h, list(levels)))
 
     @staticmethod
     def backward(ctx, *grads):
