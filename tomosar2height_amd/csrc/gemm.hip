@@ -553,6 +553,10 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
     float *slab = static_cast<float *>(workspace);
     float *colslab = slab + (size_t)p.splits * N * K;
     int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
+    // one split, plain store, no bias gradient (the grid-side products of the deferred point update): the kernel writes dW
+    // itself and the slab reduction launch is skipped (same values: the reduction of one slab is a copy)
+    const bool direct = !p.smallk && p.splits == 1 && !accumulate && !db && aligned4(dw, K);
+    if (direct) slab = dw;
     if (p.smallk) {
         if (K > kSmallKMax) return fail(T2H_ERR_ARG, "linear_wgrad: K=%d must be a multiple of 4 (or <= %d)", K, kSmallKMax);
         hipLaunchKernelGGL(wgrad_smallk_kernel, dim3(p.splits), dim3(256), 0, s, dy, lddy, x, ldx, M, K, N,
@@ -587,5 +591,6 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
 #undef T2H_WG
         if (rc) return rc;
     }
+    if (direct) return T2H_OK;
     return launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, colslab, db, s);
 }

@@ -1124,7 +1124,8 @@ static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C, int min
     // aim at >= 4096 workgroups; the channel chunks of a cell are workgroups of their own, so wide rows need fewer row
     // splits -- and every split costs a 9-slot partial row per cell to write and re-read (C = 512, r = 32: 4 -> 2 splits)
     const int64_t wgs = (int64_t)B * cells * p.chunks;
-    int64_t want = (4096 + wgs - 1) / wgs;
+    static const int64_t min_wgs = getenv("T2H_CELLS_MIN_WGS") ? atoll(getenv("T2H_CELLS_MIN_WGS")) : 4096;
+    int64_t want = (min_wgs + wgs - 1) / wgs;
     p.S = (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
     return p;
 }
