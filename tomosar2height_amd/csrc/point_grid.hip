@@ -988,23 +988,21 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
                 g = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + c);
             }
         };
-        // A row touches the 2 x 2 block of the 3 x 3 pixel slots that starts at (dy, dx) in {0, 1}^2: four multiply-add groups
-        // instead of nine weighted ones.  The branch is uniform over a lane group (all its lanes hold the same row); which slots
-        // a row adds to -- and in which order rows reach a slot -- is the same as with nine zero-padded weights, except that the
-        // five "+ 0 * g" terms are gone (they only mattered for -0 / NaN propagation of absent taps).
-        auto fma4 = [](float4 &a, float w, const float4 &g) {
-            // fused multiply-add: the partial sums are re-associated against the reference's order anyway (tolerance-checked)
-            a.x = __fmaf_rn(w, g.x, a.x); a.y = __fmaf_rn(w, g.y, a.y); a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
-        };
         auto accumulate = [&](const Taps &tp, const float4 &g) {
             const int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;     // slot column/row of the north-west tap: 0 or 1
-            const float w00 = __fmul_rn(tp.wx0, tp.wy0), w01 = __fmul_rn(tp.wx1, tp.wy0);
-            const float w10 = __fmul_rn(tp.wx0, tp.wy1), w11 = __fmul_rn(tp.wx1, tp.wy1);
-            switch (((dy & 1) << 1) | (dx & 1)) {
-                case 0: fma4(acc[0], w00, g); fma4(acc[1], w01, g); fma4(acc[3], w10, g); fma4(acc[4], w11, g); break;
-                case 1: fma4(acc[1], w00, g); fma4(acc[2], w01, g); fma4(acc[4], w10, g); fma4(acc[5], w11, g); break;
-                case 2: fma4(acc[3], w00, g); fma4(acc[4], w01, g); fma4(acc[6], w10, g); fma4(acc[7], w11, g); break;
-                default: fma4(acc[4], w00, g); fma4(acc[5], w01, g); fma4(acc[7], w10, g); fma4(acc[8], w11, g); break;
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy) {
+                float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
+                    float w = __fmul_rn(wx, wy);
+                    float4 &a = acc[sy * 3 + sx];
+                    // fused multiply-add: this kernel is VALU-bound (nine slots per row), and its partial sums are
+                    // re-associated against the reference's order anyway (tolerance-checked, not bit-compared)
+                    a.x = __fmaf_rn(w, g.x, a.x); a.y = __fmaf_rn(w, g.y, a.y);
+                    a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
+                }
             }
         };
         // two rows in flight per slot: the loads of the second row (points, cell code, planes, mask) are requested before
