@@ -1040,6 +1040,132 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
     }
 }
 
+// The same per-(cell, split) partials on the matrix cores (C % 64 == 0).  For one cell the contributions of its rows to the
+// 3 x 3 pixel slots are a small dense product  partial[slot, :] = sum_rows W[slot, row] * g[row, :]  with W the bilinear tap
+// weights -- v_mfma_f32_16x16x4_f32 with M = slots (9 of 16), K = rows (4 per instruction), N = channels.  Per block of 64
+// rows 64 threads compute each row's taps ONCE (the VALU kernel above recomputes them in every lane: ~40 of its ~150
+// instructions per row and lane, plus 27 for the zero-padded weights and 36 multiply-adds) and leave the [64][16] weight tile
+// (FUSED: and every row's pixel index in each gradient plane) in LDS; a wave then owns 64 channels: lane (k = l >> 4,
+// n = l & 15) loads the float4 of channels 4 n .. 4 n + 3 of row k -- 256 contiguous bytes per row -- and its four components
+// are the B operands of four MFMAs (the N index of an MFMA is only a label: tile t holds channels 4 n + t), so the results of a
+// slot come out as float4s again.  fp32 MFMA = an exact fma chain over the rows in order, as the VALU form.
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+constexpr int kMfmaRows = 64;
+template <bool FUSED>
+__global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(const float *__restrict__ gout,
+                                                                             const float *__restrict__ pts, int dim,
+                                                                             const int32_t *__restrict__ off0, int nbits,
+                                                                             int level, int C, int S,
+                                                                             float *__restrict__ partial, MultiPlanes mp,
+                                                                             const int32_t *__restrict__ cell,
+                                                                             const float *__restrict__ mask) {
+    __shared__ float Wl[kMfmaRows][16];
+    __shared__ int Po[kMfmaRows][kMaxMultiPlanes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t cellrow = blockIdx.x;
+    const int sp = blockIdx.y % S, chunk = blockIdx.y / S;
+    const int rbits = nbits - level, r = 1 << rbits;
+    const int b = (int)(cellrow >> (2 * rbits));
+    const uint32_t mk = (uint32_t)(cellrow & (((int64_t)1 << (2 * rbits)) - 1));
+    const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    const int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
+    int lo, hi;
+    split_range(s, e, sp, S, lo, hi);
+    const int ch = chunk * cell_chunk_channels(C) + wave * 64 + 4 * (lane & 15);
+    const bool active = ch < C;                            // uniform over the wave (C % 64 == 0)
+    const int kq = lane >> 4;                              // this lane's row inside a 4-row MFMA step
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int blk = lo; blk < hi; blk += kMfmaRows) {
+        __syncthreads();                                   // the previous block's tiles are consumed
+        if (tid < kMfmaRows) {
+            const int n = blk + tid;
+            float w[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) w[q] = 0.0f;
+            const int nn = min(n, hi - 1);
+            if (n < hi) {
+                const Taps tp = make_taps(pts[(size_t)n * dim + 0], pts[(size_t)n * dim + 1], r);
+                const int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;       // slot column/row of the north-west tap: 0 or 1
+#pragma unroll
+                for (int sy = 0; sy < 3; ++sy) {
+                    const float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
+                        w[sy * 3 + sx] = __fmul_rn(wx, wy);
+                    }
+                }
+            }
+            float4 *wr = reinterpret_cast<float4 *>(&Wl[tid][0]);
+            wr[0] = make_float4(w[0], w[1], w[2], w[3]);
+            wr[1] = make_float4(w[4], w[5], w[6], w[7]);
+            wr[2] = make_float4(w[8], 0.f, 0.f, 0.f);
+            wr[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FUSED) {
+                const uint32_t code = (uint32_t)cell[nn];
+                const uint32_t fb = code >> (2 * nbits), fm = code & ((1u << (2 * nbits)) - 1u);
+                const uint32_t fx = compact1by1(fm), fy = compact1by1(fm >> 1);
+#pragma unroll
+                for (int q = 0; q < kMaxMultiPlanes; ++q)
+                    if (q < mp.n) {
+                        const int l = mp.level[q], rq = 1 << (nbits - l);
+                        Po[tid][q] = (int)((fb * rq + (fy >> l)) * rq + (fx >> l));
+                    }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int steps = (min(kMfmaRows, hi - blk) + 3) >> 2;
+            // two 4-row steps per iteration, both steps' loads requested before the first step's MFMAs; an odd last step runs
+            // a padding step on clamped rows whose weights are 0
+            for (int st0 = 0; st0 < steps; st0 += 2) {
+                float a[2];
+                float4 g[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rr = 4 * (st0 + u) + kq;
+                    const int n = min(blk + rr, hi - 1);   // rows past the end carry weight 0; keep their loads in bounds
+                    a[u] = Wl[rr][lane & 15];
+                    if (FUSED) {
+                        const float4 hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + ch);
+                        float4 v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * C + ch);
+#pragma unroll
+                        for (int q = 1; q < kMaxMultiPlanes; ++q)
+                            if (q < mp.n) {
+                                const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * C + ch);
+                                v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
+                            }
+                        v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
+                        v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+                        g[u] = v;
+                    } else {
+                        g[u] = *reinterpret_cast<const float4 *>(gout + (size_t)n * C + ch);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], g[u].w, acc[3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (active) {
+        // D layout: column = lane & 15 (-> channels 4 (lane & 15) + t of tile t), row = 4 (lane >> 4) + i = the pixel slot
+        float *pbase = partial + ((size_t)cellrow * S + sp) * 9 * C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 4 * kq + i;
+            if (m < 9) *reinterpret_cast<float4 *>(pbase + (size_t)m * C + ch) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        }
+    }
+}
+
 // stage 2: pixel (px,py) sums the matching slot of its (up to) 9 neighbouring cells, cells row-major, splits in order.
 __global__ __launch_bounds__(kThreads) void sample_bwd_gather9_kernel(const float *__restrict__ partial, int B,
                                                                      int rbits, int C, int lg, int S,
@@ -1109,6 +1235,12 @@ static int check_level(const char *what, int B, int nbits, int level, int C) {
     return T2H_OK;
 }
 
+
+// the matrix-core form of the sample adjoint's per-cell partials: 64-channel wave slices (T2H_CELLS_MFMA=0: the VALU form, A/B)
+static bool cells_mfma(int C) {
+    static const bool on = !(getenv("T2H_CELLS_MFMA") && getenv("T2H_CELLS_MFMA")[0] == '0');
+    return on && C % 64 == 0;
+}
 
 // ---- coarse-level strategy: used when a cell holds >= 16 points on average and rows are float4-able ----------
 struct CoarsePlan { bool use; int S; int lgG; int chunks; };
@@ -1410,9 +1542,13 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     int64_t groups = (int64_t)B << (2 * (nbits - level));
     float *partial = static_cast<float *>(workspace);
     int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
-    hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
-                       (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
-                       partial, mp, cell, mask);
+    if (cells_mfma(C))
+        hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, mask);
+    else
+        hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+                           (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
+                           partial, mp, cell, mask);
     GroupCfg g = group_cfg<4>(C);
     hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                        partial, B, nbits - level, C, g.lg, cp.S, nullptr, gplane_nhwc);
@@ -1457,9 +1593,14 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
             return fail(T2H_ERR_WORKSPACE, "sample_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         float *partial = static_cast<float *>(workspace);
         int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
-        hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
-                           (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
-                           cp.lgG, cp.S, partial, MultiPlanes{}, nullptr, nullptr);
+        if (cells_mfma(C))
+            hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
+                               as_stream(stream), gout, pts, dim, off0, nbits, level, C, cp.S, partial, MultiPlanes{}, nullptr,
+                               nullptr);
+        else
+            hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
+                               (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
+                               cp.lgG, cp.S, partial, MultiPlanes{}, nullptr, nullptr);
         GroupCfg g = group_cfg<4>(C);
         hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                            partial, B, nbits - level, C, g.lg, cp.S, addend, gplane_nhwc);
