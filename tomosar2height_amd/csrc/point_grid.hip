@@ -1042,15 +1042,15 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
 
 // The same per-(cell, split) partials on the matrix cores (C % 64 == 0).  For one cell the contributions of its rows to the
 // 3 x 3 pixel slots are a small dense product  partial[slot, :] = sum_rows W[slot, row] * g[row, :]  with W the bilinear tap
-// weights -- v_mfma_f32_16x16x4_f32 with M = slots (9 of 16), K = rows (4 per instruction), N = channels.  Per block of 256
-// rows every thread computes one row's taps ONCE (the VALU kernel above recomputes them in every lane: ~40 of its ~150
-// instructions per row and lane, plus 27 for the zero-padded weights and 36 multiply-adds) and leave the [256][16] weight tile
+// weights -- v_mfma_f32_16x16x4_f32 with M = slots (9 of 16), K = rows (4 per instruction), N = channels.  Per block of 64
+// rows 64 threads compute each row's taps ONCE (the VALU kernel above recomputes them in every lane: ~40 of its ~150
+// instructions per row and lane, plus 27 for the zero-padded weights and 36 multiply-adds) and leave the [64][16] weight tile
 // (FUSED: and every row's pixel index in each gradient plane) in LDS; a wave then owns 64 channels: lane (k = l >> 4,
 // n = l & 15) loads the float4 of channels 4 n .. 4 n + 3 of row k -- 256 contiguous bytes per row -- and its four components
 // are the B operands of four MFMAs (the N index of an MFMA is only a label: tile t holds channels 4 n + t), so the results of a
 // slot come out as float4s again.  fp32 MFMA = an exact fma chain over the rows in order, as the VALU form.
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
-constexpr int kMfmaRows = 256;       // rows per block: every thread prepares one row (taps, plane indices), 24 KB of LDS
+constexpr int kMfmaRows = 64;
 template <bool FUSED>
 __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(const float *__restrict__ gout,
                                                                              const float *__restrict__ pts, int dim,
