@@ -42,8 +42,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
 # the scatter-reduce kernels north_star names: the largest scatter_mean, and pool_local -- which since r02 has no kernel of
 # its own: the segmented max / its backward run in the loaders of the fused trunk block kernels (csrc/trunk.hip)
-SCATTER_REDUCE_TAGS = ("t2h_segmean_fwd[C=512,r=32]", "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]",
-                       "t2h_pool_max_fwd", "t2h_pool_max_bwd")
+# r03: with the deferred point update (deferred.py) the wide scatter_means run as per-cell SUMS of the hidden activations
+# (t2h_segsum_fwd at the finest resolution + 2x2 pooling) and their joint backward
+SCATTER_REDUCE_TAGS = ("t2h_segsum_fwd[C=1024,r=256]", "t2h_segsum_fwd[C=512,r=256]", "t2h_segmean_fwd[C=512,r=32]",
+                       "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]", "t2h_pool_max_fwd", "t2h_pool_max_bwd")
 
 
 def parse():
@@ -111,6 +113,18 @@ def pmc_traffic():
         return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json (rocprofv3 --pmc passes of profile {d.get('tag', '?')}, not this run)"
     except (OSError, ValueError):
         return {}, None
+
+
+def point_update_note():
+    """Which association of the ALTO point update runs (same function as alto.py:121-130, see mlp.py / deferred.py)."""
+    from tomosar2height_amd import deferred, mlp
+    parts = []
+    if mlp.GRID_FIRST_MIN_RATIO > 0:
+        parts.append(f"fc_comm.0 on the pixels where a level has >= {mlp.GRID_FIRST_MIN_RATIO:g} points per pixel")
+    if deferred.DEFER_MIN_CHANNELS > 0:
+        parts.append(f"per-point features deferred (fc_comm.2 / fc_c on per-cell sums) from the first level with >= "
+                     f"{deferred.DEFER_MIN_CHANNELS} channels")
+    return "; ".join(parts) if parts else "point-wise as the reference (alto.py:121-130)"
 
 
 def cpu_baseline(args):
@@ -545,6 +559,7 @@ def main():
                        "channels_last": bool(args.channels_last),
                        "point_distribution": "uniform (no-skew control)" if args.uniform_xy else "70 % in 160 buildings + 30 % uniform",
                        "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",
+                       "point_update": point_update_note(),
                        "library_fallbacks": getattr(grid, "fallback_count", lambda: None)(),
                        "hip_graph": bool(args.hip_graph)},
         }

@@ -26,7 +26,10 @@ import re
 PROBE_OPS = {   # bench.py tag -> kernel-name substrings of one launch of the op, in the probe's order
     "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],
     "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
-    "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_kernel", "sample_bwd_gather9_kernel"],
+    "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_", "sample_bwd_gather9_kernel"],
+    # r03, deferred point update: per-cell sums of the widest hidden activations at the finest resolution
+    "t2h_segsum_fwd[C=1024,r=256]": ["segmean_fwd_kernel<4, false>"],
+    "t2h_segsum_bwd_multi[C=1024,n=4]": ["segsum_bwd_multi_kernel"],
 }
 # entry points of point_grid.hip do not note a kernel symbol: bench.py keys them by entry-point name
 ENTRY_OF = {"sample_fwd_kernel": "t2h_sample_fwd", "segmean_bwd_kernel": "t2h_segmean_bwd"}
@@ -68,6 +71,7 @@ def main():
     ap.add_argument("--bench", nargs=2, metavar=("FETCH_DIR", "WRITE_DIR"))
     ap.add_argument("--probe", nargs=2, metavar=("FETCH_DIR", "WRITE_DIR"))
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--tag", default="?", help="profile tag the passes belong to (recorded; bench.py prints it as the source)")
     a = ap.parse_args()
     out, detail = {}, {}
     if a.bench:
@@ -98,7 +102,7 @@ def main():
                 detail[tag] = {"parts": rows, "source": "profiles/pmc_probe.py"}
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "pmc_traffic.json"), "w") as fjs:
-        json.dump({"workload": "BASELINE.json configs[1], N=131072",
+        json.dump({"workload": "BASELINE.json configs[1], N=131072", "tag": a.tag,
                    "formula": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts half of wide reads)",
                    "bytes_per_launch": out, "detail": detail}, fjs, indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1])[:40]:

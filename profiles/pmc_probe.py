@@ -27,5 +27,14 @@ plane = torch.randn(1, 512, 32, 32, device=dev).contiguous(memory_format=torch.c
 for _ in range(REPS):
     out = ops.sample_plane(tile, plane)                       # sample_fwd_kernel<4>
     out.backward(x512)                                        # sample_bwd_cells_kernel + sample_bwd_gather9_kernel
+# r03: the deferred point update's scatter-reduce pair on the widest hidden tensor (N x 1024), finest resolution
+from tomosar2height_amd import deferred                      # noqa: E402
+x1024 = torch.randn(M, 1024, device=dev)
+planes = None
+for _ in range(REPS):
+    planes = deferred.cell_sums(tile, x1024, [0, 1, 2, 3])    # segmean_fwd_kernel<4, false> + 3 x plane_sumpool2x2_kernel
+grads = [torch.randn_like(p) for p in planes]
+for _ in range(REPS):
+    deferred._gather(tile, grads, (0, 1, 2, 3), 1024, mask=x1024)      # segsum_bwd_multi_kernel<4>
 torch.cuda.synchronize()
 print("pmc_probe done")
