@@ -138,6 +138,16 @@ int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbi
 int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream);
 int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B, int N,
                          int nbits, int C, const float *mask, const float *addend, float *gfeat, t2h_stream_t stream);
+/* Grid-side glue of the deferred form (csrc/deferred.hip): the points-per-cell plane [B, r, r] (float, row-major) of an ALTO
+ * level from the tile CSR; scatter_mean's division / empty-cell rule / composed bias applied to a product of per-cell sums,
+ *   raster[p, :] = acc[p, :] / max(cnt[p], 1) + [cnt[p] > 0] * cvec[:]                       (alto.py:76-88: count clamped to 1),
+ * and its backward (dacc = g / max(cnt, 1); dcvec = sum over non-empty cells of g, two-stage fixed-order column sum;
+ * either output may be NULL). */
+int t2h_cell_counts(const int32_t *off0, int B, int nbits, int level, float *cnt, t2h_stream_t stream);
+int t2h_mean_bias_fwd(const float *acc, const float *cnt, const float *cvec, int64_t P, int C, float *out, t2h_stream_t stream);
+size_t t2h_mean_bias_bwd_workspace_bytes(int64_t P, int C);
+int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float *dacc, float *dcvec, void *workspace,
+                      size_t workspace_bytes, t2h_stream_t stream);
 /* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */

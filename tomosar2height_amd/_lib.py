@@ -39,6 +39,10 @@ SIGNATURES = {
     "t2h_segsum_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_plane_sumpool2x2": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_segsum_bwd_multi": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "t2h_cell_counts": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "t2h_mean_bias_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "t2h_mean_bias_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "t2h_mean_bias_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_from_sums": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_fwd_relu": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -178,16 +178,94 @@ class _SumMatmulNN(torch.autograd.Function):
         return (da, *dxs)
 
 
+class _ComposeStack(torch.autograd.Function):
+    """A_k = [A_{k-1} Wc_k^T ; W1_k^T]: the maps of all earlier sources composed with this level's fc_c in ONE product, and the
+    new source's map (fc_comm.2, transposed) appended -- written straight into the stacked matrix (no cat, no transposed copy
+    outside).  ``a_prev`` None: the base tensor's map before its first fc_c is the identity, so its block is Wc_k^T itself."""
+
+    @staticmethod
+    def forward(ctx, a_prev, wc, w1):
+        ck, cprev = wc.shape
+        k2 = w1.shape[1]
+        rows_prev = cprev if a_prev is None else a_prev.shape[0]
+        out = torch.empty(rows_prev + k2, ck, dtype=torch.float32, device=wc.device)
+        wc_c, w1_c = wc.contiguous(), w1.contiguous()
+        if a_prev is None:
+            _transpose(wc_c, out[:rows_prev])                                  # [C_k, C_prev] -> [C_prev, C_k]
+        else:
+            a_prev = a_prev.contiguous()
+            mlp.linear_fwd_(a_prev, wc_c, None, out[:rows_prev])               # A_{k-1} Wc_k^T
+        _transpose(w1_c, out[rows_prev:])                                      # [C_k, 2 C_k] -> [2 C_k, C_k]
+        ctx.has_prev = a_prev is not None
+        ctx.rows_prev = rows_prev
+        ctx.save_for_backward(a_prev if a_prev is not None else wc_c, wc_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a_prev, wc = ctx.saved_tensors
+        g = g.contiguous()
+        rp = ctx.rows_prev
+        gp, gn = g[:rp], g[rp:]
+        da = dwc = None
+        if ctx.has_prev:
+            if ctx.needs_input_grad[0]:
+                da = mlp.linear_dgrad_(gp, wc, torch.empty_like(a_prev))       # gp Wc
+            dwc = torch.empty_like(wc)
+            mlp.linear_wgrad_(gp, a_prev, dwc, None)                           # gp^T A_{k-1}
+        else:
+            dwc = torch.empty_like(wc)
+            _transpose(gp, dwc)
+        dw1 = torch.empty(gn.shape[1], gn.shape[0], dtype=torch.float32, device=g.device)
+        _transpose(gn, dw1)
+        return da, dwc, dw1
+
+
+def _transpose(src, dst):
+    """dst [n, m] = src [m, n]^T, both contiguous row-major (the [B, C, P] -> [B, P, C] layout kernel with B = 1)."""
+    m, n = src.shape
+    _lib.call("t2h_nchw_to_nhwc", _lib.ptr(src), 1, m, n, _lib.ptr(dst), _lib.stream(), nbytes=8 * m * n)
+
+
+class _MeanBias(torch.autograd.Function):
+    """raster = acc / max(count, 1) + [count > 0] * const: scatter_mean's division and empty-cell rule on the product of the
+    per-cell sums, plus the composed bias -- one launch (t2h_mean_bias_fwd) instead of three elementwise ones."""
+
+    @staticmethod
+    def forward(ctx, acc, const, cnt):
+        acc, const = acc.contiguous(), const.contiguous()
+        out = torch.empty_like(acc)
+        p, c = acc.shape
+        _lib.call("t2h_mean_bias_fwd", _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(const), p, c, _lib.ptr(out), _lib.stream(),
+                  nbytes=8 * p * c + 4 * p)
+        ctx.save_for_backward(cnt)
+        ctx.const_shape = const.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (cnt,) = ctx.saved_tensors
+        g = g.contiguous()
+        p, c = g.shape
+        dacc = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        dconst = torch.empty(ctx.const_shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        ws_bytes = _lib.load().t2h_mean_bias_bwd_workspace_bytes(p, c)
+        ws = _lib.workspace(ws_bytes, g.device)
+        _lib.call("t2h_mean_bias_bwd", _lib.ptr(g), _lib.ptr(cnt), p, c, None if dacc is None else _lib.ptr(dacc),
+                  None if dconst is None else _lib.ptr(dconst), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=8 * p * c + 4 * p)
+        return dacc, dconst, None
+
+
 # ------------------------------------------------------------------------------------------------ state
 def counts(tile, level):
-    """(1 / max(count, 1), [count > 0]) as [B r r, 1] float columns for ALTO level ``level`` (cached on the tile)."""
+    """Points per cell of ALTO level ``level`` as a [B r r] float column in plane (row-major) order, cached on the tile."""
     cache = tile.__dict__.setdefault("_cell_counts", {})
-    if not cache:
-        ones = torch.ones(tile.n_points, 4, dtype=torch.float32, device=tile.device)
-        levels = list(range(0, tile.nbits))
-        for lv, s in zip(levels, cell_sums(tile, ones, levels)):
-            cnt = s[:, :1].contiguous()                   # sums of ones: exact integers in fp32
-            cache[lv] = (1.0 / cnt.clamp_min(1.0), (cnt > 0).to(torch.float32))
+    if level not in cache:
+        r = tile.R >> level
+        cnt = torch.empty(tile.B * r * r, dtype=torch.float32, device=tile.device)
+        _lib.call("t2h_cell_counts", _lib.ptr(tile.off0), tile.B, tile.nbits, level, _lib.ptr(cnt), _lib.stream(),
+                  nbytes=12 * cnt.numel())
+        cache[level] = cnt
     return cache[level]
 
 
@@ -209,9 +287,7 @@ class Deferred:
         every later exchange (what the new source will be rasterised at)."""
         tile = self.tile
         wc, bc, w1, b1 = fc_c.weight, fc_c.bias, fc_b.weight, fc_b.bias
-        # A_{k,j} = A_{k-1,j} Wc_k^T for every earlier source at once; the base tensor enters through Wc_k itself
-        prev = wc.t().contiguous() if self.a_all is None else mlp.linear(self.a_all, wc, None)
-        self.a_all = torch.cat([prev, w1.t().contiguous()], 0)
+        self.a_all = _ComposeStack.apply(self.a_all, wc, w1)
         if self.const is None:
             self.const = (bc + b1).reshape(1, -1)
         else:
@@ -220,8 +296,7 @@ class Deferred:
         self.sums.append(dict(zip(levels, _HiddenSums.apply(q_rows, tile, r, levels))))
         lv = tile.level(r)
         acc = _SumMatmulNN.apply(self.a_all, *[s[lv] for s in self.sums])
-        inv_cnt, nonempty = counts(tile, lv)
-        return acc * inv_cnt + nonempty * self.const      # scatter_mean: mean over the cell, 0 for an empty cell
+        return _MeanBias.apply(acc, self.const, counts(tile, lv))             # scatter_mean: mean per cell, 0 if empty
 
 
 def applicable(tile, r: int, c: int) -> bool:
