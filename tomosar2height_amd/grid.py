@@ -174,13 +174,27 @@ class _Conv3x3(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+OVERLAP_MAX_PIXELS = int(os.environ.get("T2H_OVERLAP_CONV_MAX_PIXELS", str(128 * 128)))
+
+
 def _conv3x3_param_grads(gm, x, weight, bias):
     """Weight / bias gradient of one conv3x3: straight into the existing ``.grad`` buffers (the trainer's bucket) under
     ``mlp.direct_grad_accumulation`` -- returns (None, None) then -- else as fresh tensors."""
     wg, bg = weight.grad, (bias.grad if bias is not None else None)
     if (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
             and (bias is None or (bg is not None and bg.is_contiguous()))):
-        conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
+        side = mlp._CONV_WGRAD_STREAM
+        if side is not None and x.shape[2] * x.shape[3] <= OVERLAP_MAX_PIXELS:
+            # small planes: the weight gradient (off the backward's critical path: nothing reads the bucket before the
+            # optimizer step) runs on a side stream beside the next layers' data gradients -- these launches are
+            # latency-bound and leave most CUs idle; the trainer joins the stream at the end of the tile
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
+            gm.record_stream(side)
+            x.record_stream(side)
+        else:
+            conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
         return None, None
     dw = torch.empty_like(weight, memory_format=torch.channels_last)
     db = torch.empty_like(bias) if bias is not None else None

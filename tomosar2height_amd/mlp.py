@@ -109,6 +109,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
 
 _DIRECT_ACCUM = False
 _WGRAD_STREAM = None
+_CONV_WGRAD_STREAM = None        # side stream for the small-plane convolution weight gradients (grid._conv3x3_param_grads)
 
 
 class direct_grad_accumulation:
@@ -117,23 +118,27 @@ class direct_grad_accumulation:
     ``None`` for them -- this removes one elementwise add launch per parameter per tile.  Off by default so that
     ``torch.autograd.grad`` and first-touch (``grad is None``) semantics stay the standard ones."""
 
-    def __init__(self, enabled: bool = True, side_stream=None):
+    def __init__(self, enabled: bool = True, side_stream=None, conv_side_stream=None):
         """``side_stream``: issue the accumulating weight-gradient GEMMs there.  They are off the backward's critical
         path (nothing reads the bucket before the optimizer step), so they fill the GPU while small-grid conv kernels
-        run on the main stream.  The caller joins the stream before touching the gradients."""
+        run on the main stream.  ``conv_side_stream``: the same for the weight gradients of convolutions on small planes.
+        The caller joins the streams before touching the gradients."""
         self.enabled = enabled
         self.side_stream = side_stream if enabled else None
+        self.conv_side_stream = conv_side_stream if enabled else None
 
     def __enter__(self):
-        global _DIRECT_ACCUM, _WGRAD_STREAM
+        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM
         self.prev, _DIRECT_ACCUM = _DIRECT_ACCUM, self.enabled
         self.prev_stream, _WGRAD_STREAM = _WGRAD_STREAM, self.side_stream
+        self.prev_conv_stream, _CONV_WGRAD_STREAM = _CONV_WGRAD_STREAM, self.conv_side_stream
         return self
 
     def __exit__(self, *exc):
-        global _DIRECT_ACCUM, _WGRAD_STREAM
+        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM
         _DIRECT_ACCUM = self.prev
         _WGRAD_STREAM = self.prev_stream
+        _CONV_WGRAD_STREAM = self.prev_conv_stream
 
 
 def _wgrad(dy, x, w, bias, relu_in=False):

@@ -94,6 +94,10 @@ class Trainer:
         # those of kernels running alone
         self.overlap_wgrad = os.environ.get("T2H_OVERLAP_WGRAD", "0") == "1"
         self._side = None
+        # the weight gradients of the convolutions on planes up to 128 x 128 (latency-bound launches that leave most CUs idle)
+        # beside the following layers' data gradients: T2H_OVERLAP_CONV_WGRAD=1
+        self.overlap_conv_wgrad = os.environ.get("T2H_OVERLAP_CONV_WGRAD", "0") == "1"
+        self._conv_side = None
 
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
@@ -174,12 +178,18 @@ class Trainer:
                 if self._side is None:
                     self._side = torch.cuda.Stream(device=loss.device)
                 side = self._side
-            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation, side):
+            conv_side = None
+            if self.overlap_conv_wgrad and self.bucket is not None and loss.is_cuda:
+                if self._conv_side is None:
+                    self._conv_side = torch.cuda.Stream(device=loss.device)
+                conv_side = self._conv_side
+            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation, side, conv_side):
                 loss.backward()
-            if side is not None:
-                # join: the overlap is with this tile's own conv backward; afterwards the gradients are visible in
-                # stream order on the current stream like any other result
-                torch.cuda.current_stream().wait_stream(side)
+            for st in (side, conv_side):
+                if st is not None:
+                    # join: the overlap is with this tile's own backward; afterwards the gradients are visible in
+                    # stream order on the current stream like any other result
+                    torch.cuda.current_stream().wait_stream(st)
         if self.bucket is None:
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
             # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
