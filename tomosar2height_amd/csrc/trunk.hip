@@ -47,6 +47,7 @@ struct TrunkFwdArgs {
     float *out; int ld_out;
     uint8_t *winner;     // [M, 8]: arg-max bits of net_prev's pooling (later blocks)
     float *c_out;        // [M, 32] (last block)
+    int loader;          // 1 = r02 loader (per-cell head loop), else the r03 ballot / per-row form (T2H_TRUNK_LOADER, A/B)
 };
 
 __device__ inline float clean(float x) { return x != x ? -FLT_MAX : x; }
@@ -167,6 +168,123 @@ __device__ inline void pool_into_tile(const TrunkFwdArgs &a, float *Xs, float *s
     __syncthreads();
 }
 
+// r03 loader: the same segmented max without the per-row `cell -> off0` hops, without the serial per-cell head loop and without
+// the broadcast phase.  The cell ids of the tile's rows go to LDS; a wave ballot over "this row starts a cell" gives two 64-bit
+// head masks, from which every row derives its cell's in-tile range with two bit scans (clz / ctz); then EVERY row reduces its
+// own cell over the LDS rows in ascending order -- the same strict '>' scan the head row ran, so all rows of a cell arrive at the
+// same maximum and arg-max, and each writes its pooled half and winner bits itself.  A cell of L rows costs L^2 LDS row reads
+// instead of L, but they run in parallel over the rows (the head loop serialised the workgroup on its longest cell), and
+// typical cells hold 2-3 rows.  Only the two border cells still need `off0` (their rows outside the tile, streamed as before).
+__device__ inline int mask_prev_head(unsigned long long m0, unsigned long long m1, int me) {     // last head <= me
+    if (me < 64) return 63 - __clzll(m0 & (me == 63 ? ~0ull : ((2ull << me) - 1ull)));
+    const unsigned long long b1 = m1 & (me == 127 ? ~0ull : ((2ull << (me - 64)) - 1ull));
+    return b1 ? 127 - __clzll(b1) : 63 - __clzll(m0);
+}
+__device__ inline int mask_next_head(unsigned long long m0, unsigned long long m1, int me) {     // first head > me, or TR
+    if (me < 64) {
+        const unsigned long long rest = me == 63 ? 0ull : (m0 >> (me + 1));
+        if (rest) return me + 1 + __ffsll((long long)rest) - 1;
+        return m1 ? 64 + __ffsll((long long)m1) - 1 : TR;
+    }
+    const unsigned long long rest = me == 127 ? 0ull : (m1 >> (me - 64 + 1));
+    return rest ? me + 1 + __ffsll((long long)rest) - 1 : TR;
+}
+
+__device__ inline void pool_into_tile_v2(const TrunkFwdArgs &a, float *Xs, float *scratch, int r0, int r1, int tid) {
+    float4 *pval = reinterpret_cast<float4 *>(scratch);                   // [NG * G]
+    int4 *parg = reinterpret_cast<int4 *>(scratch + 4 * NG * G);          // [NG * G]
+    float4 *oval = reinterpret_cast<float4 *>(scratch + 8 * NG * G);      // [2 * G]
+    int4 *oarg = reinterpret_cast<int4 *>(scratch + 8 * NG * G + 8 * G);  // [2 * G]
+    int *bounds = reinterpret_cast<int *>(scratch + 8 * NG * G + 16 * G); // [4]
+    int *cells = bounds + 4;                                              // [TR]
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(cells + TR);     // [2] (8-byte aligned: 2308 floats in)
+    const int lane = tid & (G - 1), grp = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int me = p * NG + grp, row = r0 + me;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cid = -1 - me;                                                // rows past the end: one-row cells of their own
+        if (row < r1) {
+            cid = a.cell[row];
+            v = *reinterpret_cast<const float4 *>(a.net_prev + (size_t)row * a.ld_prev + lane * 4);
+        }
+        *reinterpret_cast<float4 *>(Xs + me * XS + lane * 4) = v;
+        if (lane == 0) cells[me] = cid;
+    }
+    if (tid == 0) {
+        const int ch = a.cell[r0], ct = a.cell[r1 - 1];
+        bounds[0] = a.off0[ch]; bounds[1] = a.off0[ch + 1]; bounds[2] = a.off0[ct]; bounds[3] = a.off0[ct + 1];
+    }
+    __syncthreads();
+    if (tid < TR) {                                                       // waves 0 and 1, all lanes: row = tid
+        const bool head = tid == 0 || cells[tid] != cells[tid - 1];
+        const unsigned long long m = __ballot(head);
+        if ((tid & 63) == 0) masks[tid >> 6] = m;
+    }
+    __syncthreads();
+    // rows of the border cells that lie outside the tile: [bounds[0], r0) and [r1, bounds[3])
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int lo = side == 0 ? bounds[0] : r1, hi = side == 0 ? r0 : bounds[3];
+        if (hi <= lo) continue;                                           // uniform over the workgroup
+        Best b; best_init(b);
+        for (int n = lo + grp; n < hi; n += NG)
+            best_strict(b, *reinterpret_cast<const float4 *>(a.net_prev + (size_t)n * a.ld_prev + lane * 4), n);
+        pval[grp * G + lane] = b.v; parg[grp * G + lane] = b.a;
+        __syncthreads();
+        if (grp == 0) {
+            Best t; t.v = pval[lane]; t.a = parg[lane];
+            const int used = min(NG, hi - lo);                            // groups past the run's length hold empty partials
+            for (int g = 1; g < used; ++g) {
+                const float4 v = pval[g * G + lane]; const int4 ar = parg[g * G + lane];
+                best_merge(t.v.x, t.a.x, v.x, ar.x); best_merge(t.v.y, t.a.y, v.y, ar.y);
+                best_merge(t.v.z, t.a.z, v.z, ar.z); best_merge(t.v.w, t.a.w, v.w, ar.w);
+            }
+            oval[side * G + lane] = t.v; oarg[side * G + lane] = t.a;
+        }
+        __syncthreads();
+    }
+    const unsigned long long m0 = masks[0], m1 = masks[1];
+    const int rows = r1 - r0;
+    const bool before = bounds[0] < r0, after = bounds[3] > r1;
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int me = p * NG + grp, row = r0 + me;
+        if (row >= r1) {
+            *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int s = mask_prev_head(m0, m1, me), e = mask_next_head(m0, m1, me);       // the cell's rows inside the tile
+        Best b; best_init(b);
+        if (s == 0 && before) {                                           // earlier rows win ties
+            const int4 ar = oarg[lane];
+            b.v = oval[lane];
+            b.a = make_int4(ar.x < 0 ? -1 : -2, ar.y < 0 ? -1 : -2, ar.z < 0 ? -1 : -2, ar.w < 0 ? -1 : -2);
+        }
+        int n = s;
+        for (; n + 3 < e; n += 4) {                                       // four LDS rows in flight
+            const float *xp = Xs + n * XS + lane * 4;
+            const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + XS);
+            const float4 v2 = *reinterpret_cast<const float4 *>(xp + 2 * XS), v3 = *reinterpret_cast<const float4 *>(xp + 3 * XS);
+            best_strict(b, v0, n); best_strict(b, v1, n + 1); best_strict(b, v2, n + 2); best_strict(b, v3, n + 3);
+        }
+        for (; n < e; ++n) best_strict(b, *reinterpret_cast<const float4 *>(Xs + n * XS + lane * 4), n);
+        if (e == rows && after) {                                         // later rows: only a larger value wins
+            const float4 v = oval[G + lane];
+            if (v.x > b.v.x) { b.v.x = v.x; b.a.x = -2; }
+            if (v.y > b.v.y) { b.v.y = v.y; b.a.y = -2; }
+            if (v.z > b.v.z) { b.v.z = v.z; b.a.z = -2; }
+            if (v.w > b.v.w) { b.v.w = v.w; b.a.w = -2; }
+        }
+        // untouched (all NaN) -> 0, as torch_scatter's fill of cells that no value entered.  Only the left halves of the tile
+        // are read above and only right halves written here, so no barrier separates the two
+        *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) =
+            make_float4(b.a.x == -1 ? 0.f : b.v.x, b.a.y == -1 ? 0.f : b.v.y, b.a.z == -1 ? 0.f : b.v.z, b.a.w == -1 ? 0.f : b.v.w);
+        a.winner[(size_t)row * G + lane] = (uint8_t)((b.a.x == me) | ((b.a.y == me) << 1) | ((b.a.z == me) << 2) | ((b.a.w == me) << 3));
+    }
+    __syncthreads();
+}
+
 // 32 rows x 32 columns x K of  A[m][k] * B[n][k]  with both operands row-major in LDS (strides SA, SB); RELU_A applies
 // max(., 0) to A.  pa / pb already point at this lane's row and k offset 4 * (lane >> 5).
 template <int K, bool RELU_A>
@@ -281,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
         }
         __syncthreads();
     } else {
-        pool_into_tile(a, Xs, Hsm, r0, r1, tid);
+        if (a.loader == 1) pool_into_tile(a, Xs, Hsm, r0, r1, tid);
+        else pool_into_tile_v2(a, Xs, Hsm, r0, r1, tid);
     }
     // copy-outs: every wave copies ITS OWN 32 rows (the rows its GEMMs read and, in the LAST variant, later overwrite with
     // relu(out)), so no other wave ever reads rows that their owner may already be rewriting
@@ -795,6 +914,8 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     a.net_prev = net_prev; a.ld_prev = ld_prev; a.cell = cell; a.off0 = off0;
     a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.ws = ws; a.wc = wc; a.bc = bc;
     a.M = (int)M; a.x_full = x_full; a.pooled = pooled; a.hr = hr; a.out = out; a.ld_out = ld_out; a.winner = winner; a.c_out = c_out;
+    static const int loader = getenv("T2H_TRUNK_LOADER") ? atoi(getenv("T2H_TRUNK_LOADER")) : 2;
+    a.loader = loader;
     const int64_t n_tiles = (M + TR - 1) / TR;
     const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));      // two resident per CU, each walks its tiles
     hipStream_t s = as_stream(stream);
