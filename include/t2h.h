@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 5
+#define T2H_ABI_VERSION 6
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -134,10 +134,14 @@ int t2h_segmean_bwd(const float *gplane_nhwc, const int32_t *cell, const int32_t
  *   scatter_mean(c_k) = ( sum_j cellsum_r(h_j) A_{k,j}^T ) / count + const_k        (A_{k,j} = Wc_k .. Wc_{j+1} W1_j)
  * is formed on the r^2 pixels from per-cell sums of the hidden activations and c_k itself is never computed on the N points. */
 int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
-                   float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
-int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream);
-int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B, int N,
-                         int nbits, int C, const float *mask, const float *addend, float *gfeat, t2h_stream_t stream);
+                   float *plane_nhwc, int ld_plane, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+int t2h_plane_sumpool2x2(const float *fine_nhwc, int ld_fine, int B, int r_fine, int C, float *coarse_nhwc, int ld_coarse,
+                         t2h_stream_t stream);
+int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes, const int32_t *cell,
+                         int B, int N, int nbits, int C, const float *mask, const float *addend, float *gfeat,
+                         t2h_stream_t stream);
+/* Row strides (`ld_*`, in floats, >= C): a plane may be a COLUMN BLOCK of a wider [B r r, K] matrix -- the per-cell sums of all
+ * sources of the deferred form sit side by side per resolution, so that scatter_mean(c_k) is ONE product over K = sum K_j. */
 /* Grid-side glue of the deferred form (csrc/deferred.hip): the points-per-cell plane [B, r, r] (float, row-major) of an ALTO
  * level from the tile CSR; scatter_mean's division / empty-cell rule / composed bias applied to a product of per-cell sums,
  *   raster[p, :] = acc[p, :] / max(cnt[p], 1) + [cnt[p] > 0] * cvec[:]                       (alto.py:76-88: count clamped to 1),
@@ -151,9 +155,9 @@ int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float 
 /* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */
-int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell,
-                             const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
-                             int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
+int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
+                             const int32_t *cell, const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N,
+                             int nbits, int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                              t2h_stream_t stream);
 /* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
  * rasterisation and the next level's fc_c (alto.py:123-130), so their gradient is a sum of two -- formed here instead of

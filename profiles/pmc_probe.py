@@ -30,11 +30,13 @@ for _ in range(REPS):
 # r03: the deferred point update's scatter-reduce pair on the widest hidden tensor (N x 1024), finest resolution
 from tomosar2height_amd import deferred                      # noqa: E402
 x1024 = torch.randn(M, 1024, device=dev)
-planes = None
+planes = {lv: torch.empty((256 >> lv) ** 2, 1024, device=dev) for lv in range(4)}
 for _ in range(REPS):
-    planes = deferred.cell_sums(tile, x1024, [0, 1, 2, 3])    # segmean_fwd_kernel<4, false> + 3 x plane_sumpool2x2_kernel
-grads = [torch.randn_like(p) for p in planes]
+    deferred._segsum_into(tile, x1024, 0, planes[0])          # segmean_fwd_kernel<4, false>
+    for lv in range(3):
+        deferred._sumpool_into(tile, planes[lv], lv, planes[lv + 1])      # plane_sumpool2x2_kernel
+grads = [(torch.randn_like(p), lv) for lv, p in planes.items()]
 for _ in range(REPS):
-    deferred._gather(tile, grads, (0, 1, 2, 3), 1024, mask=x1024)      # segsum_bwd_multi_kernel<4>
+    deferred._gather(tile, grads, 1024, mask=x1024)          # segsum_bwd_multi_kernel<4>
 torch.cuda.synchronize()
 print("pmc_probe done")

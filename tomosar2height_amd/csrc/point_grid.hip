@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void pool_rows_bwd_kernel(const float *__restr
 template <int VEC, bool MEAN = true>
 __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__restrict__ feat,
                                                                const int32_t *__restrict__ off0, int B, int nbits,
-                                                               int level, int C, int lg, float *__restrict__ plane) {
+                                                               int level, int C, int lg, float *__restrict__ plane,
+                                                               int ld_out) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t gid = t >> lg;
     const int rbits = nbits - level;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__re
     int s = off0[obase], e = off0[obase + ((size_t)1 << (2 * level))];
     int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
     int r = 1 << rbits;
-    float *orow = plane + (((size_t)b * r + cy) * r + cx) * C;
+    float *orow = plane + (((size_t)b * r + cy) * r + cx) * ld_out;     // ld_out >= C: a column block of a wider matrix
     float inv_den = (float)(e - s > 0 ? e - s : 1);
     int span = VEC << lg;
     for (int c = ((int)t & ((1 << lg) - 1)) * VEC; c < C; c += span) {
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kThreads) void segmean_fwd_kernel(const float *__re
 // Gradient of per-cell sums taken at several (<= 8) resolutions of the same rows (t2h_segsum_bwd_multi): one group per point,
 // gfeat[n] = (mask[n] > 0 ?) sum_l gplane_l[cell_l(n)] (+ addend[n]); planes in the order given (a fixed summation order).
 constexpr int kMaxMultiPlanes = 8;
-struct MultiPlanes { const float *g[kMaxMultiPlanes]; int level[kMaxMultiPlanes]; int n; };
+struct MultiPlanes { const float *g[kMaxMultiPlanes]; int level[kMaxMultiPlanes]; int ld[kMaxMultiPlanes]; int n; };
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes mp, const int32_t *__restrict__ cell,
                                                                     int64_t npts, int nbits, int C, int lg,
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes 
         rows[q] = nullptr;
         if (q < mp.n) {
             const int l = mp.level[q], r = 1 << (nbits - l);
-            rows[q] = mp.g[q] + (((size_t)b * r + (y0 >> l)) * r + (x0 >> l)) * C;
+            rows[q] = mp.g[q] + (((size_t)b * r + (y0 >> l)) * r + (x0 >> l)) * mp.ld[q];
         }
     }
     const int span = VEC << lg;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void segsum_bwd_multi_kernel(MultiPlanes 
 // coarse[b, y, x, :] = fine[b, 2y, 2x, :] + fine[b, 2y, 2x+1, :] + fine[b, 2y+1, 2x, :] + fine[b, 2y+1, 2x+1, :]  (NHWC, float4 lanes):
 // the per-cell sums of resolution r / 2 from those of resolution r (a cell is the union of its four children)
 __global__ __launch_bounds__(kThreads) void plane_sumpool2x2_kernel(const float *__restrict__ fine, int64_t total4, int rc,
-                                                                   int C4, float *__restrict__ coarse) {
+                                                                   int C4, int ld_in, int ld_out, float *__restrict__ coarse) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (t >= total4) return;
     const int c4 = (int)(t % C4);
@@ -479,12 +480,14 @@ __global__ __launch_bounds__(kThreads) void plane_sumpool2x2_kernel(const float 
     const int x = (int)(pix % rc), y = (int)((pix / rc) % rc);
     const int64_t b = pix / ((int64_t)rc * rc);
     const int rf = 2 * rc;
-    const float4 *f = reinterpret_cast<const float4 *>(fine) + ((b * rf + 2 * y) * rf + 2 * x) * (int64_t)C4 + c4;
-    const float4 a = f[0], bq = f[C4], cq = f[(int64_t)rf * C4], d = f[(int64_t)rf * C4 + C4];
+    const float *f = fine + ((b * rf + 2 * y) * rf + 2 * x) * (int64_t)ld_in + 4 * c4;
+    const float4 a = *reinterpret_cast<const float4 *>(f), bq = *reinterpret_cast<const float4 *>(f + ld_in);
+    const float4 cq = *reinterpret_cast<const float4 *>(f + (int64_t)rf * ld_in);
+    const float4 d = *reinterpret_cast<const float4 *>(f + (int64_t)rf * ld_in + ld_in);
     float4 o;
     o.x = (a.x + bq.x) + (cq.x + d.x); o.y = (a.y + bq.y) + (cq.y + d.y);
     o.z = (a.z + bq.z) + (cq.z + d.z); o.w = (a.w + bq.w) + (cq.w + d.w);
-    reinterpret_cast<float4 *>(coarse)[t] = o;
+    *reinterpret_cast<float4 *>(coarse + pix * (int64_t)ld_out + 4 * c4) = o;
 }
 
 // One group per point: gfeat[n] = gplane[cell_k(n)] / count.
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(kCellThreads) void segmean_cells_kernel(const float
 __global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float *__restrict__ partial,
                                                                    const int32_t *__restrict__ off0, int B, int nbits,
                                                                    int level, int C, int lg, int S,
-                                                                   float *__restrict__ plane, int mean = 1) {
+                                                                   float *__restrict__ plane, int mean = 1, int ld_out = 0) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t gid = t >> lg;
     const int rbits = nbits - level;
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(kThreads) void segmean_finalize_kernel(const float 
     int cnt = off0[obase + ((size_t)1 << (2 * level))] - off0[obase];
     float den = (float)(cnt > 0 ? cnt : 1);
     int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1), r = 1 << rbits;
-    float *orow = plane + (((size_t)b * r + cy) * r + cx) * C;
+    float *orow = plane + (((size_t)b * r + cy) * r + cx) * (ld_out > 0 ? ld_out : C);
     for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int sp = 0; sp < S; ++sp) {
@@ -978,7 +981,7 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
                 for (int q = 0; q < kMaxMultiPlanes; ++q)
                     if (q < mp.n) {
                         const int l = mp.level[q], rq = 1 << (nbits - l);
-                        const float4 u = *reinterpret_cast<const float4 *>(mp.g[q] + (((size_t)fb * rq + (fy >> l)) * rq + (fx >> l)) * C + c);
+                        const float4 u = *reinterpret_cast<const float4 *>(mp.g[q] + (((size_t)fb * rq + (fy >> l)) * rq + (fx >> l)) * mp.ld[q] + c);
                         if (q == 0) g = u;
                         else { g.x = __fadd_rn(g.x, u.x); g.y = __fadd_rn(g.y, u.y); g.z = __fadd_rn(g.z, u.z); g.w = __fadd_rn(g.w, u.w); }
                     }
@@ -1131,11 +1134,11 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                     a[u] = Wl[rr][lane & 15];
                     if (FUSED) {
                         const float4 hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + ch);
-                        float4 v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * C + ch);
+                        float4 v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * mp.ld[0] + ch);
 #pragma unroll
                         for (int q = 1; q < kMaxMultiPlanes; ++q)
                             if (q < mp.n) {
-                                const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * C + ch);
+                                const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * mp.ld[q] + ch);
                                 v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
                             }
                         v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
@@ -1385,8 +1388,9 @@ T2H_API int t2h_pool_rows_bwd(const float *gpooled, int ldg, const uint8_t *winn
 }
 
 static int segreduce_fwd(bool mean, const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
-                         float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+                         float *plane_nhwc, int ld_out, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!feat || !off0 || !plane_nhwc) return fail(T2H_ERR_ARG, "segmean_fwd: null pointer");
+    if (ld_out < C || (C % 4 == 0 && ld_out % 4 != 0)) return fail(T2H_ERR_ARG, "segmean_fwd: plane row stride %d < C = %d", ld_out, C);
     int rc = check_level("segmean_fwd", B, nbits, level, C);
     if (rc) return rc;
     int64_t groups = (int64_t)B << (2 * (nbits - level));
@@ -1402,54 +1406,56 @@ static int segreduce_fwd(bool mean, const float *feat, const int32_t *off0, int 
                            partial);
         GroupCfg g = group_cfg<4>(C);
         hipLaunchKernelGGL(segmean_finalize_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                           partial, off0, B, nbits, level, C, g.lg, cp.S, plane_nhwc, mean ? 1 : 0);
+                           partial, off0, B, nbits, level, C, g.lg, cp.S, plane_nhwc, mean ? 1 : 0, ld_out);
         return check_launch("segmean_fwd(coarse)");
     }
     if (mean) {
         T2H_DISPATCH_VEC(C,
             { GroupCfg g = group_cfg<4>(C);
               hipLaunchKernelGGL(segmean_fwd_kernel<4>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc, ld_out); },
             { GroupCfg g = group_cfg<1>(C);
               hipLaunchKernelGGL(segmean_fwd_kernel<1>, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc, ld_out); });
     } else {
         T2H_DISPATCH_VEC(C,
             { GroupCfg g = group_cfg<4>(C);
               hipLaunchKernelGGL((segmean_fwd_kernel<4, false>), dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); },
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc, ld_out); },
             { GroupCfg g = group_cfg<1>(C);
               hipLaunchKernelGGL((segmean_fwd_kernel<1, false>), dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc); });
+                                 feat, off0, B, nbits, level, C, g.lg, plane_nhwc, ld_out); });
     }
     return check_launch("segmean_fwd");
 }
 
 T2H_API int t2h_segmean_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
                             float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
-    return segreduce_fwd(true, feat, off0, B, N, nbits, level, C, plane_nhwc, workspace, workspace_bytes, stream);
+    return segreduce_fwd(true, feat, off0, B, N, nbits, level, C, plane_nhwc, C, workspace, workspace_bytes, stream);
 }
 
 T2H_API int t2h_segsum_fwd(const float *feat, const int32_t *off0, int B, int N, int nbits, int level, int C,
-                           float *plane_nhwc, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
-    return segreduce_fwd(false, feat, off0, B, N, nbits, level, C, plane_nhwc, workspace, workspace_bytes, stream);
+                           float *plane_nhwc, int ld_plane, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    return segreduce_fwd(false, feat, off0, B, N, nbits, level, C, plane_nhwc, ld_plane, workspace, workspace_bytes, stream);
 }
 
-T2H_API int t2h_plane_sumpool2x2(const float *fine_nhwc, int B, int r_fine, int C, float *coarse_nhwc, t2h_stream_t stream) {
+T2H_API int t2h_plane_sumpool2x2(const float *fine_nhwc, int ld_fine, int B, int r_fine, int C, float *coarse_nhwc, int ld_coarse,
+                                 t2h_stream_t stream) {
     if (!fine_nhwc || !coarse_nhwc) return fail(T2H_ERR_ARG, "plane_sumpool2x2: null pointer");
-    if (B < 1 || r_fine < 2 || (r_fine & 1) || C < 4 || C % 4 != 0 || ((uintptr_t)fine_nhwc & 15) || ((uintptr_t)coarse_nhwc & 15))
-        return fail(T2H_ERR_ARG, "plane_sumpool2x2: needs an even resolution, C %% 4 == 0 and 16-byte aligned planes");
+    if (B < 1 || r_fine < 2 || (r_fine & 1) || C < 4 || C % 4 != 0 || ((uintptr_t)fine_nhwc & 15) || ((uintptr_t)coarse_nhwc & 15) ||
+        ld_fine < C || ld_coarse < C || ld_fine % 4 != 0 || ld_coarse % 4 != 0)
+        return fail(T2H_ERR_ARG, "plane_sumpool2x2: needs an even resolution, C %% 4 == 0, row strides >= C and 16-byte aligned rows");
     const int rc = r_fine / 2;
     const int64_t total4 = (int64_t)B * rc * rc * (C / 4);
     hipLaunchKernelGGL(plane_sumpool2x2_kernel, dim3((unsigned)((total4 + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       as_stream(stream), fine_nhwc, total4, rc, C / 4, coarse_nhwc);
+                       as_stream(stream), fine_nhwc, total4, rc, C / 4, ld_fine, ld_coarse, coarse_nhwc);
     return check_launch("plane_sumpool2x2");
 }
 
-T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell, int B,
-                                 int N, int nbits, int C, const float *mask, const float *addend, float *gfeat,
-                                 t2h_stream_t stream) {
-    if (!gplanes_nhwc || !levels || !cell || !gfeat) return fail(T2H_ERR_ARG, "segsum_bwd_multi: null pointer");
+T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
+                                 const int32_t *cell, int B, int N, int nbits, int C, const float *mask, const float *addend,
+                                 float *gfeat, t2h_stream_t stream) {
+    if (!gplanes_nhwc || !levels || !lds || !cell || !gfeat) return fail(T2H_ERR_ARG, "segsum_bwd_multi: null pointer");
     if (n_planes < 1 || n_planes > kMaxMultiPlanes)
         return fail(T2H_ERR_ARG, "segsum_bwd_multi: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
     if (B < 1 || N < 0 || nbits < 1 || nbits > T2H_MAX_NBITS || C < 1) return fail(T2H_ERR_ARG, "segsum_bwd_multi: unsupported shape");
@@ -1457,8 +1463,9 @@ T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *le
     mp.n = n_planes;
     for (int q = 0; q < n_planes; ++q) {
         if (!gplanes_nhwc[q] || levels[q] < 0 || levels[q] > nbits) return fail(T2H_ERR_ARG, "segsum_bwd_multi: bad plane %d", q);
-        if (C % 4 == 0 && ((uintptr_t)gplanes_nhwc[q] & 15)) return fail(T2H_ERR_ARG, "segsum_bwd_multi: planes must be 16-byte aligned");
-        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q];
+        if (C % 4 == 0 && (((uintptr_t)gplanes_nhwc[q] & 15) || lds[q] % 4 != 0)) return fail(T2H_ERR_ARG, "segsum_bwd_multi: planes must be 16-byte aligned");
+        if (lds[q] < C) return fail(T2H_ERR_ARG, "segsum_bwd_multi: plane %d row stride %d < C", q, lds[q]);
+        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q]; mp.ld[q] = lds[q];
     }
     if (C % 4 == 0 && ((mask && ((uintptr_t)mask & 15)) || (addend && ((uintptr_t)addend & 15)) || ((uintptr_t)gfeat & 15)))
         return fail(T2H_ERR_ARG, "segsum_bwd_multi: rows must be 16-byte aligned");
@@ -1514,11 +1521,11 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
     return check_launch("sample_fwd");
 }
 
-T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, int n_planes, const int32_t *cell,
-                                     const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
+                                     const int32_t *cell, const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                                      int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                                      t2h_stream_t stream) {
-    if (!gplanes_nhwc || !levels || !cell || !mask || !pts || !off0 || !gplane_nhwc)
+    if (!gplanes_nhwc || !levels || !lds || !cell || !mask || !pts || !off0 || !gplane_nhwc)
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: null pointer");
     if (n_planes < 1 || n_planes > kMaxMultiPlanes)
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
@@ -1535,9 +1542,9 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     MultiPlanes mp{};
     mp.n = n_planes;
     for (int q = 0; q < n_planes; ++q) {
-        if (!gplanes_nhwc[q] || levels[q] < 0 || levels[q] > nbits || ((uintptr_t)gplanes_nhwc[q] & 15))
+        if (!gplanes_nhwc[q] || levels[q] < 0 || levels[q] > nbits || ((uintptr_t)gplanes_nhwc[q] & 15) || lds[q] < C || lds[q] % 4)
             return fail(T2H_ERR_ARG, "sample_bwd_from_sums: bad plane %d", q);
-        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q];
+        mp.g[q] = gplanes_nhwc[q]; mp.level[q] = levels[q]; mp.ld[q] = lds[q];
     }
     int64_t groups = (int64_t)B << (2 * (nbits - level));
     float *partial = static_cast<float *>(workspace);

@@ -914,7 +914,9 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     a.net_prev = net_prev; a.ld_prev = ld_prev; a.cell = cell; a.off0 = off0;
     a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.ws = ws; a.wc = wc; a.bc = bc;
     a.M = (int)M; a.x_full = x_full; a.pooled = pooled; a.hr = hr; a.out = out; a.ld_out = ld_out; a.winner = winner; a.c_out = c_out;
-    static const int loader = getenv("T2H_TRUNK_LOADER") ? atoi(getenv("T2H_TRUNK_LOADER")) : 2;
+    // r03 A/B (N = 131072, middle block): r02 loader 47.1 us, ballot / per-row loader 50.5 us -- the loader's dependent hops were
+    // not what bounds the kernel (two workgroups of 80 KB LDS per CU run their phases nearly in sequence); the r02 form stays
+    static const int loader = getenv("T2H_TRUNK_LOADER") ? atoi(getenv("T2H_TRUNK_LOADER")) : 1;
     a.loader = loader;
     const int64_t n_tiles = (M + TR - 1) / TR;
     const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));      // two resident per CU, each walks its tiles

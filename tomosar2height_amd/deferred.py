@@ -34,150 +34,62 @@ FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
-def _segsum(tile, rows, level):
-    """[N, C] rows -> [B r r, C] per-cell sums at ALTO level ``level`` (r = R >> level)."""
+# Data layout: per resolution ONE matrix S_lv [B r r, K_total] whose column blocks are the per-cell sums of the sources in the
+# order they appear (base features, h of the first deferred level, h of the second, ...).  A level's scatter_mean is then a single
+# product over the leading K_k columns (all sources that exist at that level), its backward a single product into the gradient
+# matrix dS_lv of the same layout, and a source's kernels address "their" block through a row stride.
+def _segsum_into(tile, rows, level, dst):
+    """Per-cell sums of ``rows`` [N, C] at ALTO level ``level`` into the [B r r, C] column block ``dst`` (row stride dst.stride(0))."""
     n, c = rows.shape
     r = tile.R >> level
-    plane = torch.empty(tile.B * r * r, c, dtype=torch.float32, device=rows.device)
     ws_bytes = _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
     ws = _lib.workspace(ws_bytes, rows.device)
-    _lib.call("t2h_segsum_fwd", _lib.ptr(rows), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c, _lib.ptr(plane),
-              _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(),
+    _lib.call("t2h_segsum_fwd", _lib.ptr(rows), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c, dst.data_ptr(),
+              dst.stride(0), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * c * tile.B * r * r,
               tag=f"t2h_segsum_fwd[C={c},r={r}]")
-    return plane
 
 
-def _sumpool(tile, fine, level_fine):
-    """per-cell sums at level ``level_fine`` -> level_fine + 1 (half the resolution)."""
+def _sumpool_into(tile, fine, level_fine, coarse):
+    """Sums at ``level_fine`` (column block ``fine``) -> level_fine + 1 (column block ``coarse``): a cell is the union of its four
+    children."""
     c = fine.shape[1]
     r = tile.R >> level_fine
-    coarse = torch.empty(tile.B * (r // 2) * (r // 2), c, dtype=torch.float32, device=fine.device)
-    _lib.call("t2h_plane_sumpool2x2", _lib.ptr(fine), tile.B, r, c, _lib.ptr(coarse), _lib.stream(),
-              nbytes=4 * (fine.numel() + coarse.numel()), tag=f"t2h_plane_sumpool2x2[C={c}]")
-    return coarse
+    _lib.call("t2h_plane_sumpool2x2", fine.data_ptr(), fine.stride(0), tile.B, r, c, coarse.data_ptr(), coarse.stride(0),
+              _lib.stream(), nbytes=5 * c * tile.B * r * r, tag=f"t2h_plane_sumpool2x2[C={c}]")
 
 
-def cell_sums(tile, rows, levels):
-    """Per-cell sums of ``rows`` at every ALTO level in ``levels`` (ascending = finest first): the finest from the rows, the
-    others by 2x2 pooling (a cell is the union of its four children) -- the rows are read once."""
-    out = {}
-    cur, cur_level = _segsum(tile, rows, levels[0]), levels[0]
-    out[cur_level] = cur
-    for lv in levels[1:]:
-        while cur_level < lv:
-            cur, cur_level = _sumpool(tile, cur, cur_level), cur_level + 1
-        out[lv] = cur
-    return [out[lv] for lv in levels]
-
-
-def _gather(tile, grads, levels, c, mask=None):
-    """d rows [N, C] = (mask > 0 ?) sum over the given levels of gplane_l[cell_l(n)]  (adjoint of ``cell_sums``)."""
-    planes = [(g.contiguous(), lv) for g, lv in zip(grads, levels) if g is not None]
-    out = torch.empty(tile.n_points, c, dtype=torch.float32, device=tile.device)
-    if not planes:
-        return out.zero_()
+def _plane_args(planes):
+    """ctypes arrays (pointers, levels, row strides) of a list of (column block, level)."""
     arr = (ctypes.c_void_p * len(planes))(*[p.data_ptr() for p, _ in planes])
     lvs = (ctypes.c_int * len(planes))(*[lv for _, lv in planes])
-    _lib.call("t2h_segsum_bwd_multi", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lvs, ctypes.c_void_p), len(planes),
-              _lib.ptr(tile.cell), tile.B, tile.N, tile.nbits, c, None if mask is None else _lib.ptr(mask), None,
-              _lib.ptr(out), _lib.stream(),
-              nbytes=4 * c * tile.n_points * (2 if mask is not None else 1) + 4 * tile.n_points + sum(4 * p.numel() for p, _ in planes),
-              tag=f"t2h_segsum_bwd_multi[C={c},n={len(planes)}]")
+    lds = (ctypes.c_int * len(planes))(*[p.stride(0) for p, _ in planes])
+    return ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lvs, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p)
+
+
+def _gather(tile, planes, c, mask=None):
+    """d rows [N, C] = (mask > 0 ?) sum over ``planes`` [(column block, level)] of block[cell_level(n)]: the adjoint of the sums."""
+    out = torch.empty(tile.n_points, c, dtype=torch.float32, device=tile.device)
+    arr, lvs, lds = _plane_args(planes)
+    _lib.call("t2h_segsum_bwd_multi", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), tile.B, tile.N, tile.nbits, c,
+              None if mask is None else _lib.ptr(mask), None, _lib.ptr(out), _lib.stream(),
+              nbytes=4 * c * tile.n_points * (2 if mask is not None else 1) + 4 * tile.n_points
+              + sum(4 * c * p.shape[0] for p, _ in planes), tag=f"t2h_segsum_bwd_multi[C={c},n={len(planes)}]")
     return out
 
 
-class _HiddenSums(torch.autograd.Function):
-    """Q = fc_comm.0 applied to the plane's pixels ([B r r, 2C] rows) -> per-cell sums of h = relu(sample(Q)) at ``levels``.
-    h [N, 2C] lives only inside this node (saved for the mask); backward: gather + mask in one pass, then the sample adjoint."""
-
-    @staticmethod
-    def forward(ctx, q_rows, tile, r, levels):
-        q_rows = q_rows.contiguous()
-        c2 = q_rows.shape[1]
-        h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
-        ctx.tile, ctx.r, ctx.levels, ctx.c2 = tile, r, tuple(levels), c2
-        ctx.save_for_backward(h)
-        # (interpolation + ReLU + the finest level's per-cell sums in ONE pass over the cells was built and measured in r03:
-        # 414 us against 162 + 210 us at C = 1024 -- a cell's rows in sequence expose the tap loads' latency -- and dropped)
-        _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
-                  _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
-                  tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
-        return tuple(cell_sums(tile, h, list(levels)))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        (h,) = ctx.saved_tensors
-        tile, r, c2 = ctx.tile, ctx.r, ctx.c2
-        level = tile.level(r)
-        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
-        planes = [(g.contiguous(), lv) for g, lv in zip(grads, ctx.levels) if g is not None]
-        if FUSED_SAMPLE_BWD and ws_bytes > 0 and planes and c2 % 4 == 0:
-            # coarse level: gather + mask inside the sample adjoint's row load, dh [N, 2C] is never written
-            arr = (ctypes.c_void_p * len(planes))(*[p.data_ptr() for p, _ in planes])
-            lvs = (ctypes.c_int * len(planes))(*[lv for _, lv in planes])
-            ws = _lib.workspace(ws_bytes, h.device)
-            dq = torch.empty(tile.B * r * r, c2, dtype=torch.float32, device=h.device)
-            _lib.call("t2h_sample_bwd_from_sums", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lvs, ctypes.c_void_p), len(planes),
-                      _lib.ptr(tile.cell), _lib.ptr(h), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
-                      tile.nbits, level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, _lib.stream(),
-                      nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * dq.numel() + sum(4 * p.numel() for p, _ in planes),
-                      tag=f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
-            return dq, None, None, None
-        dh = _gather(tile, grads, ctx.levels, c2, mask=h)
-        dq = ops._sample_bwd(tile, dh, r, c2, None).reshape(tile.B * r * r, c2)
-        return dq, None, None, None
-
-
-class _PointSums(torch.autograd.Function):
-    """Per-cell sums of a per-point feature tensor [N, C] at ``levels`` (the last point-wise level's c, or the trunk's)."""
-
-    @staticmethod
-    def forward(ctx, rows, tile, levels):
-        rows = rows.contiguous()
-        ctx.tile, ctx.levels, ctx.c = tile, tuple(levels), rows.shape[1]
-        return tuple(cell_sums(tile, rows, list(levels)))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        return _gather(ctx.tile, grads, ctx.levels, ctx.c), None, None
+def counts(tile, level):
+    """Points per cell of ALTO level ``level`` as a [B r r] float column in plane (row-major) order, cached on the tile."""
+    cache = tile.__dict__.setdefault("_cell_counts", {})
+    if level not in cache:
+        r = tile.R >> level
+        cnt = torch.empty(tile.B * r * r, dtype=torch.float32, device=tile.device)
+        _lib.call("t2h_cell_counts", _lib.ptr(tile.off0), tile.B, tile.nbits, level, _lib.ptr(cnt), _lib.stream(),
+                  nbytes=12 * cnt.numel())
+        cache[level] = cnt
+    return cache[level]
 
 
 # ------------------------------------------------------------------------------------------------ grid-side products
-class _SumMatmulNN(torch.autograd.Function):
-    """sum_j x_j @ A[off_j : off_j + K_j] for row blocks x_j [m, K_j] and ONE stacked matrix A [sum K_j, n] (the composed maps
-    of all sources, stacked by rows): accumulated by the GEMM epilogues -- no concat of the x_j, no elementwise adds, and the
-    gradient of A is written block by block into one buffer.  args = (A, x_0, x_1, ...)."""
-
-    @staticmethod
-    def forward(ctx, a_all, *xs):
-        a_all = a_all.contiguous()
-        xs = [x.contiguous() for x in xs]
-        out = torch.empty(xs[0].shape[0], a_all.shape[1], dtype=torch.float32, device=a_all.device)
-        off = 0
-        for j, x in enumerate(xs):
-            mlp.linear_dgrad_(x, a_all[off:off + x.shape[1]], out, accumulate=j > 0)        # "dx = dy w" is x @ A_j
-            off += x.shape[1]
-        if off != a_all.shape[0]:
-            raise ValueError(f"_SumMatmulNN: the blocks cover {off} of A's {a_all.shape[0]} rows")
-        ctx.save_for_backward(a_all, *xs)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        a_all, *xs = ctx.saved_tensors
-        g = g.contiguous()
-        da = torch.empty_like(a_all) if ctx.needs_input_grad[0] else None
-        dxs, off = [], 0
-        for j, x in enumerate(xs):
-            k = x.shape[1]
-            blk = a_all[off:off + k]
-            dxs.append(mlp.linear_fwd_(g, blk, None, torch.empty_like(x)) if ctx.needs_input_grad[1 + j] else None)   # g @ A_j^T
-            if da is not None:
-                mlp.linear_wgrad_(x, g, da[off:off + k], None)                               # x_j^T g
-            off += k
-        return (da, *dxs)
-
-
 class _ComposeStack(torch.autograd.Function):
     """A_k = [A_{k-1} Wc_k^T ; W1_k^T]: the maps of all earlier sources composed with this level's fc_c in ONE product, and the
     new source's map (fc_comm.2, transposed) appended -- written straight into the stacked matrix (no cat, no transposed copy
@@ -227,76 +139,167 @@ def _transpose(src, dst):
     _lib.call("t2h_nchw_to_nhwc", _lib.ptr(src), 1, m, n, _lib.ptr(dst), _lib.stream(), nbytes=8 * m * n)
 
 
-class _MeanBias(torch.autograd.Function):
-    """raster = acc / max(count, 1) + [count > 0] * const: scatter_mean's division and empty-cell rule on the product of the
-    per-cell sums, plus the composed bias -- one launch (t2h_mean_bias_fwd) instead of three elementwise ones."""
+class _DeferredLevel(torch.autograd.Function):
+    """One exchange level of the deferred form.  Forward: h = relu(sample(Q)) [N, 2C] (kept inside), its per-cell sums into the
+    sum matrices of every resolution it will be needed at, then raster = (S_lv[:, :K] @ A) / count + [count > 0] const -- ONE
+    product over all sources.  Backward: the product's two gradients (A; the sums, accumulated into the gradient matrices dS),
+    then -- every later level has already added its share, autograd runs them first -- this level's own source: gather + mask
+    inside the sample adjoint -> dQ.  The first deferred level also owns the base features' sums and returns their gradient."""
 
     @staticmethod
-    def forward(ctx, acc, const, cnt):
-        acc, const = acc.contiguous(), const.contiguous()
+    def forward(ctx, q_rows, a_all, const, base_rows, state, idx, r):
+        tile = state.tile
+        q_rows, a_all, const = q_rows.contiguous(), a_all.contiguous(), const.contiguous()
+        c2 = q_rows.shape[1]
+        lv = state.levels_seq[idx]
+        if idx == 0:
+            state.write_sums(0, base_rows.contiguous())
+        h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
+        _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
+                  _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
+                  tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
+        state.write_sums(idx + 1, h)
+        k = state.off[idx + 2]                                             # columns of all sources that exist at this level
+        if a_all.shape[0] != k:
+            raise RuntimeError(f"deferred level {idx}: {a_all.shape[0]} composed rows for {k} source columns")
+        x = state.S[lv][:, :k]
+        acc = torch.empty(x.shape[0], a_all.shape[1], dtype=torch.float32, device=x.device)
+        mlp.linear_dgrad_(x, a_all, acc)                                   # "dx = dy w" is exactly x @ A
+        cnt = counts(tile, lv)
         out = torch.empty_like(acc)
-        p, c = acc.shape
-        _lib.call("t2h_mean_bias_fwd", _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(const), p, c, _lib.ptr(out), _lib.stream(),
-                  nbytes=8 * p * c + 4 * p)
-        ctx.save_for_backward(cnt)
+        _lib.call("t2h_mean_bias_fwd", _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(const), acc.shape[0], acc.shape[1], _lib.ptr(out),
+                  _lib.stream(), nbytes=8 * acc.numel() + 4 * acc.shape[0])
+        ctx.state, ctx.idx, ctx.r, ctx.has_base = state, idx, r, idx == 0
         ctx.const_shape = const.shape
+        ctx.save_for_backward(h, a_all)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (cnt,) = ctx.saved_tensors
+        h, a_all = ctx.saved_tensors
+        state, idx, r = ctx.state, ctx.idx, ctx.r
+        tile = state.tile
+        lv = state.levels_seq[idx]
+        k = state.off[idx + 2]
         g = g.contiguous()
         p, c = g.shape
-        dacc = torch.empty_like(g) if ctx.needs_input_grad[0] else None
-        dconst = torch.empty(ctx.const_shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        cnt = counts(tile, lv)
+        # through the mean / bias epilogue
+        dacc = torch.empty_like(g)
+        dconst = torch.empty(ctx.const_shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
         ws_bytes = _lib.load().t2h_mean_bias_bwd_workspace_bytes(p, c)
         ws = _lib.workspace(ws_bytes, g.device)
-        _lib.call("t2h_mean_bias_bwd", _lib.ptr(g), _lib.ptr(cnt), p, c, None if dacc is None else _lib.ptr(dacc),
-                  None if dconst is None else _lib.ptr(dconst), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=8 * p * c + 4 * p)
-        return dacc, dconst, None
-
-
-# ------------------------------------------------------------------------------------------------ state
-def counts(tile, level):
-    """Points per cell of ALTO level ``level`` as a [B r r] float column in plane (row-major) order, cached on the tile."""
-    cache = tile.__dict__.setdefault("_cell_counts", {})
-    if level not in cache:
-        r = tile.R >> level
-        cnt = torch.empty(tile.B * r * r, dtype=torch.float32, device=tile.device)
-        _lib.call("t2h_cell_counts", _lib.ptr(tile.off0), tile.B, tile.nbits, level, _lib.ptr(cnt), _lib.stream(),
-                  nbytes=12 * cnt.numel())
-        cache[level] = cnt
-    return cache[level]
+        _lib.call("t2h_mean_bias_bwd", _lib.ptr(g), _lib.ptr(cnt), p, c, _lib.ptr(dacc), None if dconst is None else _lib.ptr(dconst),
+                  _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=8 * p * c + 4 * p)
+        x = state.S[lv][:, :k]
+        da = None
+        if ctx.needs_input_grad[1]:
+            da = torch.empty_like(a_all)
+            mlp.linear_wgrad_(x, dacc, da, None)                           # x^T dacc
+        # into the gradient matrix of this resolution: the leading k columns; a later level of the same resolution (run before,
+        # more columns) has initialised them already -> accumulate
+        dS, seen = state.grad_matrix(lv)
+        if seen and seen < k:
+            raise RuntimeError("deferred backward out of order")
+        mlp.linear_fwd_(dacc, a_all, None, dS[:, :k], accumulate=bool(seen))   # dacc @ A^T
+        state.dS_cols[lv] = max(seen, k)
+        # this level's own source: every level that used its sums has contributed by now
+        lo, hi = state.off[idx + 1], state.off[idx + 2]
+        planes = [(state.dS[l][:, lo:hi], l) for l in state.needed(idx + 1)]
+        dq = None
+        if ctx.needs_input_grad[0]:
+            dq = state.hidden_grad(planes, h, r)
+        dbase = None
+        if ctx.has_base and ctx.needs_input_grad[3]:
+            lo0, hi0 = state.off[0], state.off[1]
+            dbase = _gather(tile, [(state.dS[l][:, lo0:hi0], l) for l in state.needed(0)], hi0 - lo0)
+        return dq, da, dconst, dbase, None, None, None
 
 
 class Deferred:
-    """c_k = sum_j src_j A_j + const, never materialised.  ``sums``: per source {level: [B r r, K_j] per-cell sums};
-    ``a_all`` [sum K_j, C_k]: the maps A_j = (Wc_k ... Wc_{j+1} W1_j)^T of all sources stacked by rows, so that one product
-    per level composes them all with the level's fc_c (None until the first level: the base tensor's map is the identity)."""
+    """c_k = sum_j src_j A_j + const, never materialised.  Sources: 0 = the base per-point features (the last point-wise level's
+    c), j >= 1 = the hidden activations of deferred level j - 1.  ``S[lv]`` / ``dS[lv]``: [B r r, K_total] matrices of the per-cell
+    sums / their gradients, one column block per source.  ``a_all`` [K_k, C_k]: the maps A_j = (Wc_k ... Wc_{j+1} W1_j)^T of all
+    sources stacked by rows in the same order, composed with each level's fc_c by one product (``_ComposeStack``)."""
 
-    def __init__(self, tile, later_levels, base_rows):
+    def __init__(self, tile, levels_seq, channels_seq, base_rows):
         self.tile = tile
-        levels = tuple(sorted(set(later_levels)))
-        self.sums = [dict(zip(levels, _PointSums.apply(base_rows, tile, levels)))]
-        self.a_all = None
-        self.const = None                                 # [1, C_k] row or None (zero)
+        self.levels_seq = list(levels_seq)                 # ALTO level (resolution) of this and every later exchange
+        ks = [base_rows.shape[1]] + [2 * c for c in channels_seq]
+        self.off = [0]
+        for kk in ks:
+            self.off.append(self.off[-1] + kk)
+        self.base = base_rows
+        self.S, self.dS, self.dS_cols = {}, {}, {}
+        self.a_all, self.const = None, None
+        self.n_done = 0
 
-    def advance(self, q_rows, r, later_levels, fc_b, fc_c):
-        """One level: compose the maps with this level's fc_c, add the level's hidden activations as a source (their fc_comm.2
-        is the new source's map), return the level's raster rows [B r r, C_k].  ``later_levels`` = ALTO levels of this and
-        every later exchange (what the new source will be rasterised at)."""
-        tile = self.tile
+    def needed(self, src):
+        """ALTO levels (finest first) at which source ``src`` is rasterised: the resolutions of its own level and all later ones."""
+        first = 0 if src == 0 else src - 1
+        return sorted(set(self.levels_seq[first:]))
+
+    def _matrix(self, store, lv):
+        if lv not in store:
+            r = self.tile.R >> lv
+            store[lv] = torch.empty(self.tile.B * r * r, self.off[-1], dtype=torch.float32, device=self.tile.device)
+        return store[lv]
+
+    def grad_matrix(self, lv):
+        return self._matrix(self.dS, lv), self.dS_cols.get(lv, 0)
+
+    def write_sums(self, src, rows):
+        """Per-cell sums of ``rows`` [N, K_src] into the source's column block at every needed resolution: the finest from the
+        rows (read once), the coarser ones by 2x2 pooling."""
+        tile, (lo, hi) = self.tile, (self.off[src], self.off[src + 1])
+        levels = self.needed(src)
+        cur_level = levels[0]
+        cur = self._matrix(self.S, cur_level)[:, lo:hi]
+        _segsum_into(tile, rows, cur_level, cur)
+        for lv in levels[1:]:
+            while cur_level < lv:
+                nxt_level = cur_level + 1
+                if nxt_level in levels:
+                    nxt = self._matrix(self.S, nxt_level)[:, lo:hi]
+                else:                                       # a resolution no level uses: a compact temporary on the way down
+                    rn = tile.R >> nxt_level
+                    nxt = torch.empty(tile.B * rn * rn, hi - lo, dtype=torch.float32, device=tile.device)
+                _sumpool_into(tile, cur, cur_level, nxt)
+                cur, cur_level = nxt, nxt_level
+
+    def hidden_grad(self, planes, h, r):
+        """dQ [B r r, 2C] = S^T ((h > 0) * sum_l dS_l[cell_l(.)]): gather + ReLU mask inside the sample adjoint where the level
+        takes the per-cell partials, else as two passes."""
+        tile, c2 = self.tile, h.shape[1]
+        level = tile.level(r)
+        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
+        if FUSED_SAMPLE_BWD and ws_bytes > 0 and c2 % 4 == 0:
+            arr, lvs, lds = _plane_args(planes)
+            ws = _lib.workspace(ws_bytes, h.device)
+            dq = torch.empty(tile.B * r * r, c2, dtype=torch.float32, device=h.device)
+            _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(h), _lib.ptr(tile.pts),
+                      tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes,
+                      _lib.stream(), nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * dq.numel()
+                      + sum(4 * c2 * p.shape[0] for p, _ in planes), tag=f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
+            return dq
+        dh = _gather(tile, planes, c2, mask=h)
+        return ops._sample_bwd(tile, dh, r, c2, None).reshape(tile.B * r * r, c2)
+
+    def advance(self, q_rows, r, fc_b, fc_c):
+        """One level: compose the maps with this level's fc_c and append fc_comm.2's as the new source's, then the level's raster
+        rows [B r r, C_k] (``_DeferredLevel``)."""
+        idx = self.n_done
+        if self.tile.level(r) != self.levels_seq[idx]:
+            raise RuntimeError("deferred levels out of order")
         wc, bc, w1, b1 = fc_c.weight, fc_c.bias, fc_b.weight, fc_b.bias
         self.a_all = _ComposeStack.apply(self.a_all, wc, w1)
         if self.const is None:
             self.const = (bc + b1).reshape(1, -1)
         else:
             self.const = mlp.linear(self.const, wc, bc) + b1.reshape(1, -1)   # const_k = const_{k-1} Wc_k^T + bc_k + b1_k
-        levels = tuple(sorted(set(later_levels)))
-        self.sums.append(dict(zip(levels, _HiddenSums.apply(q_rows, tile, r, levels))))
-        lv = tile.level(r)
-        acc = _SumMatmulNN.apply(self.a_all, *[s[lv] for s in self.sums])
-        return _MeanBias.apply(acc, self.const, counts(tile, lv))             # scatter_mean: mean per cell, 0 if empty
+        raster = _DeferredLevel.apply(q_rows, self.a_all, self.const, self.base if idx == 0 else None, self, idx, r)
+        self.n_done += 1
+        return raster
 
 
 def applicable(tile, r: int, c: int) -> bool:

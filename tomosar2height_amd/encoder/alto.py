@@ -69,18 +69,22 @@ class _PointGridLevel(nn.Module):
 
     def _exchange(self, tile: TileIndex, plane: torch.Tensor, c_last, later_res=None):
         """-> (raster, c, plane): the returned ``plane`` is the input plane for its further consumers (its gradient is then
-        summed inside the sample backward kernel, ops.sample_plane_thru).  ``later_res``: plane resolutions of this and every
-        later point<->grid exchange of the U-Net; with it the wide levels run in the deferred form (deferred.py): ``c`` is then
-        a ``deferred.Deferred`` -- the per-point features as a linear map of the hidden activations, never materialised."""
+        summed inside the sample backward kernel, ops.sample_plane_thru).  ``later_res``: (plane resolutions, channel counts) of
+        this and every later point<->grid exchange of the U-Net; with it the wide levels run in the deferred form
+        (deferred.py): ``c`` is then a ``deferred.Deferred`` -- the per-point features as a linear map of the hidden
+        activations, never materialised."""
         fa, fb = self.fc_comm[0], self.fc_comm[2]
         r, ch = plane.shape[2], plane.shape[1]
         if isinstance(c_last, deferred.Deferred) or (later_res is not None and torch.is_tensor(c_last)
                                                      and deferred.applicable(tile, r, ch)):
-            levels = [tile.level(x) for x in later_res]
-            state = c_last if isinstance(c_last, deferred.Deferred) else deferred.Deferred(tile, levels, c_last)
+            if isinstance(c_last, deferred.Deferred):
+                state = c_last
+            else:
+                res, chs = later_res
+                state = deferred.Deferred(tile, [tile.level(x) for x in res], chs, c_last)
             rows = plane.permute(0, 2, 3, 1).reshape(-1, ch)                      # the pixels as rows (a view if channels_last)
             q = mlp.linear(rows, fa.weight, fa.bias)                              # fc_comm.0 on the pixels (alto.py:123)
-            raster = state.advance(q, r, levels, fb, self.fc_c).reshape(plane.shape[0], r, r, ch).permute(0, 3, 1, 2)
+            raster = state.advance(q, r, fb, self.fc_c).reshape(plane.shape[0], r, r, ch).permute(0, 3, 1, 2)
             return (raster if self.channels_last else raster.contiguous()), state, plane
         if mlp.grid_first_applicable(tile, r, ch):
             # coarse levels (many points per pixel): fc_comm.0 on the pixels, its 2C-wide result interpolated straight into
@@ -211,21 +215,23 @@ class UNet(nn.Module):
         skips, prev_conv, c = [], None, c_sorted
         # plane resolution of every point<->grid exchange, in order (the deferred form needs to know where the hidden
         # activations of a level will be rasterised later): down levels, then every up level but the last (alto.py:241-242)
-        res, r = [], plane.shape[2]
+        res, chs, r = [], [], plane.shape[2]
         for down in self.down_convs:
             res.append(r)
+            chs.append(down.out_channels)
             r = r // 2 if down.pooling else r
         for up in self.up_convs:
             if not up.is_last:
                 r *= 2
                 res.append(r)
+                chs.append(up.out_channels)
         pos = 0
         for down in self.down_convs:
-            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, res[pos:])
+            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, (res[pos:], chs[pos:]))
             skips.append(raster)
             pos += 1
         for i, up in enumerate(self.up_convs):
-            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, res[pos:])
+            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, (res[pos:], chs[pos:]))
             pos += 1
         if self.down_convs[0].channels_last:
             return grid.conv1x1(plane, self.conv_final)
