@@ -99,6 +99,9 @@ def parse():
                          "producer.TileSource from a synthetic chunk resident in HBM (dataset.py:201-330) inside the loop, "
                          "instead of cycling --tile-pool prepared tiles; N varies per tile around --points")
     ap.add_argument("--chunk-tiles", type=int, default=3, help="--from-producer: the chunk is this many 512 m tiles per side")
+    ap.add_argument("--producer-prefetch", type=int, default=1,
+                    help="--from-producer: 1 = tile i + 1 is produced on a side stream while step i runs (the overlap the "
+                         "reference gets from DataLoader workers), 0 = produce, then train, in sequence on one stream")
     return ap.parse_args()
 
 
@@ -431,7 +434,8 @@ def main():
         source = TileSource(TileProducer(ch["points"].to(dev), z_bound=ch["z_bound"]),
                             RasterPatcher(ch["dsm"].to(dev), ch["left"], ch["top"]),
                             RasterPatcher(ch["image"].to(dev), ch["left"], ch["top"]) if args.use_image else None,
-                            flip_augm=True, rotate_augm=True, rng=np.random.RandomState(7 + rank))
+                            flip_augm=True, rotate_augm=True, rng=np.random.RandomState(7 + rank),
+                            stream=torch.cuda.Stream() if args.producer_prefetch else None)
         span = 512.0 * (args.chunk_tiles - 1)
         anchors = np.floor(np.random.RandomState(11 + rank).uniform(0, span, (4096, 2))) + np.array([ch["left"], ch["bottom"]])
     else:
@@ -444,7 +448,13 @@ def main():
     def next_tile():
         if source is None:
             return tiles[state["i"] % len(tiles)]
-        t = source.get(anchors[state["i"] % len(anchors)])
+        if not args.producer_prefetch:
+            t = source.get(anchors[state["i"] % len(anchors)])
+        else:
+            # tile i was produced (on the producer's side stream) while step i - 1 ran; produce tile i + 1 now, before step i
+            # is issued, so that its crop runs beside the steps in flight and its host read does not wait for them
+            t = state.pop("pending", None) or source.get(anchors[state["i"] % len(anchors)])
+            state["pending"] = source.get(anchors[(state["i"] + 1) % len(anchors)])
         state["points"] += t["inputs"].shape[1]
         return t
 
@@ -599,7 +609,8 @@ def main():
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
         if args.from_producer:
             out["config"]["tile_source"] = (f"producer.TileSource in the loop: crop + normalise + rot/flip augmentation + DSM patch "
-                                            f"per tile from a {args.chunk_tiles}x{args.chunk_tiles}-tile chunk resident in HBM; "
+                                            f"per tile from a {args.chunk_tiles}x{args.chunk_tiles}-tile chunk resident in HBM"
+                                            f"{', next tile produced on a side stream during the step' if args.producer_prefetch else ''}; "
                                             f"mean N = {timed_points / max(args.steps, 1):.0f} points/tile in the timed region")
             out["config"]["workload"] += ", tiles from the device tile producer (dataset.py:201-330)"
         if dp is not None:

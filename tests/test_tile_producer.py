@@ -109,5 +109,15 @@ def test_device_augmented_tiles_match_fixture():
     t = src.get(g["anchor"])
     assert (t["rotate"], t["flip"]) == (3, 0) and t["dsm"].shape == (1, ph, pw) and t["image"].shape == (1, 3, ph, pw)
     assert np.array_equal(t["dsm"].cpu().numpy(), g["dsm_r3_f1"]) and np.array_equal(t["image"][0].cpu().numpy(), g["image_r3_f1"])
+    # the same tile produced on a side stream (the prefetching form: the host's point-count read waits for the crop only,
+    # not for a training step running on the main stream) -- while the main stream is kept busy -- is bit-identical
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(4):
+        busy = busy @ busy * 1e-4
+    src2 = TileSource(prod, dsm, img, flip_augm=True, rotate_augm=True, rng=_Fixed([3, 1]), stream=torch.cuda.Stream())
+    t2 = src2.get(g["anchor"])
+    for k in ("inputs", "dsm", "image"):
+        assert torch.equal(t2[k], t[k]), k
+    assert (t2["rotate"], t2["flip"]) == (3, 0)
     with pytest.raises(RuntimeError, match="leave the"):
         dsm.patch((left - 10 * px, float(g["anchor"][1])))

@@ -98,13 +98,30 @@ class TileSource:
     ``Trainer.train_step`` takes: ``inputs [1, N, 3]``, ``dsm [1, ph, pw]``, ``image [1, 3, ph, pw]``, ``is_valid``."""
 
     def __init__(self, points: TileProducer, dsm: RasterPatcher, image: RasterPatcher = None, flip_augm=False,
-                 rotate_augm=False, rng=None):
+                 rotate_augm=False, rng=None, stream=None):
+        """``stream``: a side ``torch.cuda.Stream`` to produce tiles on.  The one host read per tile (its point count) then
+        waits for the crop kernels only, not for the training step still running on the main stream, so tile t + 1 can be
+        produced while step t executes (the reference gets the same overlap from its DataLoader workers, train.py:80-85);
+        the main stream is made to wait for the produced tensors before ``get`` returns."""
         import numpy as np
         self.points, self.dsm, self.image = points, dsm, image
         self.flip_augm, self.rotate_augm = flip_augm, rotate_augm
         self.rng = rng if rng is not None else np.random
+        self.stream = stream
 
     def get(self, anchor):
+        if self.stream is None:
+            return self._produce(anchor)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            out = self._produce(anchor)
+        main.wait_stream(self.stream)
+        for v in out.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(main)                             # allocated on the side stream, consumed on the main one
+        return out
+
+    def _produce(self, anchor):
         rot = int(self.rng.choice(4)) if self.rotate_augm else 0
         flip = (-1, 0, 1)[int(self.rng.choice(3))] if self.flip_augm else -1
         out = self.points.crop(anchor, rot_times=rot, flip_dim=flip)
