@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 6
+#define T2H_ABI_VERSION 7
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -156,7 +156,7 @@ int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float 
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */
 int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
-                             const int32_t *cell, const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N,
+                             const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim, const int32_t *off0, int B, int N,
                              int nbits, int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                              t2h_stream_t stream);
 /* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
@@ -184,7 +184,10 @@ int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, in
  * padding_mode='border', align_corners=True):  relu(W0 sample(P) + b0) == relu(sample(P W0^T + b0)).  `plane_nhwc` is then the
  * [B, r, r, 2C] plane P W0^T + b0; where N >> r^2 this replaces an [N, C] x [C, 2C] product by an [r^2, C] x [C, 2C] one. */
 int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
-                        t2h_stream_t stream);
+                        void *sign_bits, t2h_stream_t stream);
+/* `sign_bits` (may be NULL; C % 256 == 0): the pattern out > 0 packed 1 bit per element, [B*N][C / 256][4] 64-bit words, bit l of
+ * word j <=> channel 256 q + 4 l + j -- all the backward needs of the hidden activations (t2h_sample_bwd_from_sums with
+ * mask_is_bits = 1 reads 32 B instead of 1 KB per row and chunk, and the activations need not be kept for the backward). */
 size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C);
 int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                    int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,

@@ -541,10 +541,14 @@ __device__ inline Taps make_taps(float x01, float y01, int r) {
 
 // RELU: out = max(sample, 0) -- the hidden layer of fc_comm when its first Linear was applied on the grid
 // (t2h_sample_fwd_relu)
+// `bits` (RELU, VEC = 4, C % 256 == 0 only; may be null): the sign pattern of the result packed 1 bit per element -- for
+// row n and 256-channel chunk q four 64-bit words, bit l of word j <=> out[n][256 q + 4 l + j] > 0 -- which is all the backward
+// needs of the hidden activations (32 B instead of 1 KB per row and chunk; t2h_sample_bwd_from_sums reads it)
 template <int VEC, bool RELU = false>
 __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__restrict__ plane,
                                                               const float *__restrict__ pts, int dim, int64_t npts,
-                                                              int N, int r, int C, int lg, float *__restrict__ out) {
+                                                              int N, int r, int C, int lg, float *__restrict__ out,
+                                                              unsigned long long *__restrict__ bits = nullptr) {
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t n = t >> lg;
     if (n >= npts) return;
@@ -583,6 +587,15 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
         if (RELU) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc.v[j] = fmaxf(acc.v[j], 0.0f);
+            if (VEC == 4 && bits) {             // lg == 6 here: the wave is one (row, 256-channel chunk), lane l = channels 4 l ..
+                unsigned long long w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = __ballot(acc.v[j] > 0.0f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long *dst = bits + ((size_t)n * (C >> 8) + (c >> 8)) * 4;
+                    dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+                }
+            }
         }
         acc.store(out + (size_t)n * C + c);
     }
@@ -1054,7 +1067,7 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_kernel(const fl
 // slot come out as float4s again.  fp32 MFMA = an exact fma chain over the rows in order, as the VALU form.
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 constexpr int kMfmaRows = 64;
-template <bool FUSED>
+template <bool FUSED, bool BITS = false>
 __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(const float *__restrict__ gout,
                                                                              const float *__restrict__ pts, int dim,
                                                                              const int32_t *__restrict__ off0, int nbits,
@@ -1133,7 +1146,20 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                     const int n = min(blk + rr, hi - 1);   // rows past the end carry weight 0; keep their loads in bounds
                     a[u] = Wl[rr][lane & 15];
                     if (FUSED) {
-                        const float4 hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + ch);
+                        float4 hm;
+                        if (BITS) {            // packed sign bits (sample_fwd_kernel): 32 B per row and 256-channel chunk
+                            const uint4 *bw = reinterpret_cast<const uint4 *>(
+                                reinterpret_cast<const unsigned long long *>(mask) + ((size_t)n * (C >> 8) + (ch >> 8)) * 4);
+                            const uint4 b01 = bw[0], b23 = bw[1];
+                            const int li = (ch & 255) >> 2;
+                            const unsigned int s0 = li < 32 ? b01.x : b01.y, s1 = li < 32 ? b01.z : b01.w;
+                            const unsigned int s2 = li < 32 ? b23.x : b23.y, s3 = li < 32 ? b23.z : b23.w;
+                            const int sh = li & 31;
+                            hm = make_float4((float)((s0 >> sh) & 1u), (float)((s1 >> sh) & 1u), (float)((s2 >> sh) & 1u),
+                                             (float)((s3 >> sh) & 1u));
+                        } else {
+                            hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + ch);
+                        }
                         float4 v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * mp.ld[0] + ch);
 #pragma unroll
                         for (int q = 1; q < kMaxMultiPlanes; ++q)
@@ -1522,7 +1548,7 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
 }
 
 T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
-                                     const int32_t *cell, const float *mask, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                                     const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                                      int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                                      t2h_stream_t stream) {
     if (!gplanes_nhwc || !levels || !lds || !cell || !mask || !pts || !off0 || !gplane_nhwc)
@@ -1532,6 +1558,9 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     int rc = check_level("sample_bwd_from_sums", B, nbits, level, C);
     if (rc) return rc;
     if (dim < 2 || N < 0 || C % 4 != 0 || ((uintptr_t)mask & 15)) return fail(T2H_ERR_ARG, "sample_bwd_from_sums: unsupported shape");
+    if (mask_is_bits && (C % 256 != 0 || !cells_mfma(C)))
+        return fail(T2H_ERR_ARG, "sample_bwd_from_sums: packed sign bits need C %% 256 == 0 (and the matrix-core partials)");
+    const float *maskf = static_cast<const float *>(mask);
     CoarsePlan cp = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
     if (!cp.use)
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: level %d holds too few points per cell for the per-cell partials "
@@ -1549,13 +1578,16 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     int64_t groups = (int64_t)B << (2 * (nbits - level));
     float *partial = static_cast<float *>(workspace);
     int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
-    if (cells_mfma(C))
+    if (mask_is_bits)
+        hipLaunchKernelGGL((sample_bwd_cells_mfma_kernel<true, true>), dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf);
+    else if (cells_mfma(C))
         hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, mask);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf);
     else
         hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                            (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
-                           partial, mp, cell, mask);
+                           partial, mp, cell, maskf);
     GroupCfg g = group_cfg<4>(C);
     hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream),
                        partial, B, nbits - level, C, g.lg, cp.S, nullptr, gplane_nhwc);
@@ -1563,15 +1595,17 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
 }
 
 T2H_API int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
-                                t2h_stream_t stream) {
+                                void *sign_bits, t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd_relu: null pointer");
     if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_fwd_relu: unsupported shape");
+    if (sign_bits && (C % 256 != 0 || ((uintptr_t)sign_bits & 15)))
+        return fail(T2H_ERR_ARG, "sample_fwd_relu: the packed sign bits need C %% 256 == 0 and a 16-byte aligned buffer");
     int64_t npts = (int64_t)B * N;
     if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
           hipLaunchKernelGGL((sample_fwd_kernel<4, true>), dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
-                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); },
+                             plane_nhwc, pts, dim, npts, N, r, C, g.lg, out, static_cast<unsigned long long *>(sign_bits)); },
         { GroupCfg g = group_cfg<1>(C);
           hipLaunchKernelGGL((sample_fwd_kernel<1, true>), dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
                              plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });

@@ -31,6 +31,8 @@ from . import _lib, mlp, ops
 
 DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
 FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
+CELLS_MFMA = os.environ.get("T2H_CELLS_MFMA", "1") != "0"                  # (mirrors the library's switch: the bit mask needs it)
+SIGN_BITS = os.environ.get("T2H_SIGN_BITS", "1") != "0"                    # A/B: 0 = keep the hidden activations for the mask
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
@@ -155,8 +157,15 @@ class _DeferredLevel(torch.autograd.Function):
         if idx == 0:
             state.write_sums(0, base_rows.contiguous())
         h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
+        # the backward needs only the sign pattern of h: where its fused form will run, keep 1 bit per element (written by the
+        # sample kernel's ballots) and let h go after the per-cell sums -- 1/32 of the bytes to keep and to re-read
+        bits = None
+        if (SIGN_BITS and c2 % 256 == 0 and FUSED_SAMPLE_BWD and CELLS_MFMA and
+                _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0):
+            bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
-                  _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel(),
+                  None if bits is None else _lib.ptr(bits), _lib.stream(),
+                  nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel() + (c2 // 8) * tile.n_points * (bits is not None),
                   tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
         state.write_sums(idx + 1, h)
         k = state.off[idx + 2]                                             # columns of all sources that exist at this level
@@ -171,7 +180,8 @@ class _DeferredLevel(torch.autograd.Function):
                   _lib.stream(), nbytes=8 * acc.numel() + 4 * acc.shape[0])
         ctx.state, ctx.idx, ctx.r, ctx.has_base = state, idx, r, idx == 0
         ctx.const_shape = const.shape
-        ctx.save_for_backward(h, a_all)
+        ctx.mask_is_bits = bits is not None
+        ctx.save_for_backward(h if bits is None else bits, a_all)
         return out
 
     @staticmethod
@@ -208,7 +218,7 @@ class _DeferredLevel(torch.autograd.Function):
         planes = [(state.dS[l][:, lo:hi], l) for l in state.needed(idx + 1)]
         dq = None
         if ctx.needs_input_grad[0]:
-            dq = state.hidden_grad(planes, h, r)
+            dq = state.hidden_grad(planes, h, r, hi - lo, ctx.mask_is_bits)
         dbase = None
         if ctx.has_base and ctx.needs_input_grad[3]:
             lo0, hi0 = state.off[0], state.off[1]
@@ -267,19 +277,20 @@ class Deferred:
                 _sumpool_into(tile, cur, cur_level, nxt)
                 cur, cur_level = nxt, nxt_level
 
-    def hidden_grad(self, planes, h, r):
+    def hidden_grad(self, planes, h, r, c2, mask_is_bits=False):
         """dQ [B r r, 2C] = S^T ((h > 0) * sum_l dS_l[cell_l(.)]): gather + ReLU mask inside the sample adjoint where the level
-        takes the per-cell partials, else as two passes."""
-        tile, c2 = self.tile, h.shape[1]
+        takes the per-cell partials, else as two passes.  ``h``: the hidden activations, or their packed sign bits."""
+        tile = self.tile
         level = tile.level(r)
         ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
-        if FUSED_SAMPLE_BWD and ws_bytes > 0 and c2 % 4 == 0:
+        if mask_is_bits or (FUSED_SAMPLE_BWD and ws_bytes > 0 and c2 % 4 == 0):
             arr, lvs, lds = _plane_args(planes)
             ws = _lib.workspace(ws_bytes, h.device)
             dq = torch.empty(tile.B * r * r, c2, dtype=torch.float32, device=h.device)
-            _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(h), _lib.ptr(tile.pts),
-                      tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes,
-                      _lib.stream(), nbytes=4 * c2 * tile.n_points + 12 * tile.n_points + 4 * dq.numel()
+            _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(h),
+                      1 if mask_is_bits else 0, _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
+                      level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, _lib.stream(),
+                      nbytes=(c2 // 8 if mask_is_bits else 4 * c2) * tile.n_points + 12 * tile.n_points + 4 * dq.numel()
                       + sum(4 * c2 * p.shape[0] for p, _ in planes), tag=f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
             return dq
         dh = _gather(tile, planes, c2, mask=h)

@@ -352,7 +352,7 @@ def hidden_from_plane(tile, plane_rows, r, w_a, b_a):
     linear_fwd_(plane_rows, w_a, b_a, q)                                       # fc_comm.0 on the pixels
     h = _empty(tile.n_points, w_a.shape[0], plane_rows)
     c2 = w_a.shape[0]
-    _lib.call("t2h_sample_fwd_relu", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
+    _lib.call("t2h_sample_fwd_relu", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h), None,
               _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q.numel(),
               tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
     return h
