@@ -3,8 +3,6 @@ t2h_plane_sumpool2x2, t2h_segsum_bwd_multi, t2h_sample_bwd_from_sums, t2h_cell_c
 against plain torch restatements of what they replace (reference: alto.py:76-95, 121-130: grid_sample, ReLU, scatter_add,
 count clamp, division), through the C ABI.  Whole-level and whole-network checks of the same path: test_hip_masks.py,
 test_full_size_vs_oracle.py."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
