@@ -507,7 +507,9 @@ def main():
         fence()
         evs[0].record()
         ts0 = time.perf_counter()
+        cpu0 = time.process_time()
         run(n_sus, evs)
+        issue_s, issue_cpu_s = time.perf_counter() - ts0, time.process_time() - cpu0
         fence()
         sus_elapsed = time.perf_counter() - ts0
         if world > 1:
@@ -520,7 +522,11 @@ def main():
                      "tiles_per_s": round(world * n_sus / sus_elapsed, 3),
                      "first_quartile_ms": round(sum(per[:q]) / q, 3), "last_quartile_ms": round(sum(per[-q:]) / q, 3),
                      "median_ms": round(statistics.median(per), 3), "max_ms": round(max(per), 3),
-                     "optimizer_steps": n_sus // trainer.local_every}
+                     "optimizer_steps": n_sus // trainer.local_every,
+                     # host side: wall time until the last launch was issued (== the whole leg when the host or the HIP queue's
+                     # depth limit paces the run) and CPU time of this process per step (Python + HIP runtime, all threads)
+                     "host_issue_ms_per_step": round(1e3 * issue_s / n_sus, 3),
+                     "host_cpu_ms_per_step": round(1e3 * issue_cpu_s / n_sus, 3)}
 
     # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
     timeline = None

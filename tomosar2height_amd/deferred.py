@@ -44,11 +44,11 @@ def _segsum_into(tile, rows, level, dst):
     """Per-cell sums of ``rows`` [N, C] at ALTO level ``level`` into the [B r r, C] column block ``dst`` (row stride dst.stride(0))."""
     n, c = rows.shape
     r = tile.R >> level
-    ws_bytes = _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+    ws_bytes = _lib.ws_bytes("t2h_segmean_workspace_bytes", tile.B, tile.N, tile.nbits, level, c)
     ws = _lib.workspace(ws_bytes, rows.device)
     _lib.call("t2h_segsum_fwd", _lib.ptr(rows), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c, dst.data_ptr(),
               dst.stride(0), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * c * tile.B * r * r,
-              tag=f"t2h_segsum_fwd[C={c},r={r}]")
+              tag=_lib.timing() and f"t2h_segsum_fwd[C={c},r={r}]")
 
 
 def _sumpool_into(tile, fine, level_fine, coarse):
@@ -57,7 +57,7 @@ def _sumpool_into(tile, fine, level_fine, coarse):
     c = fine.shape[1]
     r = tile.R >> level_fine
     _lib.call("t2h_plane_sumpool2x2", fine.data_ptr(), fine.stride(0), tile.B, r, c, coarse.data_ptr(), coarse.stride(0),
-              _lib.stream(), nbytes=5 * c * tile.B * r * r, tag=f"t2h_plane_sumpool2x2[C={c}]")
+              _lib.stream(), nbytes=5 * c * tile.B * r * r, tag=_lib.timing() and f"t2h_plane_sumpool2x2[C={c}]")
 
 
 def _plane_args(planes):
@@ -75,7 +75,7 @@ def _gather(tile, planes, c, mask=None):
     _lib.call("t2h_segsum_bwd_multi", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), tile.B, tile.N, tile.nbits, c,
               None if mask is None else _lib.ptr(mask), None, _lib.ptr(out), _lib.stream(),
               nbytes=4 * c * tile.n_points * (2 if mask is not None else 1) + 4 * tile.n_points
-              + sum(4 * c * p.shape[0] for p, _ in planes), tag=f"t2h_segsum_bwd_multi[C={c},n={len(planes)}]")
+              + sum(4 * c * p.shape[0] for p, _ in planes), tag=_lib.timing() and f"t2h_segsum_bwd_multi[C={c},n={len(planes)}]")
     return out
 
 
@@ -161,12 +161,12 @@ class _DeferredLevel(torch.autograd.Function):
         # sample kernel's ballots) and let h go after the per-cell sums -- 1/32 of the bytes to keep and to re-read
         bits = None
         if (SIGN_BITS and c2 % 256 == 0 and FUSED_SAMPLE_BWD and CELLS_MFMA and
-                _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0):
+                _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0):
             bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
                   None if bits is None else _lib.ptr(bits), _lib.stream(),
                   nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel() + (c2 // 8) * tile.n_points * (bits is not None),
-                  tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
+                  tag=_lib.timing() and f"t2h_sample_fwd_relu[C={c2},r={r}]")
         state.write_sums(idx + 1, h)
         k = state.off[idx + 2]                                             # columns of all sources that exist at this level
         if a_all.shape[0] != k:
@@ -197,7 +197,7 @@ class _DeferredLevel(torch.autograd.Function):
         # through the mean / bias epilogue
         dacc = torch.empty_like(g)
         dconst = torch.empty(ctx.const_shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
-        ws_bytes = _lib.load().t2h_mean_bias_bwd_workspace_bytes(p, c)
+        ws_bytes = _lib.ws_bytes("t2h_mean_bias_bwd_workspace_bytes", p, c)
         ws = _lib.workspace(ws_bytes, g.device)
         _lib.call("t2h_mean_bias_bwd", _lib.ptr(g), _lib.ptr(cnt), p, c, _lib.ptr(dacc), None if dconst is None else _lib.ptr(dconst),
                   _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=8 * p * c + 4 * p)
@@ -282,7 +282,7 @@ class Deferred:
         takes the per-cell partials, else as two passes.  ``h``: the hidden activations, or their packed sign bits."""
         tile = self.tile
         level = tile.level(r)
-        ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
+        ws_bytes = _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, level, c2)
         if mask_is_bits or (FUSED_SAMPLE_BWD and ws_bytes > 0 and c2 % 4 == 0):
             arr, lvs, lds = _plane_args(planes)
             ws = _lib.workspace(ws_bytes, h.device)
@@ -291,7 +291,7 @@ class Deferred:
                       1 if mask_is_bits else 0, _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
                       level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, _lib.stream(),
                       nbytes=(c2 // 8 if mask_is_bits else 4 * c2) * tile.n_points + 12 * tile.n_points + 4 * dq.numel()
-                      + sum(4 * c2 * p.shape[0] for p, _ in planes), tag=f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
+                      + sum(4 * c2 * p.shape[0] for p, _ in planes), tag=_lib.timing() and f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
             return dq
         dh = _gather(tile, planes, c2, mask=h)
         return ops._sample_bwd(tile, dh, r, c2, None).reshape(tile.B * r * r, c2)

@@ -69,7 +69,7 @@ class _ConvBiasAct(torch.autograd.Function):
         b, c, h, w = g.shape
         gm = torch.empty_like(g, memory_format=torch.channels_last) if relu else g     # masked gradient, out of place
         dbias = torch.empty(c, dtype=torch.float32, device=g.device)
-        ws_bytes = _lib.load().t2h_bias_relu_bwd_workspace_bytes(b * h * w, c)
+        ws_bytes = _lib.ws_bytes("t2h_bias_relu_bwd_workspace_bytes", b * h * w, c)
         ws = _lib.workspace(ws_bytes, g.device)
         _lib.call("t2h_bias_relu_bwd", _lib.ptr(g), _lib.ptr(y), _lib.ptr(gm) if relu else None, b * h * w, c,
                   1 if relu else 0, 0, _lib.ptr(dbias), _lib.ptr(ws), ws_bytes, _lib.stream(),
@@ -102,13 +102,13 @@ def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
     b, cin, h, wd = x.shape
     cout = w.shape[0]
     lib = _lib.load()
-    nws = lib.t2h_conv3x3_fwd_workspace_bytes(b, h, wd, cin, cout)
+    nws = _lib.ws_bytes("t2h_conv3x3_fwd_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, x.device)
     flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
     _lib.call("t2h_conv3x3_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None, _lib.ptr(y),
               b, h, wd, cin, cout, flags, _lib.ptr(ws), nws, _lib.stream(),
               nbytes=4 * (x.numel() + y.numel() + w.numel()), flops=2 * 9 * cin * cout * b * h * wd,
-              tag=f"t2h_conv3x3_fwd[{cin}->{cout},{h}x{wd}]")
+              tag=_lib.timing() and f"t2h_conv3x3_fwd[{cin}->{cout},{h}x{wd}]")
     return y
 
 
@@ -116,12 +116,12 @@ def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
     b, cout, h, wd = gy.shape
     cin = w.shape[1]
     lib = _lib.load()
-    nws = lib.t2h_conv3x3_dgrad_workspace_bytes(b, h, wd, cin, cout)
+    nws = _lib.ws_bytes("t2h_conv3x3_dgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(mask) if mask is not None else None,
               b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
               nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel()),
-              flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
+              flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
     return dx
 
 
@@ -129,12 +129,12 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
     b, cout, h, wd = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
-    nws = lib.t2h_conv3x3_wgrad_workspace_bytes(b, h, wd, cin, cout)
+    nws = _lib.ws_bytes("t2h_conv3x3_wgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
               b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
               nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
-              tag=f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
+              tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -221,7 +221,7 @@ class _Conv3x3Small(torch.autograd.Function):
         y = _empty_cl(b, cout, h, wd, x.device)
         _lib.call("t2h_conv3x3_smallcin_fwd", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), b, h, wd, cin, cout,
                   _lib.RELU_OUT if relu else 0, _lib.stream(), nbytes=4 * (x.numel() + y.numel()),
-                  flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_smallcin_fwd[{cin}->{cout},{h}x{wd}]")
+                  flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_smallcin_fwd[{cin}->{cout},{h}x{wd}]")
         need_y = relu and not grad_premasked
         ctx.save_for_backward(x, weight, bias, y if need_y else None)
         ctx.conf = (relu, grad_premasked)
@@ -245,17 +245,17 @@ class _Conv3x3Small(torch.autograd.Function):
             dx = torch.empty_like(x, memory_format=torch.channels_last)
             _lib.call("t2h_conv3x3_smallcin_dgrad", _lib.ptr(gm), _lib.ptr(w), _lib.ptr(dx), b, h, wd, cin, cout, 0,
                       _lib.stream(), nbytes=4 * (gm.numel() + dx.numel()), flops=2 * 9 * cin * cout * b * h * wd,
-                      tag=f"t2h_conv3x3_smallcin_dgrad[{cout}->{cin},{h}x{wd}]")
+                      tag=_lib.timing() and f"t2h_conv3x3_smallcin_dgrad[{cout}->{cin},{h}x{wd}]")
         wg, bg = weight.grad, bias.grad
         direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous() and bg is not None
                   and bg.is_contiguous())
         dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
         db = bg if direct else torch.empty_like(bias)
-        nws = _lib.load().t2h_conv3x3_smallcin_wgrad_workspace_bytes(cin, cout)
+        nws = _lib.ws_bytes("t2h_conv3x3_smallcin_wgrad_workspace_bytes", cin, cout)
         ws = _lib.workspace(nws, g.device)
         _lib.call("t2h_conv3x3_smallcin_wgrad", _lib.ptr(gm), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), b, h, wd, cin, cout,
                   _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (gm.numel() + x.numel()),
-                  flops=2 * 9 * cin * cout * b * h * wd, tag=f"t2h_conv3x3_smallcin_wgrad[{cin}->{cout},{h}x{wd}]")
+                  flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_smallcin_wgrad[{cin}->{cout},{h}x{wd}]")
         return (dx, None, None, None, None) if direct else (dx, dw, db, None, None)
 
 
@@ -312,7 +312,7 @@ class _Conv1x1(torch.autograd.Function):
         _lib.call("t2h_linear_fwd_add", _lib.ptr(x), cin, _lib.ptr(w2), _lib.ptr(bias) if bias is not None else None,
                   _lib.ptr(addend) if addend is not None else None, cout, _lib.ptr(y), cout, m, cin, cout, 0, _lib.stream(),
                   nbytes=4 * (m * cin + m * cout * (2 if addend is not None else 1) + cin * cout),
-                  flops=2 * m * cin * cout, tag=f"t2h_linear_fwd[K={cin},N={cout}]")
+                  flops=2 * m * cin * cout, tag=_lib.timing() and f"t2h_linear_fwd[K={cin},N={cout}]")
         ctx.has_addend = addend is not None
         ctx.save_for_backward(x, weight, bias)
         return y
@@ -329,19 +329,19 @@ class _Conv1x1(torch.autograd.Function):
             dx = _empty_cl(b, cin, h, wd, x.device)
             _lib.call("t2h_linear_dgrad", _lib.ptr(g), cout, _lib.ptr(w2), _lib.ptr(dx), cin, m, cin, cout, None, 0, 0,
                       _lib.stream(), nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
-                      tag=f"t2h_linear_dgrad[N={cout},K={cin}]")
+                      tag=_lib.timing() and f"t2h_linear_dgrad[N={cout},K={cin}]")
         wg, bg = weight.grad, (bias.grad if bias is not None else None)
         direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
                   and (bias is None or (bg is not None and bg.is_contiguous())))
         dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
         db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
         lib = _lib.load()
-        nws = lib.t2h_linear_wgrad_workspace_bytes(m, cin, cout)
+        nws = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, cin, cout)
         ws = _lib.workspace(nws, g.device)
         _lib.call("t2h_linear_wgrad", _lib.ptr(g), cout, _lib.ptr(x), cin, m, cin, cout, _lib.ACCUM if direct else 0,
                   _lib.ptr(dw), _lib.ptr(db) if db is not None else None, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
-                  tag=f"t2h_linear_wgrad[N={cout},K={cin}]")
+                  tag=_lib.timing() and f"t2h_linear_wgrad[N={cout},K={cin}]")
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
@@ -385,7 +385,7 @@ class _UpConv2x2(torch.autograd.Function):
                   _lib.ptr(addend) if addend is not None else None, _lib.ptr(y),
                   b, h, wd, cin, cout, 0, _lib.stream(),
                   nbytes=4 * (x.numel() + y.numel() * (2 if addend is not None else 1) + w.numel()),
-                  flops=2 * 4 * cin * cout * b * h * wd, tag=f"t2h_upconv2x2_fwd[{cin}->{cout},{h}x{wd}]")
+                  flops=2 * 4 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_upconv2x2_fwd[{cin}->{cout},{h}x{wd}]")
         ctx.save_for_backward(x, weight, bias)
         return y
 
@@ -401,23 +401,23 @@ class _UpConv2x2(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=torch.channels_last)
-            nws = lib.t2h_upconv2x2_dgrad_workspace_bytes(b, h, wd, cin, cout)
+            nws = _lib.ws_bytes("t2h_upconv2x2_dgrad_workspace_bytes", b, h, wd, cin, cout)
             ws = _lib.workspace(nws, g.device)
             _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(g), _lib.ptr(w), _lib.ptr(dx), b, h, wd, cin, cout, 0, _lib.ptr(ws), nws,
                       _lib.stream(), nbytes=4 * (g.numel() + dx.numel() + w.numel()), flops=flops,
-                      tag=f"t2h_upconv2x2_dgrad[{cout}->{cin},{h}x{wd}]")
+                      tag=_lib.timing() and f"t2h_upconv2x2_dgrad[{cout}->{cin},{h}x{wd}]")
         wg, bg = weight.grad, (bias.grad if bias is not None else None)
         direct = (mlp._DIRECT_ACCUM and wg is not None and wg.permute(0, 2, 3, 1).is_contiguous()
                   and (bias is None or (bg is not None and bg.is_contiguous())))
         dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
         db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
-        nws = lib.t2h_upconv2x2_wgrad_workspace_bytes(b, h, wd, cin, cout)
+        nws = _lib.ws_bytes("t2h_upconv2x2_wgrad_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, g.device)
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
         _lib.call("t2h_upconv2x2_wgrad_bias", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
                   b, h, wd, cin, cout, _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
-                  tag=f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
+                  tag=_lib.timing() and f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
@@ -458,7 +458,7 @@ def _head_bwd(xs, dxs, weight, bias, g, relu_inputs=()):
     wflat = weight.reshape(-1).contiguous()
     dw = torch.empty(ctot, dtype=torch.float32, device=g.device)
     db = torch.empty(1, dtype=torch.float32, device=g.device) if bias is not None else None
-    ws_bytes = _lib.load().t2h_head1x1_bwd_workspace_bytes(b * h * w, ctot)
+    ws_bytes = _lib.ws_bytes("t2h_head1x1_bwd_workspace_bytes", b * h * w, ctot)
     ws = _lib.workspace(ws_bytes, g.device)
     xarr, dxarr = _ptr_array(xs), _ptr_array(dxs)
     carr = (ctypes.c_int * len(xs))(*chans)

@@ -68,7 +68,7 @@ def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
     flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
     _lib.call("t2h_linear_fwd", xp, ldx, w.data_ptr(), bias.data_ptr() if bias is not None else None, yp, ldy, m, k, n,
               flags, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
-              tag=f"t2h_linear_fwd[K={k},N={n}]")
+              tag=_lib.timing() and f"t2h_linear_fwd[K={k},N={n}]")
     return y
 
 
@@ -82,7 +82,7 @@ def linear_dgrad_(dy, w, dx, mask=None, accumulate=False):
     _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm,
               (_lib.ACCUM if accumulate else 0) | _pflag(),
               _lib.stream(), nbytes=4 * (m * k + m * n + n * k + (m * k if mask is not None else 0)),
-              flops=2 * m * k * n, tag=f"t2h_linear_dgrad[N={n},K={k}]")
+              flops=2 * m * k * n, tag=_lib.timing() and f"t2h_linear_dgrad[N={n},K={k}]")
     return dx
 
 
@@ -99,12 +99,12 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
             if db is not None:
                 db.zero_()
         return
-    ws_bytes = _lib.load().t2h_linear_wgrad_workspace_bytes(m, k, n)
+    ws_bytes = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, k, n)
     ws = _lib.workspace(ws_bytes, dy.device)
     flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
     _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
               ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
-              tag=f"t2h_linear_wgrad[N={n},K={k}]")
+              tag=_lib.timing() and f"t2h_linear_wgrad[N={n},K={k}]")
 
 
 _DIRECT_ACCUM = False
@@ -354,7 +354,7 @@ def hidden_from_plane(tile, plane_rows, r, w_a, b_a):
     c2 = w_a.shape[0]
     _lib.call("t2h_sample_fwd_relu", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h), None,
               _lib.stream(), nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q.numel(),
-              tag=f"t2h_sample_fwd_relu[C={c2},r={r}]")
+              tag=_lib.timing() and f"t2h_sample_fwd_relu[C={c2},r={r}]")
     return h
 
 
@@ -484,7 +484,7 @@ def _trunk_backward_fused(tile, pts, params, nets, pooled, hrs, winners, g_out):
     w_pos, b_pos, w_c, b_c = params[0], params[1], params[-2], params[-1]
     direct = _DIRECT_ACCUM and all(p.grad is not None and p.grad.is_contiguous() for p in params)
     grads = [None] * len(params)
-    ws_bytes = lib.t2h_trunk_block_bwd_workspace_bytes(m)
+    ws_bytes = _lib.ws_bytes("t2h_trunk_block_bwd_workspace_bytes", m)
     ws = _lib.workspace(ws_bytes, pts.device)            # reused by every block: launches are stream ordered
     dx_next = None
     for i in range(nb - 1, -1, -1):

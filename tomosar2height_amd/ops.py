@@ -134,10 +134,10 @@ class _RasteriseMean(torch.autograd.Function):
             raise ValueError(f"rasterise_mean: {n} feature rows for a tile of {tile.n_points} points")
         r = tile.R >> level
         plane = torch.empty(tile.B, r, r, c, dtype=torch.float32, device=feat.device)
-        ws_bytes = _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+        ws_bytes = _lib.ws_bytes("t2h_segmean_workspace_bytes", tile.B, tile.N, tile.nbits, level, c)
         ws = _lib.workspace(ws_bytes, feat.device)
         _lib.call("t2h_segmean_fwd", _lib.ptr(feat), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, level, c,
-                  _lib.ptr(plane), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(), tag=f"t2h_segmean_fwd[C={c},r={r}]")
+                  _lib.ptr(plane), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=4 * c * n + 4 * n + 4 * plane.numel(), tag=_lib.timing() and f"t2h_segmean_fwd[C={c},r={r}]")
         ctx.tile, ctx.level, ctx.c = tile, level, c
         return from_nhwc(plane, channels_last)
 
@@ -149,7 +149,7 @@ class _RasteriseMean(torch.autograd.Function):
         _lib.call("t2h_segmean_bwd", _lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
                   ctx.level, ctx.c, _lib.ptr(gfeat), _lib.stream(),
                   nbytes=4 * g.numel() + 4 * tile.n_points + 4 * g.numel() // ctx.c + 4 * ctx.c * tile.n_points,
-                  tag=f"t2h_segmean_bwd[C={ctx.c},r={g.shape[1]}]")
+                  tag=_lib.timing() and f"t2h_segmean_bwd[C={ctx.c},r={g.shape[1]}]")
         return gfeat, None, None, None
 
 
@@ -179,7 +179,7 @@ class _RasteriseMeanThru(torch.autograd.Function):
         _lib.call("t2h_segmean_bwd_add", _lib.ptr(g), _lib.ptr(tile.cell), _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
                   ctx.level, c, None if addend is None else _lib.ptr(addend), _lib.ptr(gfeat), _lib.stream(),
                   nbytes=4 * g.numel() + 4 * n + 4 * g.numel() // c + 4 * c * n * (2 if addend is not None else 1),
-                  tag=f"t2h_segmean_bwd[C={c},r={g.shape[1]}]")
+                  tag=_lib.timing() and f"t2h_segmean_bwd[C={c},r={g.shape[1]}]")
         return gfeat, None, None, None
 
 
@@ -213,13 +213,13 @@ def _sample_bwd(tile, gout, r, c, addend):
         offsets, entries = tile.sample_adjoint(level)
         _lib.call("t2h_sample_bwd_adjoint", _lib.ptr(gout), _lib.ptr(offsets), _lib.ptr(entries), tile.B, tile.nbits, level, c,
                   None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.stream(), nbytes=nbytes,
-                  tag=f"t2h_sample_bwd[C={c},r={r}]")
+                  tag=_lib.timing() and f"t2h_sample_bwd[C={c},r={r}]")
         return gplane
-    ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c)
+    ws_bytes = _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, level, c)
     ws = _lib.workspace(ws_bytes, gout.device)
     _lib.call("t2h_sample_bwd_add", _lib.ptr(gout), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
               tile.nbits, level, c, None if addend is None else _lib.ptr(addend), _lib.ptr(gplane), _lib.ptr(ws),
-              ws_bytes, _lib.stream(), nbytes=nbytes, tag=f"t2h_sample_bwd[C={c},r={r}]")
+              ws_bytes, _lib.stream(), nbytes=nbytes, tag=_lib.timing() and f"t2h_sample_bwd[C={c},r={r}]")
     return gplane
 
 
@@ -236,7 +236,7 @@ class _SamplePlane(torch.autograd.Function):
         out = torch.empty(tile.n_points, c, dtype=torch.float32, device=p.device)
         _lib.call("t2h_sample_fwd", _lib.ptr(p), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c, _lib.ptr(out),
                   _lib.stream(), nbytes=4 * c * tile.n_points + 8 * tile.n_points + 4 * p.numel(),
-                  tag=f"t2h_sample_fwd[C={c},r={r}]")
+                  tag=_lib.timing() and f"t2h_sample_fwd[C={c},r={r}]")
         ctx.tile, ctx.r, ctx.c = tile, r, c
         return out
 

@@ -30,7 +30,7 @@ class TileProducer:
         self._src = torch.empty(max(p, 1), dtype=torch.int32, device=dev)
         self._count = torch.zeros(1, dtype=torch.int32, device=dev)
         self._zshift = torch.zeros(1, dtype=torch.float64, device=dev)
-        self._ws_bytes = _lib.load().t2h_tile_crop_workspace_bytes(p)
+        self._ws_bytes = _lib.ws_bytes("t2h_tile_crop_workspace_bytes", p)
         self._ws = _lib.workspace(self._ws_bytes, dev)
 
     def crop(self, anchor, with_index: bool = False, rot_times: int = 0, flip_dim: int = -1):

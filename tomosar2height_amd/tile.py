@@ -47,7 +47,7 @@ class TileIndex:
         elif status.dtype != torch.int32 or status.numel() != 2 or status.device != dev:
             raise ValueError("status must be an int32 [2] tensor on the points' device")
         self.status = status
-        ws_bytes = lib.t2h_tile_workspace_bytes(self.B, self.N, self.nbits)
+        ws_bytes = _lib.ws_bytes("t2h_tile_workspace_bytes", self.B, self.N, self.nbits)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         _lib.call("t2h_tile_build", _lib.ptr(cloud), self.dim, self.B, self.N, self.nbits, _lib.ptr(self.pts),
                   _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0), _lib.ptr(self.status), _lib.ptr(ws),
