@@ -527,6 +527,16 @@ def main():
                      # depth limit paces the run) and CPU time of this process per step (Python + HIP runtime, all threads)
                      "host_issue_ms_per_step": round(1e3 * issue_s / n_sus, 3),
                      "host_cpu_ms_per_step": round(1e3 * issue_cpu_s / n_sus, 3)}
+        # what the host alone needs per tile-step: issue time of single steps onto an EMPTY queue (no back-pressure); well
+        # below ms_per_step = the run is GPU-bound and a rank needs that fraction of one core
+        lone = []
+        for _ in range(8):
+            fence()
+            th = time.perf_counter()
+            run(1)
+            lone.append(time.perf_counter() - th)
+        fence()
+        sustained["host_issue_ms_empty_queue"] = round(1e3 * statistics.median(lone), 3)
 
     # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
     timeline = None
