@@ -152,6 +152,13 @@ int t2h_mean_bias_fwd(const float *acc, const float *cnt, const float *cvec, int
 size_t t2h_mean_bias_bwd_workspace_bytes(int64_t P, int C);
 int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float *dacc, float *dcvec, void *workspace,
                       size_t workspace_bytes, t2h_stream_t stream);
+/* The forward of a deferred level at a coarse sampling resolution in ONE pass, with the hidden activations never leaving the
+ * chip: per (cell of the sampling level, 256-channel chunk) one wave stages the cell's 3 x 3 pixel neighbourhood in LDS, walks the
+ * cell's rows and emits the per-cell SUMS of relu(sample(plane)) at the finer resolution `sum_level` (into a column block with row
+ * stride ld_sums) and the packed sign bits (layout of t2h_sample_fwd_relu).  Bit-identical to t2h_sample_fwd_relu +
+ * t2h_segsum_fwd; for levels with many points per cell (the walk is sequential inside a cell).  C % 256 == 0. */
+int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                             int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits, t2h_stream_t stream);
 /* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */

@@ -174,3 +174,28 @@ def test_compose_stack_matches_matmul():
         assert ((got.to(D) - ref).abs().max() / ref.abs().max()).item() <= 2e-6, name
     first = deferred._ComposeStack.apply(None, wc.detach(), w1.detach())          # the base tensor's map is the identity
     assert torch.equal(first, torch.cat([wc.detach().t(), w1.detach().t()], 0))
+
+
+@pytest.mark.parametrize("c,r,sum_level", [(256, 64, 0), (1024, 32, 0), (512, 32, 1), (256, 32, 3)])
+def test_on_chip_hidden_activations_equal_the_two_kernel_form(c, r, sum_level):
+    """t2h_sample_relu_cellsums (hidden activations never written) == t2h_sample_fwd_relu + t2h_segsum_fwd, bit for bit: the
+    per-cell sums at `sum_level` inside a column block, and the packed sign bits."""
+    from tomosar2height_amd import _lib, deferred
+    tile = _tile(n=70000, batch=2)
+    g = torch.Generator().manual_seed(8)
+    q = torch.randn(tile.B, r, r, c, generator=g).to(_dev())
+    h = torch.empty(tile.n_points, c, device=_dev())
+    bits_ref = torch.zeros(tile.n_points * (c // 256) * 4, dtype=torch.int64, device=_dev())
+    _lib.call("t2h_sample_fwd_relu", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c, _lib.ptr(h),
+              _lib.ptr(bits_ref), _lib.stream())
+    rs = 256 >> sum_level
+    ktot, off = c + 64, 32
+    want = torch.full((tile.B * rs * rs, ktot), 3.0, device=_dev())
+    deferred._segsum_into(tile, h, sum_level, want[:, off:off + c])
+    got = torch.full((tile.B * rs * rs, ktot), 3.0, device=_dev())
+    bits = torch.zeros_like(bits_ref)
+    blk = got[:, off:off + c]
+    _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+              tile.nbits, tile.level(r), sum_level, c, blk.data_ptr(), blk.stride(0), _lib.ptr(bits), _lib.stream())
+    assert torch.equal(bits, bits_ref)
+    assert torch.equal(got, want)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "t2h_mean_bias_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "t2h_mean_bias_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "t2h_mean_bias_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_sample_relu_cellsums": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "t2h_sample_bwd_from_sums": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_fwd_relu": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

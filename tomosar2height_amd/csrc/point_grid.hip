@@ -601,6 +601,99 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
     }
 }
 
+// Hidden activations that never leave the chip (t2h_sample_relu_cellsums): for a coarse sampling level (many points per cell)
+// one WAVE owns (cell of the sampling level, 256-channel chunk).  It stages the 3 x 3 pixel neighbourhood of the cell -- every
+// tap of every point of the cell lies in it -- in LDS once (9 KB), then walks the cell's rows child by child (children = the
+// cells of the finest resolution the sums are needed at, contiguous row runs in Morton order): per row the taps, four LDS
+// reads, the same multiply-add chain as sample_fwd_kernel, ReLU, four ballots for the packed sign bits, and the running
+// per-child sum in registers, written when the child ends (empty children write zeros, so nothing is memset).  Out go the
+// per-cell sums (half the size of h at two points per finest cell) and 1 bit per element; h [N, C] itself is never written
+// or re-read.  Same bits as t2h_sample_fwd_relu + t2h_segsum_fwd: identical operation order per element and per sum.
+__global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *__restrict__ plane,
+                                                                 const float *__restrict__ pts, int dim,
+                                                                 const int32_t *__restrict__ off0, int nbits, int level,
+                                                                 int sum_level, int C, float *__restrict__ sums, int ld_sums,
+                                                                 unsigned long long *__restrict__ bits, int npts_m1) {
+    extern __shared__ float nb_lds[];                                   // [waves][9][256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.y * 4 + wave;
+    if (chunk * 256 >= C) return;                                       // (no workgroup barrier below)
+    float *T = nb_lds + wave * (9 * 256);
+    const int rbits = nbits - level, r = 1 << rbits;
+    const int64_t cellrow = blockIdx.x;
+    const int b = (int)(cellrow >> (2 * rbits));
+    const uint32_t mk = (uint32_t)(cellrow & (((int64_t)1 << (2 * rbits)) - 1));
+    const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    const int c0 = chunk * 256 + lane * 4;
+#pragma unroll
+    for (int sl = 0; sl < 9; ++sl) {
+        const int py = cy - 1 + sl / 3, px = cx - 1 + sl % 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)py < (unsigned)r && (unsigned)px < (unsigned)r)
+            v = *reinterpret_cast<const float4 *>(plane + (((size_t)b * r + py) * r + px) * C + c0);
+        *reinterpret_cast<float4 *>(T + sl * 256 + lane * 4) = v;
+    }
+    const int d = level - sum_level, nchild = 1 << (2 * d), rs = 1 << (nbits - sum_level);
+    const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    const int cpc = C >> 8;                                             // 256-channel chunks per row (bit words)
+    int nb0 = 0;                                                        // first row of the points currently held in (px_, py_)
+    float px_ = 0.f, py_ = 0.f;
+    bool have = false;
+    for (int cb = 0; cb < nchild; cb += 64) {                           // children in batches of 64: their row boundaries
+        const int ci = cb + lane;
+        const int bnd_lo = ci <= nchild ? off0[obase + ((size_t)ci << (2 * sum_level))] : 0;
+        const int bnd_hi = ci + 1 <= nchild ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
+        const int nc = min(64, nchild - cb);
+        for (int c = 0; c < nc; ++c) {
+            const int s = __shfl(bnd_lo, c), e = __shfl(bnd_hi, c);
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int n = s; n < e; ++n) {
+                if (!have || n >= nb0 + 64) {                           // the next 64 rows' coordinates, one per lane
+                    nb0 = n; have = true;
+                    const int nn = min(n + lane, npts_m1);                // rows past this cell belong to later cells: valid
+                    px_ = pts[(size_t)nn * dim + 0];
+                    py_ = pts[(size_t)nn * dim + 1];
+                }
+                const Taps tp = make_taps(__shfl(px_, n - nb0), __shfl(py_, n - nb0), r);
+                const float nw = __fmul_rn(tp.wx0, tp.wy0), ne = __fmul_rn(tp.wx1, tp.wy0);
+                const float sw = __fmul_rn(tp.wx0, tp.wy1), se = __fmul_rn(tp.wx1, tp.wy1);
+                const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                const int sy = min(max(tp.y0 - cy + 1, 0), 1), sx = min(max(tp.x0 - cx + 1, 0), 1);   // 0 or 1 by construction
+                const float *t00 = T + (sy * 3 + sx) * 256 + lane * 4;
+                const float4 v00 = *reinterpret_cast<const float4 *>(t00);
+                float4 a;
+                a.x = __fmul_rn(v00.x, nw); a.y = __fmul_rn(v00.y, nw); a.z = __fmul_rn(v00.z, nw); a.w = __fmul_rn(v00.w, nw);
+                if (x1ok) {
+                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 256);
+                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, ne));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, ne));
+                }
+                if (y1ok) {
+                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 3 * 256);
+                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, sw));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, sw));
+                }
+                if (x1ok && y1ok) {
+                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
+                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, se));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, se));
+                }
+                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
+                const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
+                if (lane == 0) {
+                    unsigned long long *dst = bits + ((size_t)n * cpc + chunk) * 4;
+                    dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+                }
+                sum.x += a.x; sum.y += a.y; sum.z += a.z; sum.w += a.w;
+            }
+            const uint32_t cm = (uint32_t)(cb + c);                      // child's Morton code inside the cell
+            const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
+            *reinterpret_cast<float4 *>(sums + (((size_t)b * rs + fy) * rs + fx) * ld_sums + c0) = sum;
+        }
+    }
+}
+
 // Deterministic backward: one group per pixel; a point of cell (cx,cy) only touches pixels
 // {cx-1..cx+1} x {cy-1..cy+1} (px = x*(r-1) lies in (cx-1, cx+1)), so pixel (px,py) gathers from the
 // 3x3 cells around it.  Cells are visited row-major, points in sorted order: a fixed summation order.
@@ -1545,6 +1638,24 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
           hipLaunchKernelGGL(sample_fwd_kernel<1>, dim3(grid_for(npts, g.lg)), dim3(kThreads), 0, as_stream(stream),
                              plane_nhwc, pts, dim, npts, N, r, C, g.lg, out); });
     return check_launch("sample_fwd");
+}
+
+T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
+                                     int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits,
+                                     t2h_stream_t stream) {
+    if (!plane_nhwc || !pts || !off0 || !sums_nhwc || !sign_bits) return fail(T2H_ERR_ARG, "sample_relu_cellsums: null pointer");
+    int rc = check_level("sample_relu_cellsums", B, nbits, level, C);
+    if (rc) return rc;
+    if (dim < 2 || N < 0 || sum_level < 0 || sum_level > level || C % 256 != 0 || ld_sums < C || ld_sums % 4 != 0 ||
+        ((uintptr_t)plane_nhwc & 15) || ((uintptr_t)sums_nhwc & 15) || ((uintptr_t)sign_bits & 15))
+        return fail(T2H_ERR_ARG, "sample_relu_cellsums: needs C %% 256 == 0, sum_level <= level, 16-byte aligned rows");
+    if ((int64_t)B * N == 0) return fail(T2H_ERR_ARG, "sample_relu_cellsums: empty tile");
+    const int64_t cells = (int64_t)B << (2 * (nbits - level));
+    const int chunks = C / 256, waves = chunks < 4 ? chunks : 4;
+    hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4), dim3(64 * waves),
+                       (size_t)waves * 9 * 256 * sizeof(float), as_stream(stream), plane_nhwc, pts, dim, off0, nbits, level,
+                       sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1));
+    return check_launch("sample_relu_cellsums");
 }
 
 T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,

@@ -33,6 +33,8 @@ DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
 FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
 CELLS_MFMA = os.environ.get("T2H_CELLS_MFMA", "1") != "0"                  # (mirrors the library's switch: the bit mask needs it)
 SIGN_BITS = os.environ.get("T2H_SIGN_BITS", "1") != "0"                    # A/B: 0 = keep the hidden activations for the mask
+ON_CHIP_HIDDEN = os.environ.get("T2H_ON_CHIP_HIDDEN", "1") != "0"          # A/B: 0 = sample kernel + per-cell sum kernel
+ON_CHIP_MIN_PTS_PER_CELL = float(os.environ.get("T2H_ON_CHIP_MIN_PTS", "16"))   # the walk is sequential inside a cell
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
@@ -153,21 +155,41 @@ class _DeferredLevel(torch.autograd.Function):
         tile = state.tile
         q_rows, a_all, const = q_rows.contiguous(), a_all.contiguous(), const.contiguous()
         c2 = q_rows.shape[1]
-        lv = state.levels_seq[idx]
         if idx == 0:
             state.write_sums(0, base_rows.contiguous())
+        bits_ok = (SIGN_BITS and c2 % 256 == 0 and FUSED_SAMPLE_BWD and CELLS_MFMA and tile.n_points > 0 and
+                   _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0)
+        if bits_ok and ON_CHIP_HIDDEN and tile.n_points >= ON_CHIP_MIN_PTS_PER_CELL * tile.B * r * r:
+            # coarse sampling level: interpolation, ReLU, sign bits and the per-cell sums of the finest needed resolution in one
+            # pass over the cells -- the hidden activations are never written to memory (t2h_sample_relu_cellsums)
+            bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
+            lo, hi = state.off[idx + 1], state.off[idx + 2]
+            levels = state.needed(idx + 1)
+            finest = state._matrix(state.S, levels[0])[:, lo:hi]
+            _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+                      tile.N, tile.nbits, tile.level(r), levels[0], c2, finest.data_ptr(), finest.stride(0), _lib.ptr(bits),
+                      _lib.stream(), nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0] + (c2 // 8) * tile.n_points,
+                      tag=_lib.timing() and f"t2h_sample_relu_cellsums[C={c2},r={r}]")
+            state.pool_down(idx + 1)
+            return _DeferredLevel._finish(ctx, state, idx, r, a_all, const, bits, True)
         h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
         # the backward needs only the sign pattern of h: where its fused form will run, keep 1 bit per element (written by the
         # sample kernel's ballots) and let h go after the per-cell sums -- 1/32 of the bytes to keep and to re-read
         bits = None
-        if (SIGN_BITS and c2 % 256 == 0 and FUSED_SAMPLE_BWD and CELLS_MFMA and
-                _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0):
+        if bits_ok:
             bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
                   None if bits is None else _lib.ptr(bits), _lib.stream(),
                   nbytes=4 * c2 * tile.n_points + 8 * tile.n_points + 4 * q_rows.numel() + (c2 // 8) * tile.n_points * (bits is not None),
                   tag=_lib.timing() and f"t2h_sample_fwd_relu[C={c2},r={r}]")
         state.write_sums(idx + 1, h)
+        return _DeferredLevel._finish(ctx, state, idx, r, a_all, const, h if bits is None else bits, bits is not None)
+
+    @staticmethod
+    def _finish(ctx, state, idx, r, a_all, const, saved_mask, mask_is_bits):
+        """The level's product over all sources' sums + the mean / empty-cell / bias epilogue; saves what the backward needs."""
+        tile = state.tile
+        lv = state.levels_seq[idx]
         k = state.off[idx + 2]                                             # columns of all sources that exist at this level
         if a_all.shape[0] != k:
             raise RuntimeError(f"deferred level {idx}: {a_all.shape[0]} composed rows for {k} source columns")
@@ -180,8 +202,8 @@ class _DeferredLevel(torch.autograd.Function):
                   _lib.stream(), nbytes=8 * acc.numel() + 4 * acc.shape[0])
         ctx.state, ctx.idx, ctx.r, ctx.has_base = state, idx, r, idx == 0
         ctx.const_shape = const.shape
-        ctx.mask_is_bits = bits is not None
-        ctx.save_for_backward(h if bits is None else bits, a_all)
+        ctx.mask_is_bits = mask_is_bits
+        ctx.save_for_backward(saved_mask, a_all)
         return out
 
     @staticmethod
@@ -261,11 +283,17 @@ class Deferred:
     def write_sums(self, src, rows):
         """Per-cell sums of ``rows`` [N, K_src] into the source's column block at every needed resolution: the finest from the
         rows (read once), the coarser ones by 2x2 pooling."""
+        lo, hi = self.off[src], self.off[src + 1]
+        levels = self.needed(src)
+        _segsum_into(self.tile, rows, levels[0], self._matrix(self.S, levels[0])[:, lo:hi])
+        self.pool_down(src)
+
+    def pool_down(self, src):
+        """The source's sums at its coarser needed resolutions from the (already written) finest one, by 2x2 pooling."""
         tile, (lo, hi) = self.tile, (self.off[src], self.off[src + 1])
         levels = self.needed(src)
         cur_level = levels[0]
         cur = self._matrix(self.S, cur_level)[:, lo:hi]
-        _segsum_into(tile, rows, cur_level, cur)
         for lv in levels[1:]:
             while cur_level < lv:
                 nxt_level = cur_level + 1
