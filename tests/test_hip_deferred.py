@@ -198,4 +198,8 @@ def test_on_chip_hidden_activations_equal_the_two_kernel_form(c, r, sum_level):
     _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
               tile.nbits, tile.level(r), sum_level, c, blk.data_ptr(), blk.stride(0), _lib.ptr(bits), _lib.stream())
     assert torch.equal(bits, bits_ref)
-    assert torch.equal(got, want)
+    if _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, sum_level, c) == 0:
+        assert torch.equal(got, want)             # the two-kernel form sums a cell's rows in sequence too: same bits
+    else:                                         # ... unless it takes the per-(cell, split) partials there: same sums, re-associated
+        assert torch.equal(got[:, :off], want[:, :off]) and torch.equal(got[:, off + c:], want[:, off + c:])
+        assert ((got - want).abs().max() / want.abs().max()).item() <= 2e-6
