@@ -636,8 +636,11 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
     const int d = level - sum_level, nchild = 1 << (2 * d), rs = 1 << (nbits - sum_level);
     const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
     const int cpc = C >> 8;                                             // 256-channel chunks per row (bit words)
-    int nb0 = 0;                                                        // first row of the points currently held in (px_, py_)
-    float px_ = 0.f, py_ = 0.f;
+    // the taps of 64 consecutive rows are computed lane-parallel (lane l = row nb0 + l) and handed to the row loop by
+    // readlane: ~40 instructions once per 64 rows instead of once per row and lane.  A tap outside the plane gets weight 0 and
+    // reads the staged zero (the sample kernel skips it: the same value)
+    int nb0 = 0, slot_l = 0;
+    float nw_l = 0.f, ne_l = 0.f, sw_l = 0.f, se_l = 0.f;
     bool have = false;
     for (int cb = 0; cb < nchild; cb += 64) {                           // children in batches of 64: their row boundaries
         const int ci = cb + lane;
@@ -648,36 +651,30 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
             const int s = __shfl(bnd_lo, c), e = __shfl(bnd_hi, c);
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int n = s; n < e; ++n) {
-                if (!have || n >= nb0 + 64) {                           // the next 64 rows' coordinates, one per lane
+                if (!have || n >= nb0 + 64) {
                     nb0 = n; have = true;
                     const int nn = min(n + lane, npts_m1);                // rows past this cell belong to later cells: valid
-                    px_ = pts[(size_t)nn * dim + 0];
-                    py_ = pts[(size_t)nn * dim + 1];
+                    const Taps tp = make_taps(pts[(size_t)nn * dim + 0], pts[(size_t)nn * dim + 1], r);
+                    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                    nw_l = __fmul_rn(tp.wx0, tp.wy0);
+                    ne_l = x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.f;
+                    sw_l = y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.f;
+                    se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
+                    slot_l = min(max(tp.y0 - cy + 1, 0), 1) * 3 + min(max(tp.x0 - cx + 1, 0), 1);     // 0 or 1 each by construction
                 }
-                const Taps tp = make_taps(__shfl(px_, n - nb0), __shfl(py_, n - nb0), r);
-                const float nw = __fmul_rn(tp.wx0, tp.wy0), ne = __fmul_rn(tp.wx1, tp.wy0);
-                const float sw = __fmul_rn(tp.wx0, tp.wy1), se = __fmul_rn(tp.wx1, tp.wy1);
-                const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
-                const int sy = min(max(tp.y0 - cy + 1, 0), 1), sx = min(max(tp.x0 - cx + 1, 0), 1);   // 0 or 1 by construction
-                const float *t00 = T + (sy * 3 + sx) * 256 + lane * 4;
-                const float4 v00 = *reinterpret_cast<const float4 *>(t00);
+                const int i = n - nb0;
+                const float nw = __shfl(nw_l, i), ne = __shfl(ne_l, i), sw = __shfl(sw_l, i), se = __shfl(se_l, i);
+                const float *t00 = T + __shfl(slot_l, i) * 256 + lane * 4;
+                const float4 v00 = *reinterpret_cast<const float4 *>(t00), v01 = *reinterpret_cast<const float4 *>(t00 + 256);
+                const float4 v10 = *reinterpret_cast<const float4 *>(t00 + 3 * 256), v11 = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
                 float4 a;
                 a.x = __fmul_rn(v00.x, nw); a.y = __fmul_rn(v00.y, nw); a.z = __fmul_rn(v00.z, nw); a.w = __fmul_rn(v00.w, nw);
-                if (x1ok) {
-                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 256);
-                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, ne));
-                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, ne));
-                }
-                if (y1ok) {
-                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 3 * 256);
-                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, sw));
-                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, sw));
-                }
-                if (x1ok && y1ok) {
-                    const float4 v = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
-                    a.x = __fadd_rn(a.x, __fmul_rn(v.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v.y, se));
-                    a.z = __fadd_rn(a.z, __fmul_rn(v.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v.w, se));
-                }
+                a.x = __fadd_rn(a.x, __fmul_rn(v01.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v01.y, ne));
+                a.z = __fadd_rn(a.z, __fmul_rn(v01.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v01.w, ne));
+                a.x = __fadd_rn(a.x, __fmul_rn(v10.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v10.y, sw));
+                a.z = __fadd_rn(a.z, __fmul_rn(v10.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v10.w, sw));
+                a.x = __fadd_rn(a.x, __fmul_rn(v11.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v11.y, se));
+                a.z = __fadd_rn(a.z, __fmul_rn(v11.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v11.w, se));
                 a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
                 const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
                 const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
