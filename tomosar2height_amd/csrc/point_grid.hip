@@ -650,7 +650,8 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
         for (int c = 0; c < nc; ++c) {
             const int s = __shfl(bnd_lo, c), e = __shfl(bnd_hi, c);
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int n = s; n < e; ++n) {
+            int n = s;
+            while (n < e) {
                 if (!have || n >= nb0 + 64) {
                     nb0 = n; have = true;
                     const int nn = min(n + lane, npts_m1);                // rows past this cell belong to later cells: valid
@@ -662,27 +663,40 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                     se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
                     slot_l = min(max(tp.y0 - cy + 1, 0), 1) * 3 + min(max(tp.x0 - cx + 1, 0), 1);     // 0 or 1 each by construction
                 }
-                const int i = n - nb0;
-                const float nw = __shfl(nw_l, i), ne = __shfl(ne_l, i), sw = __shfl(sw_l, i), se = __shfl(se_l, i);
-                const float *t00 = T + __shfl(slot_l, i) * 256 + lane * 4;
-                const float4 v00 = *reinterpret_cast<const float4 *>(t00), v01 = *reinterpret_cast<const float4 *>(t00 + 256);
-                const float4 v10 = *reinterpret_cast<const float4 *>(t00 + 3 * 256), v11 = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
-                float4 a;
-                a.x = __fmul_rn(v00.x, nw); a.y = __fmul_rn(v00.y, nw); a.z = __fmul_rn(v00.z, nw); a.w = __fmul_rn(v00.w, nw);
-                a.x = __fadd_rn(a.x, __fmul_rn(v01.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v01.y, ne));
-                a.z = __fadd_rn(a.z, __fmul_rn(v01.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v01.w, ne));
-                a.x = __fadd_rn(a.x, __fmul_rn(v10.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v10.y, sw));
-                a.z = __fadd_rn(a.z, __fmul_rn(v10.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v10.w, sw));
-                a.x = __fadd_rn(a.x, __fmul_rn(v11.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v11.y, se));
-                a.z = __fadd_rn(a.z, __fmul_rn(v11.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v11.w, se));
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
-                const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
-                if (lane == 0) {
-                    unsigned long long *dst = bits + ((size_t)n * cpc + chunk) * 4;
-                    dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+                const int i0 = n - nb0, cnt = min(e - n, 64 - i0);        // rows of this child inside the current batch
+                auto row = [&](int i, int nrow) -> float4 {
+                    const float nw = __shfl(nw_l, i), ne = __shfl(ne_l, i), sw = __shfl(sw_l, i), se = __shfl(se_l, i);
+                    const float *t00 = T + __shfl(slot_l, i) * 256 + lane * 4;
+                    const float4 v00 = *reinterpret_cast<const float4 *>(t00), v01 = *reinterpret_cast<const float4 *>(t00 + 256);
+                    const float4 v10 = *reinterpret_cast<const float4 *>(t00 + 3 * 256), v11 = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
+                    float4 a;
+                    a.x = __fmul_rn(v00.x, nw); a.y = __fmul_rn(v00.y, nw); a.z = __fmul_rn(v00.z, nw); a.w = __fmul_rn(v00.w, nw);
+                    a.x = __fadd_rn(a.x, __fmul_rn(v01.x, ne)); a.y = __fadd_rn(a.y, __fmul_rn(v01.y, ne));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v01.z, ne)); a.w = __fadd_rn(a.w, __fmul_rn(v01.w, ne));
+                    a.x = __fadd_rn(a.x, __fmul_rn(v10.x, sw)); a.y = __fadd_rn(a.y, __fmul_rn(v10.y, sw));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v10.z, sw)); a.w = __fadd_rn(a.w, __fmul_rn(v10.w, sw));
+                    a.x = __fadd_rn(a.x, __fmul_rn(v11.x, se)); a.y = __fadd_rn(a.y, __fmul_rn(v11.y, se));
+                    a.z = __fadd_rn(a.z, __fmul_rn(v11.z, se)); a.w = __fadd_rn(a.w, __fmul_rn(v11.w, se));
+                    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+                    const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
+                    const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
+                    if (lane == 0) {
+                        unsigned long long *dst = bits + ((size_t)nrow * cpc + chunk) * 4;
+                        dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+                    }
+                    return a;
+                };
+                int j = 0;
+                for (; j + 1 < cnt; j += 2) {                             // two rows in flight; summed in row order
+                    const float4 a0 = row(i0 + j, n + j), a1 = row(i0 + j + 1, n + j + 1);
+                    sum.x += a0.x; sum.y += a0.y; sum.z += a0.z; sum.w += a0.w;
+                    sum.x += a1.x; sum.y += a1.y; sum.z += a1.z; sum.w += a1.w;
                 }
-                sum.x += a.x; sum.y += a.y; sum.z += a.z; sum.w += a.w;
+                if (j < cnt) {
+                    const float4 a0 = row(i0 + j, n + j);
+                    sum.x += a0.x; sum.y += a0.y; sum.z += a0.z; sum.w += a0.w;
+                }
+                n += cnt;
             }
             const uint32_t cm = (uint32_t)(cb + c);                      // child's Morton code inside the cell
             const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
