@@ -642,11 +642,14 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
     int nb0 = 0, slot_l = 0;
     float nw_l = 0.f, ne_l = 0.f, sw_l = 0.f, se_l = 0.f;
     bool have = false;
-    for (int cb = 0; cb < nchild; cb += 64) {                           // children in batches of 64: their row boundaries
+    // blockIdx.z: this workgroup's share of the children (dense cells would otherwise set the kernel's duration: one wave
+    // walking 500+ rows while most of the chip has finished); the children's sums are independent, so nothing is reduced
+    const int per_group = nchild / (int)gridDim.z, child_lo = (int)blockIdx.z * per_group, child_hi = child_lo + per_group;
+    for (int cb = child_lo; cb < child_hi; cb += 64) {                  // children in batches of 64: their row boundaries
         const int ci = cb + lane;
-        const int bnd_lo = ci <= nchild ? off0[obase + ((size_t)ci << (2 * sum_level))] : 0;
-        const int bnd_hi = ci + 1 <= nchild ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
-        const int nc = min(64, nchild - cb);
+        const int bnd_lo = ci <= child_hi ? off0[obase + ((size_t)ci << (2 * sum_level))] : 0;
+        const int bnd_hi = ci + 1 <= child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
+        const int nc = min(64, child_hi - cb);
         for (int c = 0; c < nc; ++c) {
             const int s = __shfl(bnd_lo, c), e = __shfl(bnd_hi, c);
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1663,7 +1666,10 @@ T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, 
     if ((int64_t)B * N == 0) return fail(T2H_ERR_ARG, "sample_relu_cellsums: empty tile");
     const int64_t cells = (int64_t)B << (2 * (nbits - level));
     const int chunks = C / 256, waves = chunks < 4 ? chunks : 4;
-    hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4), dim3(64 * waves),
+    int groups = 1;                                                   // split the children until ~4096 workgroups exist
+    const int nchild = 1 << (2 * (level - sum_level));
+    while (groups < nchild && cells * ((chunks + 3) / 4) * groups < 4096) groups *= 2;
+    hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4, groups), dim3(64 * waves),
                        (size_t)waves * 9 * 256 * sizeof(float), as_stream(stream), plane_nhwc, pts, dim, off0, nbits, level,
                        sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1));
     return check_launch("sample_relu_cellsums");

@@ -34,7 +34,7 @@ FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B
 CELLS_MFMA = os.environ.get("T2H_CELLS_MFMA", "1") != "0"                  # (mirrors the library's switch: the bit mask needs it)
 SIGN_BITS = os.environ.get("T2H_SIGN_BITS", "1") != "0"                    # A/B: 0 = keep the hidden activations for the mask
 ON_CHIP_HIDDEN = os.environ.get("T2H_ON_CHIP_HIDDEN", "1") != "0"          # A/B: 0 = sample kernel + per-cell sum kernel
-ON_CHIP_MIN_PTS_PER_CELL = float(os.environ.get("T2H_ON_CHIP_MIN_PTS", "16"))   # the walk is sequential inside a cell
+ON_CHIP_MIN_PTS_PER_CELL = float(os.environ.get("T2H_ON_CHIP_MIN_PTS", "8"))   # the walk is sequential inside a cell
 
 
 # ------------------------------------------------------------------------------------------------ per-cell sums
