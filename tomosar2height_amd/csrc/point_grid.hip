@@ -1666,9 +1666,10 @@ T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, 
     if ((int64_t)B * N == 0) return fail(T2H_ERR_ARG, "sample_relu_cellsums: empty tile");
     const int64_t cells = (int64_t)B << (2 * (nbits - level));
     const int chunks = C / 256, waves = chunks < 4 ? chunks : 4;
-    int groups = 1;                                                   // split the children until ~4096 workgroups exist
+    int groups = 1;                                                   // split the children until ~8192 workgroups exist (4096: +10 us at r = 64; 16384: +18 us at r = 32)
     const int nchild = 1 << (2 * (level - sum_level));
-    while (groups < nchild && cells * ((chunks + 3) / 4) * groups < 4096) groups *= 2;
+    static const int min_wgs = [] { const char* e = getenv("T2H_ON_CHIP_MIN_WGS"); return e ? atoi(e) : 8192; }();
+    while (groups < nchild && cells * ((chunks + 3) / 4) * groups < min_wgs) groups *= 2;
     hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4, groups), dim3(64 * waves),
                        (size_t)waves * 9 * 256 * sizeof(float), as_stream(stream), plane_nhwc, pts, dim, off0, nbits, level,
                        sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1));
