@@ -18,7 +18,10 @@ def _rel(got, want):
 SHAPES = [(300, 8, 16), (257, 64, 32), (1000, 32, 32), (4096, 64, 128), (777, 128, 64), (3000, 256, 512),
           (2048, 512, 1024), (1500, 1024, 512), (129, 3, 64), (5000, 36, 20),
           # edges of the LDS-DMA staged forward kernel (N > 64, K % 16 == 0): one row, ragged row / column tiles, one slab
-          (1, 16, 128), (129, 48, 96), (500, 16, 200)]
+          (1, 16, 128), (129, 48, 96), (500, 16, 200),
+          # few rows, long reduction: the four waves of a workgroup split the reduction (gemm_kwaves_kernel); ragged last
+          # slab, ragged tiles, fewer slabs than waves
+          (1000, 300, 100), (1024, 1664, 512), (33, 260, 68), (640, 2432, 128)]
 
 
 @pytest.mark.parametrize("m,k,n", SHAPES)
@@ -84,6 +87,24 @@ def test_linear_wgrad(m, k, n, relu_in, accum):
     dw2, db2 = dw0.to(_dev()), db0.to(_dev())
     mlp.linear_wgrad_(dy.to(_dev()), x.to(_dev()), dw2, db2, relu_in=relu_in, accumulate=accum)
     assert torch.equal(dw2, dwd) and torch.equal(db2, dbd)
+
+
+@pytest.mark.parametrize("m,k,n", [(1024, 512, 1664), (4096, 256, 512), (1000, 300, 100), (16384, 128, 2432), (300, 68, 36)])
+@pytest.mark.parametrize("relu_in,accum", [(False, False), (True, True)])
+def test_linear_wgrad_without_bias_gradient(m, k, n, relu_in, accum):
+    """The grid-side products of the deferred point update ask for dW only (few rows: one launch whose waves split the rows)."""
+    from tomosar2height_amd import mlp
+    g = torch.Generator().manual_seed(m + k + n + 3)
+    dy, x, dw0 = torch.randn(m, n, generator=g), torch.randn(m, k, generator=g), torch.randn(n, k, generator=g)
+    want = dy.double().t() @ (x.double().clamp(min=0) if relu_in else x.double())
+    if accum:
+        want = want + dw0.double()
+    dwd = dw0.to(_dev())
+    mlp.linear_wgrad_(dy.to(_dev()), x.to(_dev()), dwd, None, relu_in=relu_in, accumulate=accum)
+    assert _rel(dwd, want) < 3e-5
+    dw2 = dw0.to(_dev())
+    mlp.linear_wgrad_(dy.to(_dev()), x.to(_dev()), dw2, None, relu_in=relu_in, accumulate=accum)
+    assert torch.equal(dw2, dwd)
 
 
 def test_a_equals_identity_asymmetric_b():

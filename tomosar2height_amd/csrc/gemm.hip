@@ -385,6 +385,99 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float *__restri
     }
 }
 
+// Few rows and a long reduction (the grid-side products of the deferred ALTO point update: 1024 .. 16384 pixel rows against
+// 256 .. 2560 stacked source columns): a workgroup per output tile walking the whole reduction is a chain of dependent
+// global -> LDS -> MFMA round trips with nothing to overlap them.  Here one workgroup = one 32 x 32 output tile and its four
+// waves split the reduction: wave w takes the 32-deep slabs w, w + 4, ... with its own double-buffered LDS pair (no
+// workgroup barrier in the loop), four times the loads in flight and a quarter of the chain.  The four partial tiles are
+// summed in wave order through LDS -- a fixed tree, deterministic -- and the usual epilogue (bias, mask, ReLU, accumulate,
+// addend) follows on 16 bytes per lane.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kwaves_kernel(GemmArgs p) {
+    constexpr int BK = 32, S = 32 + kPad, BUF = 2 * BK * S;          // floats per wave buffer: A slab, B slab
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned nb = gridDim.x * gridDim.y;
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q8 = nb / 8, r8 = nb % 8, x8 = b % 8, i8 = b / 8;
+    const unsigned t = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + i8;
+    const int tile_n = t % gridDim.x, tile_m = t / gridDim.x;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const bool relu_a = p.flags & F_RELU_A, relu_b = p.flags & F_RELU_B;
+    const int nk = (p.K + BK - 1) / BK;
+    float *mine = lds + wave * 2 * BUF;
+
+    TileLoader<32, 64, A_KC, BK> la;
+    TileLoader<32, 64, B_KC, BK> lb;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) acc[0][0][z] = 0.0f;
+    int kt = wave;
+    if (kt < nk) {
+        la.load(p.A, p.lda, m0, p.M, kt * BK, p.K, lane, relu_a);
+        lb.load(p.B, p.ldb, n0, p.N, kt * BK, p.K, lane, relu_b);
+        la.store(mine, lane);
+        lb.store(mine + BK * S, lane);
+    }
+    int cur = 0;
+    for (; kt < nk; kt += 4) {
+        const bool more = kt + 4 < nk;
+        if (more) {
+            la.load(p.A, p.lda, m0, p.M, (kt + 4) * BK, p.K, lane, relu_a);
+            lb.load(p.B, p.ldb, n0, p.N, (kt + 4) * BK, p.K, lane, relu_b);
+        }
+        __builtin_amdgcn_wave_barrier();       // LDS operations of one wave execute in order: its stores above are visible
+        const float *a_base = mine + cur * BUF + (lane >> 5) * S + (lane & 31);
+        mfma_slab_f32<1, 1, S, S, BK>(a_base, a_base + BK * S, acc);
+        if (more) {
+            la.store(mine + (cur ^ 1) * BUF, lane);
+            lb.store(mine + (cur ^ 1) * BUF + BK * S, lane);
+        }
+        cur ^= 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int EP = 36;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) mine[((z & 3) + 8 * (z >> 2) + 4 * (lane >> 5)) * EP + (lane & 31)] = acc[0][0][z];
+    __syncthreads();
+    const int row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
+    if (row >= p.M || col >= p.N) return;
+    float4 v = *reinterpret_cast<const float4 *>(lds + (tid >> 3) * EP + (tid & 7) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 u = *reinterpret_cast<const float4 *>(lds + w * 2 * BUF + (tid >> 3) * EP + (tid & 7) * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (p.mask) {
+        const float4 mk = *reinterpret_cast<const float4 *>(p.mask + (size_t)row * p.ldm + col);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    if (p.flags & F_RELU_OUT) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float4 *dst = reinterpret_cast<float4 *>(p.C + (size_t)row * p.ldc + col);
+    if (p.flags & F_ACCUM) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    if (p.addend) {
+        const float4 o = *reinterpret_cast<const float4 *>(p.addend + (size_t)row * p.ldadd + col);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *dst = v;
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm_kwaves(const GemmArgs &a, hipStream_t s, const char *what) {
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    if (grid.y > 65535) return fail(T2H_ERR_ARG, "%s: grid too large", what);
+    hipLaunchKernelGGL((gemm_kwaves_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+    note_kernel(!A_KC ? "gemm_kwaves_kernel<false,false>" : (B_KC ? "gemm_kwaves_kernel<true,true>" : "gemm_kwaves_kernel<true,false>"));
+    return check_launch(what);
+}
+// few output tiles (every CU would not even get one 64 x 64 tile's worth) and a reduction long enough to split
+static bool kwaves_applicable(long long rows, int cols, int depth) {
+    static const int min_k = [] { const char *e = getenv("T2H_KWAVES_MIN_K"); return e ? atoi(e) : 256; }();
+    static const long long max_tiles = [] { const char *e = getenv("T2H_KWAVES_MAX_TILES"); return e ? atoll(e) : 1024ll; }();
+    return depth >= min_k && ((rows + 31) / 32) * ((cols + 31) / 32) <= max_tiles;
+}
+
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int BK = 16, bool XCD = true, int MINW = 1, int MODE = 0>
 static int launch_gemm(const GemmArgs &a, int splits, hipStream_t s, const char *what) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splits);
@@ -423,7 +516,14 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
         if (t128 < 192) {
             const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-            if (t64 >= 192) return launch_gemm<64, 64, 2, 2, true, B_KC, 16, true, 1, 0>(a, 1, s, what);
+            static const int small_bk = [] { const char *e = getenv("T2H_SMALLM_BK"); return e ? atoi(e) : 64; }();
+            if (kwaves_applicable(a.M, a.N, a.K)) return launch_gemm_kwaves<true, B_KC>(a, s, what);
+            if (t64 >= 192) {
+                if (small_bk >= 32) return launch_gemm<64, 64, 2, 2, true, B_KC, 32, true, 1, 0>(a, 1, s, what);
+                return launch_gemm<64, 64, 2, 2, true, B_KC, 16, true, 1, 0>(a, 1, s, what);
+            }
+            if (small_bk >= 64) return launch_gemm<32, 32, 1, 1, true, B_KC, 64, true, 1, 0>(a, 1, s, what);
+            if (small_bk >= 32) return launch_gemm<32, 32, 1, 1, true, B_KC, 32, true, 1, 0>(a, 1, s, what);
             return launch_gemm<32, 32, 1, 1, true, B_KC, 16, true, 1, 0>(a, 1, s, what);
         }
     }
@@ -571,6 +671,15 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
         a.k_chunk = p.k_chunk; a.slab_stride = (long long)N * K;
         int rc;
         const int mode = mode_of(flags);
+        // the grid-side products of the deferred point update at r = 32 (1024 pixel rows, no bias gradient; 4096 rows and more: the
+        // split launch + slab reduction below is faster, 70 vs 87 us at [2176, 256]): one launch, the
+        // workgroup's four waves split the rows (gemm_kwaves_kernel), dW stored (or accumulated) directly
+        static const int kwaves_wgrad_max_rows = [] { const char *e = getenv("T2H_KWAVES_WGRAD_MAX_ROWS"); return e ? atoi(e) : 1024; }();
+        if (mode == 0 && !db && M <= kwaves_wgrad_max_rows && aligned4(dw, K) && kwaves_applicable(N, K, M)) {
+            a.C = dw; a.colsum = nullptr; a.k_chunk = M; a.slab_stride = 0;
+            if (accumulate) a.flags |= F_ACCUM;
+            return launch_gemm_kwaves<false, false>(a, s, "linear_wgrad");
+        }
 #define T2H_WG(BM_, BN_, WM_, WN_, MW_)                                                                                \
     (mode == 2 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 2 ? 2 : MW_), 2>(a, p.splits, s, "linear_wgrad") \
      : mode == 1 ? launch_gemm<BM_, BN_, WM_, WN_, false, false, 16, true, (MW_ > 3 ? 3 : MW_), 1>(a, p.splits, s, "linear_wgrad") \
