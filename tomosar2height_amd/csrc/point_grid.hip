@@ -1181,9 +1181,14 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                                                                              int level, int C, int S,
                                                                              float *__restrict__ partial, MultiPlanes mp,
                                                                              const int32_t *__restrict__ cell,
-                                                                             const float *__restrict__ mask) {
+                                                                             const float *__restrict__ mask, int tlevel) {
     __shared__ float Wl[kMfmaRows][16];
     __shared__ int Po[kMfmaRows][kMaxMultiPlanes];
+    // FUSED: the planes at level >= tlevel (at most 16 cells of that level inside this workgroup's cell) are summed ONCE per
+    // workgroup into this table -- entry t = child t (Morton order) of the cell at level tlevel -- so a row reads one LDS entry
+    // for them instead of one global row per plane (r = 32, four planes: 16 KB of L2 reads per row -> 4 KB + this table)
+    __shared__ float4 Tl[FUSED ? 16 : 1][FUSED ? 65 : 1];
+    __shared__ int Ti[kMfmaRows];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t cellrow = blockIdx.x;
     const int sp = blockIdx.y % S, chunk = blockIdx.y / S;
@@ -1198,6 +1203,26 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
     const int ch = chunk * cell_chunk_channels(C) + wave * 64 + 4 * (lane & 15);
     const bool active = ch < C;                            // uniform over the wave (C % 64 == 0)
     const int kq = lane >> 4;                              // this lane's row inside a 4-row MFMA step
+    if (FUSED && tlevel >= 0 && lo < hi) {
+        const int tb = 2 * (level - tlevel), nT = 1 << tb;
+        for (int e = tid; e < nT * 64; e += kCellThreads) {
+            const int t = e >> 6, c4 = e & 63, che = chunk * cell_chunk_channels(C) + c4 * 4;
+            if (che < C) {
+                const uint32_t mt = (mk << tb) | (uint32_t)t;                // Morton code of the child at level tlevel
+                const uint32_t tx = compact1by1(mt), ty = compact1by1(mt >> 1);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < kMaxMultiPlanes; ++q)
+                    if (q < mp.n && mp.level[q] >= tlevel) {
+                        const int l = mp.level[q], rq = 1 << (nbits - l), sh = l - tlevel;
+                        const float4 w = *reinterpret_cast<const float4 *>(
+                            mp.g[q] + (((size_t)b * rq + (ty >> sh)) * rq + (tx >> sh)) * mp.ld[q] + che);
+                        v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
+                    }
+                Tl[t][c4] = v;
+            }
+        }
+    }
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1237,6 +1262,7 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                         const int l = mp.level[q], rq = 1 << (nbits - l);
                         Po[tid][q] = (int)((fb * rq + (fy >> l)) * rq + (fx >> l));
                     }
+                if (tlevel >= 0) Ti[tid] = (int)((fm >> (2 * tlevel)) & ((1u << (2 * (level - tlevel))) - 1u));
             }
         }
         __syncthreads();
@@ -1267,13 +1293,24 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                         } else {
                             hm = *reinterpret_cast<const float4 *>(mask + (size_t)n * C + ch);
                         }
-                        float4 v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * mp.ld[0] + ch);
+                        float4 v;
+                        if (tlevel >= 0) {          // coarse planes from the table, the finer ones (level < tlevel) per row
+                            v = Tl[Ti[rr]][wave * 16 + (lane & 15)];
 #pragma unroll
-                        for (int q = 1; q < kMaxMultiPlanes; ++q)
-                            if (q < mp.n) {
-                                const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * mp.ld[q] + ch);
-                                v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
-                            }
+                            for (int q = 0; q < kMaxMultiPlanes; ++q)
+                                if (q < mp.n && mp.level[q] < tlevel) {
+                                    const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * mp.ld[q] + ch);
+                                    v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
+                                }
+                        } else {
+                            v = *reinterpret_cast<const float4 *>(mp.g[0] + (size_t)Po[rr][0] * mp.ld[0] + ch);
+#pragma unroll
+                            for (int q = 1; q < kMaxMultiPlanes; ++q)
+                                if (q < mp.n) {
+                                    const float4 w = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)Po[rr][q] * mp.ld[q] + ch);
+                                    v.x = __fadd_rn(v.x, w.x); v.y = __fadd_rn(v.y, w.y); v.z = __fadd_rn(v.z, w.z); v.w = __fadd_rn(v.w, w.w);
+                                }
+                        }
                         v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
                         v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
                         g[u] = v;
@@ -1299,6 +1336,184 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
             const int m = 4 * kq + i;
             if (m < 9) *reinterpret_cast<float4 *>(pbase + (size_t)m * C + ch) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
         }
+    }
+}
+
+// ---- t2h_sample_bwd_from_sums with packed sign bits: the backward twin of sample_relu_cellsums_kernel -----------------------
+// One WAVE walks a contiguous run of the finest cells ("children", level wl) of ONE sampling cell for a 256-channel chunk,
+// lane l = channels 4 l .. 4 l + 3.  Per child the gathered gradient G = sum_q plane_q[parent_q(child)] is formed once (all
+// rows of a child share it; the next child's plane rows are requested while this child's rows run); per row the four tap
+// weights, the slot of the north-west tap and the four 64-bit sign words are computed / loaded lane-parallel for 64 rows at a
+// time and handed to the row by readlane, the sign words ARE lane masks (v_cndmask with an SGPR pair: no bit arithmetic), and
+// the row is added to the wave's 9 register accumulators (3 x 3 pixel neighbourhood of the cell) with its nine slot weights,
+// five of them zero (a wave-uniform switch over the four tap positions instead makes the compiler copy the accumulator set
+// between the cases: 256 VGPRs).  Nothing per row touches LDS or waits for global memory.
+//   K = 0: the four waves of a workgroup share the sampling cell (a quarter of its children each -- a dense cell's 500 rows
+//          would otherwise be one serial wave) and add their 9 slots in wave order through LDS;
+//   K = 1: the workgroup is a 2 x 2 block of sampling cells, one per wave, added in wave order into the 4 x 4 neighbourhood
+//          of the block -- 16 slots per 4 cells written and re-read instead of 36 (r = 128: 8 rows per cell on average).
+// Fixed orders everywhere => deterministic.  Row values: fma(w, g, acc) with g = G or 0.
+__device__ inline float keep_if(unsigned long long lanes, float v) {      // lane l: v if bit l of the wave-uniform mask, else 0
+    float o;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(lanes));
+    return o;
+}
+__device__ inline float readlane_f(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), i);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline void fma4(float4 &a, float w, const float4 &g) {
+    a.x = __fmaf_rn(w, g.x, a.x); a.y = __fmaf_rn(w, g.y, a.y); a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
+}
+
+constexpr int kWalkPlanes = 4;       // (more planes: the matrix-core kernel)
+template <int K>
+__global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__restrict__ pts, int dim,
+                                                            const int32_t *__restrict__ off0, int nbits, int level, int wl,
+                                                            int C, float *__restrict__ partial, MultiPlanes mp,
+                                                            const unsigned long long *__restrict__ bits, int npts_m1) {
+    constexpr int SIDE = 3 + K, NS = SIDE * SIDE;
+    __shared__ float4 NB[NS][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.y, c0 = chunk * 256 + lane * 4, cpc = C >> 8;
+    const int rbits = nbits - level, r = 1 << rbits, sbits = rbits - K;
+    const int64_t wg = blockIdx.x;                                    // Morton index (batch-major) of the cell at level + K
+    const int b = (int)(wg >> (2 * sbits));
+    const uint32_t smk = (uint32_t)(wg & (((int64_t)1 << (2 * sbits)) - 1));
+    const int d = level - wl, nchild = 1 << (2 * d);
+    const uint32_t mk = K == 0 ? smk : ((smk << 2) | (uint32_t)wave);
+    const int child_lo = K == 0 ? wave * (nchild >> 2) : 0, child_hi = K == 0 ? child_lo + (nchild >> 2) : nchild;
+    const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    for (int e = tid; e < NS * 64; e += 256) NB[e >> 6][e & 63] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the plane rows of a child, requested (raw) ahead of their use; a coarser plane's row is shared by 4, 16, .. consecutive
+    // children and requested only when it changes
+    float4 raw[kWalkPlanes];
+    int held[kWalkPlanes];
+#pragma unroll
+    for (int q = 0; q < kWalkPlanes; ++q) held[q] = -1;
+    auto request = [&](int child) {
+        const uint32_t cm = (uint32_t)child;
+        const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
+#pragma unroll
+        for (int q = 0; q < kWalkPlanes; ++q)
+            if (q < mp.n) {
+                const int sh = mp.level[q] - wl, rq = 1 << (nbits - mp.level[q]);
+                const int row = (b * rq + (fy >> sh)) * rq + (fx >> sh);
+                if (row != held[q]) {
+                    held[q] = row;
+                    raw[q] = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)row * mp.ld[q] + c0);
+                }
+            }
+    };
+    int nb0 = 0;
+    float w9_l[9];                               // lane i: the nine slot weights of row nb0 + i (five of them 0)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) w9_l[q] = 0.f;
+    unsigned long long w0_l = 0, w1_l = 0, w2_l = 0, w3_l = 0;
+    bool have = false;
+    for (int cb = child_lo; cb < child_hi; cb += 64) {
+        const int ci = cb + lane;
+        const int bnd_lo = ci < child_hi ? off0[obase + ((size_t)ci << (2 * wl))] : 0;
+        const int bnd_hi = ci < child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * wl))] : 0;
+        unsigned long long todo = __ballot(bnd_hi > bnd_lo);             // the non-empty children of this batch
+        if (todo) request(cb + (int)__builtin_ctzll(todo));
+        while (todo) {
+            const int c = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int s = __builtin_amdgcn_readlane(bnd_lo, c), e = __builtin_amdgcn_readlane(bnd_hi, c);
+            float4 G = raw[0];
+#pragma unroll
+            for (int q = 1; q < kWalkPlanes; ++q)
+                if (q < mp.n) { G.x = __fadd_rn(G.x, raw[q].x); G.y = __fadd_rn(G.y, raw[q].y); G.z = __fadd_rn(G.z, raw[q].z); G.w = __fadd_rn(G.w, raw[q].w); }
+            if (todo) request(cb + (int)__builtin_ctzll(todo));          // the next child's rows, under this child's work
+            int n = s;
+            while (n < e) {
+                if (!have || n >= nb0 + 64) {
+                    nb0 = n; have = true;
+                    const int nn = min(n + lane, npts_m1);
+                    const Taps tp = make_taps(pts[(size_t)nn * dim + 0], pts[(size_t)nn * dim + 1], r);
+                    const int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;        // slot column / row of the north-west tap: 0 or 1
+#pragma unroll
+                    for (int sy = 0; sy < 3; ++sy) {
+                        const float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
+#pragma unroll
+                        for (int sx = 0; sx < 3; ++sx) {
+                            const float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
+                            w9_l[sy * 3 + sx] = __fmul_rn(wx, wy);
+                        }
+                    }
+                    const ulonglong2 *bw = reinterpret_cast<const ulonglong2 *>(bits + ((size_t)nn * cpc + chunk) * 4);
+                    const ulonglong2 b01 = bw[0], b23 = bw[1];
+                    w0_l = b01.x; w1_l = b01.y; w2_l = b23.x; w3_l = b23.y;
+                }
+                const int i0 = n - nb0, cnt = min(e - n, 64 - i0);
+                for (int j = 0; j < cnt; ++j) {
+                    const int i = i0 + j;
+                    float4 g;
+                    g.x = keep_if(readlane_u64(w0_l, i), G.x); g.y = keep_if(readlane_u64(w1_l, i), G.y);
+                    g.z = keep_if(readlane_u64(w2_l, i), G.z); g.w = keep_if(readlane_u64(w3_l, i), G.w);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) fma4(acc[q], readlane_f(w9_l[q], i), g);
+                }
+                n += cnt;
+            }
+        }
+    }
+    // the four waves add their neighbourhoods in wave order
+    const int qx = K ? (wave & 1) : 0, qy = K ? (wave >> 1) : 0;
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int sl = 0; sl < 9; ++sl) {
+                float4 &t = NB[(sl / 3 + qy) * SIDE + sl % 3 + qx][lane];
+                float4 v = t;
+                v.x += acc[sl].x; v.y += acc[sl].y; v.z += acc[sl].z; v.w += acc[sl].w;
+                t = v;
+            }
+        }
+    }
+    __syncthreads();
+    float *pbase = partial + (size_t)wg * NS * C + chunk * 256;
+    for (int e = tid; e < NS * 64; e += 256)
+        *reinterpret_cast<float4 *>(pbase + (size_t)(e >> 6) * C + (e & 63) * 4) = NB[e >> 6][e & 63];
+}
+
+// stage 2 for K = 1: pixel (px, py) takes its slot from the (up to) four 2 x 2 cell blocks whose 4 x 4 windows hold it
+__global__ __launch_bounds__(kThreads) void sample_bwd_gather4_kernel(const float *__restrict__ partial, int B, int rbits,
+                                                                     int C, int lg, float *__restrict__ gplane) {
+    int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    int64_t gid = t >> lg;
+    const int r = 1 << rbits, rs = r >> 1;
+    if (gid >= (int64_t)B * r * r) return;
+    const int b = (int)(gid >> (2 * rbits));
+    const int py = (int)((gid >> rbits) & (r - 1)), px = (int)(gid & (r - 1));
+    const int X = px >> 1, Y = py >> 1;
+    const int X2 = (px & 1) ? X + 1 : X - 1, Y2 = (py & 1) ? Y + 1 : Y - 1;
+    const int xs[2] = {min(X, X2), max(X, X2)}, ys[2] = {min(Y, Y2), max(Y, Y2)};
+    for (int c = ((int)t & ((1 << lg) - 1)) * 4; c < C; c += 4 << lg) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const int bx = xs[ix], by = ys[iy];
+                if ((unsigned)bx < (unsigned)rs && (unsigned)by < (unsigned)rs) {
+                    const size_t blk = ((size_t)b << (2 * (rbits - 1))) + morton2((uint32_t)bx, (uint32_t)by);
+                    const int slot = (py - (2 * by - 1)) * 4 + (px - (2 * bx - 1));
+                    const float4 u = *reinterpret_cast<const float4 *>(partial + (blk * 16 + slot) * C + c);
+                    acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+                }
+            }
+        *reinterpret_cast<float4 *>(gplane + (((size_t)b * r + py) * r + px) * C + c) = acc;
     }
 }
 
@@ -1707,12 +1922,52 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     int64_t groups = (int64_t)B << (2 * (nbits - level));
     float *partial = static_cast<float *>(workspace);
     int G = 1 << cp.lgG, P = kCellThreads >> cp.lgG;
+    // table level of the matrix-core kernel: two levels finer than the sampling level (16 entries), not finer than the
+    // finest plane; -1 (no table) when no plane would go into it or the rows per workgroup would not repay building it
+    static const int table_on = getenv("T2H_CELLS_TABLE") ? atoi(getenv("T2H_CELLS_TABLE")) : 1;
+    int tlevel = -1;
+    if (table_on && C % 256 == 0) {
+        int finest = nbits;
+        for (int q = 0; q < n_planes; ++q) finest = levels[q] < finest ? levels[q] : finest;
+        int tl = level - 2 > finest ? level - 2 : finest;
+        if (tl < 0) tl = 0;
+        if (tl > level) tl = level;
+        const int64_t entries = (int64_t)1 << (2 * (level - tl));
+        int folded = 0;
+        for (int q = 0; q < n_planes; ++q) folded += levels[q] >= tl;
+        // rows per workgroup (average) against table entries: build when it replaces more row loads than it costs
+        const int64_t rows_per_wg = (int64_t)B * N / (groups * cp.S > 0 ? groups * cp.S : 1);
+        if (folded > 0 && rows_per_wg * table_on >= entries) tlevel = tl;
+    }
+    static const int walk_on = getenv("T2H_CELLS_WALK") ? atoi(getenv("T2H_CELLS_WALK")) : 1;
+    if (mask_is_bits && walk_on && level >= 1 && nbits - level >= 1 && n_planes <= kWalkPlanes) {
+        // walk level: the finest plane's cells, and at least one level below the sampling level (the waves split children)
+        int wl = level - 1;
+        for (int q = 0; q < n_planes; ++q) wl = levels[q] < wl ? levels[q] : wl;
+        // few rows per sampling cell: one workgroup per 2 x 2 block of cells (walk_on == 2 / 3 force one of the forms)
+        const bool blocks = walk_on == 3 || (walk_on == 1 && (int64_t)B * N < 64 * groups);
+        const unsigned long long *bw = static_cast<const unsigned long long *>(mask);
+        const int npts_m1 = (int)((int64_t)B * N - 1);
+        GroupCfg g = group_cfg<4>(C);
+        if (blocks) {
+            hipLaunchKernelGGL(sample_bwd_walk_kernel<1>, dim3((unsigned)(groups >> 2), C / 256), dim3(256), 0, as_stream(stream), pts,
+                               dim, off0, nbits, level, wl, C, partial, mp, bw, npts_m1);
+            hipLaunchKernelGGL(sample_bwd_gather4_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream), partial,
+                               B, nbits - level, C, g.lg, gplane_nhwc);
+        } else {
+            hipLaunchKernelGGL(sample_bwd_walk_kernel<0>, dim3((unsigned)groups, C / 256), dim3(256), 0, as_stream(stream), pts, dim,
+                               off0, nbits, level, wl, C, partial, mp, bw, npts_m1);
+            hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream), partial,
+                               B, nbits - level, C, g.lg, 1, nullptr, gplane_nhwc);
+        }
+        return check_launch("sample_bwd_from_sums(walk)");
+    }
     if (mask_is_bits)
         hipLaunchKernelGGL((sample_bwd_cells_mfma_kernel<true, true>), dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel);
     else if (cells_mfma(C))
         hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel);
     else
         hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                            (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
@@ -1766,7 +2021,7 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
         if (cells_mfma(C))
             hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
                                as_stream(stream), gout, pts, dim, off0, nbits, level, C, cp.S, partial, MultiPlanes{}, nullptr,
-                               nullptr);
+                               nullptr, -1);
         else
             hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                                (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
