@@ -497,6 +497,11 @@ template <bool B_KC, int MODE>
 static int launch_rows_p(const GemmArgs &a, hipStream_t s, const char *what) {
     constexpr int MW = MODE == 0 ? 4 : (MODE == 1 ? 3 : 2);     // register budget: 128 / 168 / 256 per lane
     if (a.N > 64) return launch_gemm<128, 128, 2, 2, true, B_KC, 16, true, MW, MODE>(a, 1, s, what);
+    // 33 .. 64 output columns from a long reduction (the level products of the deferred point update at r = 256: 65536 pixel
+    // rows x 2560 stacked columns -> 64): the A operand is streamed once, so smaller row tiles = more workgroups in flight
+    // (64 x 64 x 32: 222 -> 207 us; 64-deep slabs or 32-row tiles: 262 / 332 us)
+    static const bool skinny = !(getenv("T2H_SKINNY") && getenv("T2H_SKINNY")[0] == '0');
+    if (MODE == 0 && a.N > 32 && a.K >= 512 && skinny) return launch_gemm<64, 64, 2, 2, true, B_KC, 32, true, 1, 0>(a, 1, s, what);
     if (a.N > 32) return launch_gemm<128, 64, 2, 2, true, B_KC, 16, true, 1, MODE>(a, 1, s, what);
     return launch_gemm<128, 32, 4, 1, true, B_KC, 16, true, 1, MODE>(a, 1, s, what);
 }
