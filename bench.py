@@ -44,7 +44,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
 # its own: the segmented max / its backward run in the loaders of the fused trunk block kernels (csrc/trunk.hip)
 # r03: with the deferred point update (deferred.py) the wide scatter_means run as per-cell SUMS of the hidden activations
 # (t2h_segsum_fwd at the finest resolution + 2x2 pooling) and their joint backward
-SCATTER_REDUCE_TAGS = ("t2h_segsum_fwd[C=1024,r=256]", "t2h_segsum_fwd[C=512,r=256]", "t2h_segmean_fwd[C=512,r=32]",
+# (since r03y the coarse levels' sums are formed on chip by t2h_sample_relu_cellsums, backward t2h_sample_bwd_from_sums)
+SCATTER_REDUCE_TAGS = ("t2h_sample_relu_cellsums[C=1024,r=32]", "t2h_sample_bwd_from_sums[C=1024,r=32]",
+                       "t2h_segsum_fwd[C=1024,r=256]", "t2h_segsum_fwd[C=512,r=256]", "t2h_segmean_fwd[C=512,r=32]",
                        "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]", "t2h_pool_max_fwd", "t2h_pool_max_bwd")
 
 

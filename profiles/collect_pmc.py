@@ -23,14 +23,45 @@ import json
 import os
 import re
 
-PROBE_OPS = {   # bench.py tag -> kernel-name substrings of one launch of the op, in the probe's order
-    "t2h_segmean_fwd[C=512,r=32]": ["segmean_cells_kernel", "segmean_finalize_kernel"],
-    "t2h_sample_fwd[C=512,r=32]": ["sample_fwd_kernel"],
-    "t2h_sample_bwd[C=512,r=32]": ["sample_bwd_cells_", "sample_bwd_gather9_kernel"],
+REPS = 3        # profiles/pmc_probe.py launches every group this many times in a row
+# the probe's launches in order: groups of (bench.py tag, kernel-name substrings of one launch of the op); ops that share a
+# kernel symbol (the pixel gather of both sample adjoints) are told apart by their position in the dispatch sequence
+PROBE_GROUPS = [
+    [("t2h_segmean_fwd[C=512,r=32]", ["segmean_cells_kernel", "segmean_finalize_kernel"])],
+    [("t2h_sample_fwd[C=512,r=32]", ["sample_fwd_kernel"]),
+     ("t2h_sample_bwd[C=512,r=32]", ["sample_bwd_cells_", "sample_bwd_gather9_kernel"])],
     # r03, deferred point update: per-cell sums of the widest hidden activations at the finest resolution
-    "t2h_segsum_fwd[C=1024,r=256]": ["segmean_fwd_kernel<4, false>"],
-    "t2h_segsum_bwd_multi[C=1024,n=4]": ["segsum_bwd_multi_kernel"],
-}
+    [("t2h_segsum_fwd[C=1024,r=256]", ["segmean_fwd_kernel<4, false>"])],
+    [("t2h_segsum_bwd_multi[C=1024,n=4]", ["segsum_bwd_multi_kernel"])],
+    # r03, hidden activations on chip: sample + ReLU + per-cell sums + sign bits; the backward walk + its pixel gather
+    [("t2h_sample_relu_cellsums[C=1024,r=32]", ["sample_relu_cellsums_kernel"])],
+    [("t2h_sample_bwd_from_sums[C=1024,r=32]", ["sample_bwd_walk_kernel", "sample_bwd_gather9_kernel"])],
+]
+
+
+def probe_sequence(rows):
+    """Walk the probe's dispatches in order -> {tag: [mean counter value per part]} (None where the sequence does not match)."""
+    out, i = {}, 0
+    for group in PROBE_GROUPS:
+        acc = {tag: [0.0] * len(parts) for tag, parts in group}
+        ok = True
+        for _ in range(REPS):
+            for tag, parts in group:
+                for j, sub in enumerate(parts):
+                    while i < len(rows) and sub not in rows[i]["Kernel_Name"]:
+                        i += 1
+                    if i >= len(rows):
+                        ok = False
+                        break
+                    acc[tag][j] += float(rows[i]["Counter_Value"]) / REPS
+                    i += 1
+        for tag, _ in group:
+            out[tag] = acc[tag] if ok else None
+        if not ok:
+            break
+    return out
+
+
 # entry points of point_grid.hip do not note a kernel symbol: bench.py keys them by entry-point name
 ENTRY_OF = {"sample_fwd_kernel": "t2h_sample_fwd", "segmean_bwd_kernel": "t2h_segmean_bwd"}
 
@@ -85,20 +116,15 @@ def main():
                 if k.split("<")[0] in ENTRY_OF:
                     out[ENTRY_OF[k.split("<")[0]]] = out[k]
     if a.probe:
-        fr, wr = rows_of(a.probe[0], "FETCH_SIZE"), rows_of(a.probe[1], "WRITE_SIZE")
-        f, _ = mean_by(fr, lambda n: n)
-        w, _ = mean_by(wr, lambda n: n)
-        for tag, parts in PROBE_OPS.items():
-            total, rows = 0.0, []
-            for sub in parts:
-                kf, kw = [k for k in f if sub in k], [k for k in w if sub in k]
-                if not kf or not kw:
-                    total = None
-                    break
-                rows.append({"kernel": sub, "FETCH_SIZE_KiB": round(f[kf[0]], 1), "WRITE_SIZE_KiB": round(w[kw[0]], 1)})
-                total += (2.0 * f[kf[0]] + w[kw[0]]) * 1024.0
-            if total is not None:
-                out[tag] = int(total)
+        f = probe_sequence(rows_of(a.probe[0], "FETCH_SIZE"))
+        w = probe_sequence(rows_of(a.probe[1], "WRITE_SIZE"))
+        for group in PROBE_GROUPS:
+            for tag, parts in group:
+                if f.get(tag) is None or w.get(tag) is None:
+                    continue
+                rows = [{"kernel": sub, "FETCH_SIZE_KiB": round(f[tag][j], 1), "WRITE_SIZE_KiB": round(w[tag][j], 1)}
+                        for j, sub in enumerate(parts)]
+                out[tag] = int(sum((2.0 * f[tag][j] + w[tag][j]) * 1024.0 for j in range(len(parts))))
                 detail[tag] = {"parts": rows, "source": "profiles/pmc_probe.py"}
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "pmc_traffic.json"), "w") as fjs:

@@ -38,5 +38,24 @@ for _ in range(REPS):
 grads = [(torch.randn_like(p), lv) for lv, p in planes.items()]
 for _ in range(REPS):
     deferred._gather(tile, grads, 1024, mask=x1024)          # segsum_bwd_multi_kernel<4>
+# r03: the hidden activations that stay on chip -- interpolation + ReLU + per-cell sums + sign bits in one pass over the cells
+# (t2h_sample_relu_cellsums), and its backward twin (t2h_sample_bwd_from_sums, walk form), widest level: 1024 x 32^2
+from tomosar2height_amd import _lib                           # noqa: E402
+import ctypes                                                 # noqa: E402
+q = torch.randn(32 * 32, 1024, device=dev)
+sums = torch.empty(256 * 256, 1024, device=dev)
+bits = torch.empty(M * 4 * 4, dtype=torch.int64, device=dev)
+lv32 = tile.level(32)
+for _ in range(REPS):
+    _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+              tile.nbits, lv32, 0, 1024, sums.data_ptr(), sums.stride(0), _lib.ptr(bits), _lib.stream())
+arr, lvs, lds = deferred._plane_args(grads)
+ws_bytes = _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, lv32, 1024)
+ws = _lib.workspace(ws_bytes, dev)
+dq = torch.empty(32 * 32, 1024, device=dev)
+for _ in range(REPS):
+    _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(grads), _lib.ptr(tile.cell), _lib.ptr(bits), 1, _lib.ptr(tile.pts),
+              tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, lv32, 1024, _lib.ptr(dq), _lib.ptr(ws), ws_bytes,
+              _lib.stream())
 torch.cuda.synchronize()
 print("pmc_probe done")
