@@ -192,8 +192,9 @@ int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, in
  * [B, r, r, 2C] plane P W0^T + b0; where N >> r^2 this replaces an [N, C] x [C, 2C] product by an [r^2, C] x [C, 2C] one. */
 int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                         void *sign_bits, t2h_stream_t stream);
-/* `sign_bits` (may be NULL; C % 256 == 0): the pattern out > 0 packed 1 bit per element, [B*N][C / 256][4] 64-bit words, bit l of
- * word j <=> channel 256 q + 4 l + j -- all the backward needs of the hidden activations (t2h_sample_bwd_from_sums with
+/* `sign_bits` (may be NULL; C % 256 == 0): the pattern out > 0 packed 1 bit per element, [C / 256][B*N][4] 64-bit words (chunk-
+ * major: the rows of a 256-channel chunk q are consecutive 32-byte records), bit l of word j <=> channel 256 q + 4 l + j -- all
+ * the backward needs of the hidden activations (t2h_sample_bwd_from_sums with
  * mask_is_bits = 1 reads 32 B instead of 1 KB per row and chunk, and the activations need not be kept for the backward). */
 size_t t2h_sample_bwd_workspace_bytes(int B, int N, int nbits, int level, int C);
 int t2h_sample_bwd(const float *gout, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,

@@ -47,11 +47,11 @@ def test_sample_relu_and_sign_bits(c, r):
               None if bits is None else _lib.ptr(bits), _lib.stream())
     assert torch.equal(h, want)
     if bits is not None:
-        w = bits.view(tile.n_points, c // 256, 4).cpu().numpy().view(np.uint64)
+        w = bits.view(c // 256, tile.n_points, 4).cpu().numpy().view(np.uint64)       # chunk-major: [C / 256][rows][4]
         got = np.zeros((tile.n_points, c), bool)
         for j in range(4):
             for lane in range(64):
-                got[:, lane * 4 + j::256] = ((w[:, :, j] >> np.uint64(lane)) & np.uint64(1)).astype(bool)
+                got[:, lane * 4 + j::256] = ((w[:, :, j].T >> np.uint64(lane)) & np.uint64(1)).astype(bool)
         assert np.array_equal(got, (h > 0).cpu().numpy())
 
 

@@ -542,8 +542,10 @@ __device__ inline Taps make_taps(float x01, float y01, int r) {
 // RELU: out = max(sample, 0) -- the hidden layer of fc_comm when its first Linear was applied on the grid
 // (t2h_sample_fwd_relu)
 // `bits` (RELU, VEC = 4, C % 256 == 0 only; may be null): the sign pattern of the result packed 1 bit per element -- for
-// row n and 256-channel chunk q four 64-bit words, bit l of word j <=> out[n][256 q + 4 l + j] > 0 -- which is all the backward
-// needs of the hidden activations (32 B instead of 1 KB per row and chunk; t2h_sample_bwd_from_sums reads it)
+// row n and 256-channel chunk q four 64-bit words at [q][n][4] (chunk-major: the rows of a chunk are consecutive 32-byte
+// records, so the per-row stores of a wave fill whole cache lines and 64 rows load as one coalesced 2 KB run), bit l of word
+// j <=> out[n][256 q + 4 l + j] > 0 -- which is all the backward needs of the hidden activations (32 B instead of 1 KB per
+// row and chunk; t2h_sample_bwd_from_sums reads it)
 template <int VEC, bool RELU = false>
 __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__restrict__ plane,
                                                               const float *__restrict__ pts, int dim, int64_t npts,
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = __ballot(acc.v[j] > 0.0f);
                 if ((threadIdx.x & 63) == 0) {
-                    unsigned long long *dst = bits + ((size_t)n * (C >> 8) + (c >> 8)) * 4;
+                    unsigned long long *dst = bits + ((size_t)(c >> 8) * npts + n) * 4;
                     dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
                 }
             }
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                     const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
                     const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
                     if (lane == 0) {
-                        unsigned long long *dst = bits + ((size_t)nrow * cpc + chunk) * 4;
+                        unsigned long long *dst = bits + ((size_t)chunk * ((size_t)npts_m1 + 1) + nrow) * 4;
                         dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
                     }
                     return a;
@@ -1181,7 +1183,8 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                                                                              int level, int C, int S,
                                                                              float *__restrict__ partial, MultiPlanes mp,
                                                                              const int32_t *__restrict__ cell,
-                                                                             const float *__restrict__ mask, int tlevel) {
+                                                                             const float *__restrict__ mask, int tlevel,
+                                                                             size_t npts) {
     __shared__ float Wl[kMfmaRows][16];
     __shared__ int Po[kMfmaRows][kMaxMultiPlanes];
     // FUSED: the planes at level >= tlevel (at most 16 cells of that level inside this workgroup's cell) are summed ONCE per
@@ -1282,7 +1285,7 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
                         float4 hm;
                         if (BITS) {            // packed sign bits (sample_fwd_kernel): 32 B per row and 256-channel chunk
                             const uint4 *bw = reinterpret_cast<const uint4 *>(
-                                reinterpret_cast<const unsigned long long *>(mask) + ((size_t)n * (C >> 8) + (ch >> 8)) * 4);
+                                reinterpret_cast<const unsigned long long *>(mask) + ((size_t)(ch >> 8) * npts + n) * 4);
                             const uint4 b01 = bw[0], b23 = bw[1];
                             const int li = (ch & 255) >> 2;
                             const unsigned int s0 = li < 32 ? b01.x : b01.y, s1 = li < 32 ? b01.z : b01.w;
@@ -1449,7 +1452,7 @@ __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__res
                             w9_l[sy * 3 + sx] = __fmul_rn(wx, wy);
                         }
                     }
-                    const ulonglong2 *bw = reinterpret_cast<const ulonglong2 *>(bits + ((size_t)nn * cpc + chunk) * 4);
+                    const ulonglong2 *bw = reinterpret_cast<const ulonglong2 *>(bits + ((size_t)chunk * ((size_t)npts_m1 + 1) + nn) * 4);
                     const ulonglong2 b01 = bw[0], b23 = bw[1];
                     w0_l = b01.x; w1_l = b01.y; w2_l = b23.x; w3_l = b23.y;
                 }
@@ -1964,10 +1967,10 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     }
     if (mask_is_bits)
         hipLaunchKernelGGL((sample_bwd_cells_mfma_kernel<true, true>), dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)B * N);
     else if (cells_mfma(C))
         hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)B * N);
     else
         hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                            (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
@@ -2021,7 +2024,7 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
         if (cells_mfma(C))
             hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
                                as_stream(stream), gout, pts, dim, off0, nbits, level, C, cp.S, partial, MultiPlanes{}, nullptr,
-                               nullptr, -1);
+                               nullptr, -1, (size_t)B * N);
         else
             hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                                (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
