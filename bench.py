@@ -64,6 +64,9 @@ def parse():
                     help="untimed tile-steps with per-launch HIP events after the timed region (0 = no kernel table)")
     ap.add_argument("--kernel-table", default=os.path.join("gpurun_out", "bench_kernels.json"),
                     help="where rank 0 writes the full per-kernel table (never printed: the stdout line stays compact)")
+    ap.add_argument("--tile-prefetch", type=int, default=0,
+                    help="build the next tile's point index on a side stream during the current step (Trainer.prepare); "
+                         "measured slower (12.20 vs 11.97 ms: like every two-stream overlap tried on this stack), so off")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=8, help="intra-op threads of the headline CPU baseline "
                                                                 "(reference default: conf/config.yaml:20-21, train.py:77-78)")
@@ -447,16 +450,30 @@ def main():
 
     state = {"i": 0, "optimizer_steps": 0, "points": 0}
 
+    tile_stream = torch.cuda.Stream() if (args.tile_prefetch and args.mode == "train" and not args.hip_graph) else None
+
     def next_tile():
+        if tile_stream is None:
+            return raw_tile()
+        # the index of tile i (cell sort, sampling adjoint, counts) was built on a side stream while step i - 1 ran; build
+        # tile i + 1's now, before step i is issued (Trainer.prepare): every tile's index is still built once per step
+        ready = state.pop("indexed", None)
+        if ready is None:
+            ready = trainer.prepare(raw_tile(), tile_stream)
+        state["indexed"] = trainer.prepare(raw_tile(), tile_stream)
+        return ready
+
+    def raw_tile():
+        j = state["j"] = state.get("j", -1) + 1                       # raw tiles handed out so far
         if source is None:
-            return tiles[state["i"] % len(tiles)]
+            return tiles[j % len(tiles)]
         if not args.producer_prefetch:
-            t = source.get(anchors[state["i"] % len(anchors)])
+            t = source.get(anchors[j % len(anchors)])
         else:
-            # tile i was produced (on the producer's side stream) while step i - 1 ran; produce tile i + 1 now, before step i
-            # is issued, so that its crop runs beside the steps in flight and its host read does not wait for them
-            t = state.pop("pending", None) or source.get(anchors[state["i"] % len(anchors)])
-            state["pending"] = source.get(anchors[(state["i"] + 1) % len(anchors)])
+            # tile j was produced (on the producer's side stream) while the previous step ran; produce tile j + 1 now, before
+            # the next step is issued, so that its crop runs beside the steps in flight and its host read does not wait
+            t = state.pop("pending", None) or source.get(anchors[j % len(anchors)])
+            state["pending"] = source.get(anchors[(j + 1) % len(anchors)])
         state["points"] += t["inputs"].shape[1]
         return t
 

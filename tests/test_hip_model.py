@@ -590,3 +590,35 @@ def test_side_stream_wgrad_overlap_gives_identical_gradients():
     for k in a:
         scale = a[k].abs().max().item() + 1e-12
         assert (a[k] - b[k]).abs().max().item() <= 1e-4 * scale, k
+
+
+def test_tile_index_built_ahead_on_a_side_stream_gives_the_same_step():
+    """``Trainer.prepare`` builds the next tile's index (cell sort, sampling adjoint, cell counts) on a side stream while the
+    current step runs; the step on the prebuilt index is the step on the raw cloud, bit for bit (same kernels, same order)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.tile import TileIndex
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    tiles = [{"inputs": synth_cloud(40000, seed=700 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(4)]
+
+    def run(ahead):
+        model = det_init_(TomoSAR2Height(cfg), seed=15).to(_dev())
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=100, use_cloud=True)
+        side = torch.cuda.Stream() if ahead else None
+        nxt = tr.prepare(tiles[0], side) if ahead else tiles[0]
+        for i in range(len(tiles)):
+            cur = nxt
+            if i + 1 < len(tiles):
+                nxt = tr.prepare(tiles[i + 1], side) if ahead else tiles[i + 1]       # issued before step i
+            assert isinstance(cur["inputs"], TileIndex) == ahead
+            tr.train_step(cur)
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, float(tr.accumulated_loss)
+
+    (a, la), (b, lb) = run(False), run(True)
+    assert la == lb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

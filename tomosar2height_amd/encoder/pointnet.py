@@ -62,9 +62,19 @@ class LocalPoolPointnet(nn.Module):
         """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max- (or mean-) pools, fc_c."""
         return mlp.point_trunk(tile, tile.pts, self.fc_pos, self.blocks, self.fc_c, self.scatter_type)
 
+    def prepare(self, inputs: torch.Tensor, stream=None) -> TileIndex:
+        """Build the index of a tile ahead of its step, on ``stream`` (see ``TileIndex.prebuild``)."""
+        return TileIndex.prebuild(inputs, self.reso_plane, status=self.domain_status, stream=stream)
+
     def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``."""
-        tile = TileIndex(inputs, self.reso_plane, status=self.domain_status)
+        """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``.  ``inputs`` may also be the tile's index built
+        ahead of the step (``TileIndex.prebuild`` / ``prepare``)."""
+        if isinstance(inputs, TileIndex):
+            if inputs.R != self.reso_plane:
+                raise ValueError(f"prebuilt TileIndex has resolution {inputs.R}, the encoder {self.reso_plane}")
+            tile = inputs.wait_ready()
+        else:
+            tile = TileIndex(inputs, self.reso_plane, status=self.domain_status)
         if self.check_domain:
             tile.check_domain()
         net = self.point_features(tile)

@@ -75,6 +75,52 @@ class TileIndex:
     def n_points(self) -> int:
         return self.B * self.N
 
+    # -------------------------------------------------------------------------------------- built ahead of its step
+    @classmethod
+    def prebuild(cls, cloud: torch.Tensor, plane_resolution: int, status: torch.Tensor = None, stream=None):
+        """The index of the NEXT tile, built on ``stream`` (a side stream) while the current tile's step runs: the sort, the
+        sampling adjoint of the finest level (when the sample backward will take it) and the per-cell point counts are a
+        handful of small, latency-bound kernels (~150 us at N = 131072) that leave the chip idle when they run alone at the
+        head of a step.  Pass the result where the ``[B, N, 3]`` cloud would go (``LocalPoolPointnet.forward``); the consumer
+        waits for ``ready`` on its own stream.  Same kernels, same results as building inside the step."""
+        if stream is None:
+            return cls(cloud, plane_resolution, status=status)
+        main = torch.cuda.current_stream(cloud.device)
+        stream.wait_stream(main)                                   # the cloud was produced on the caller's stream
+        with torch.cuda.stream(stream):
+            tile = cls(cloud, plane_resolution, status=status)
+            from . import ops, deferred
+            if ops.SAMPLE_ADJOINT and 0 < tile.n_points <= ops.SAMPLE_ADJOINT_MAX_ROWS * tile.B * tile.R * tile.R:
+                tile.sample_adjoint(0)
+            for lv in range(min(4, tile.nbits)):
+                deferred.counts(tile, lv)
+            tile.ready = torch.cuda.Event()
+            tile.ready.record(stream)
+        cloud.record_stream(stream)
+        for t in tile._tensors():
+            t.record_stream(main)                                  # allocated on the side stream, read on the main one
+        return tile
+
+    def _tensors(self):
+        out = [self.pts, self.perm, self.cell, self.off0]
+        for offsets, entries in self._adjoint.values():
+            out += [offsets, entries]
+        out += list(self.__dict__.get("_cell_counts", {}).values())
+        return out
+
+    def wait_ready(self):
+        """Make the current stream wait for a prebuilt index (no-op for one built in stream order)."""
+        ev = self.__dict__.pop("ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return self
+
+    def to(self, device=None, *args, **kwargs):
+        """Where a cloud tensor would be moved to the model's device: the index already lives there."""
+        if device is not None and torch.device(device).type != self.device.type:
+            raise ValueError("a TileIndex cannot be moved between devices")
+        return self
+
     def level(self, reso: int) -> int:
         """ALTO level k whose plane resolution is ``reso`` (= R >> k)."""
         k = self.nbits - _log2_exact(int(reso))

@@ -157,7 +157,21 @@ class Trainer:
         g = getattr(self, "_graph", None)
         if g is None:
             return False
-        return all(data.get(k) is not None and tuple(data[k].shape) == shp for k, shp in g["shapes"].items())
+        return all(data.get(k) is not None and tuple(getattr(data[k], "shape", ())) == shp for k, shp in g["shapes"].items())
+
+    # ------------------------------------------------------------------------------------------ input pipeline
+    def prepare(self, data, stream=None):
+        """Build the point index of the NEXT tile (cell sort, sampling adjoint, cell counts) ahead of its ``train_step``, on
+        ``stream`` -- a side stream, so these small latency-bound kernels run beside the current tile's step instead of alone
+        at the head of the next one.  Returns ``data`` with the cloud replaced by the prebuilt ``TileIndex``; results are the
+        same as for the raw cloud.  (HIP model with a point encoder only; anything else is returned unchanged.)"""
+        enc = getattr(self.model, "point_encoder", None)
+        cloud = data.get("inputs") if self.use_cloud else None
+        if enc is None or not hasattr(enc, "prepare") or not torch.is_tensor(cloud):
+            return data
+        out = dict(data)
+        out["inputs"] = enc.prepare(cloud.to(self.device), stream=stream)
+        return out
 
     # ------------------------------------------------------------------------------------------ train
     def train_step(self, data) -> bool:
