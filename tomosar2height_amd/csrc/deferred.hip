@@ -41,12 +41,19 @@ __global__ __launch_bounds__(256) void mean_bias_fwd_kernel(const float *__restr
     reinterpret_cast<float4 *>(out)[t] = o;
 }
 
-constexpr int kMbRows = 64;      // rows per workgroup of the backward: its column sums go to one slab row
+// rows per workgroup of the backward (its column sums go to one slab row): 64, more for long matrices so that at most 256
+// slab rows are left for the second stage -- one workgroup per 64 columns sums them, a chain of `slabs / 64` dependent loads
+// (65536 rows x 64 columns: 1024 slabs of 64 rows made that chain the whole cost, 19 of 22 us)
+static int mb_rows(int64_t P) {
+    int64_t r = (P + 255) / 256;
+    r = (r + 63) / 64 * 64;
+    return (int)(r < 64 ? 64 : (r > 4096 ? 4096 : r));
+}
 // dacc = g / max(cnt, 1); slab[blockIdx.x][:] = sum over this block's non-empty rows of g.  Threads: C / 4 float4 columns x
 // `slots` row slots (rows dealt round-robin); the slots are combined through LDS in slot order -> a fixed summation order.
 __global__ __launch_bounds__(256) void mean_bias_bwd_kernel(const float *__restrict__ g, const float *__restrict__ cnt,
                                                            int64_t P, int C, float *__restrict__ dacc,
-                                                           float *__restrict__ slab) {
+                                                           float *__restrict__ slab, int kMbRows) {
     __shared__ float4 red[256];
     const int C4 = C / 4;
     const int cols = min(C4, 256), slots = 256 / cols;
@@ -111,6 +118,7 @@ T2H_API int t2h_mean_bias_fwd(const float *acc, const float *cnt, const float *c
 
 T2H_API size_t t2h_mean_bias_bwd_workspace_bytes(int64_t P, int C) {
     if (P < 1 || C < 1) return 0;
+    const int kMbRows = mb_rows(P);
     return (size_t)((P + kMbRows - 1) / kMbRows) * C * sizeof(float);
 }
 
@@ -123,9 +131,10 @@ T2H_API int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C
     if (dcvec && (!workspace || workspace_bytes < need || !al16(workspace)))
         return fail(T2H_ERR_WORKSPACE, "mean_bias_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     if (!dacc && !dcvec) return T2H_OK;
+    const int kMbRows = mb_rows(P);
     const int blocks = (int)((P + kMbRows - 1) / kMbRows);
     float *slab = dcvec ? static_cast<float *>(workspace) : nullptr;
-    hipLaunchKernelGGL(mean_bias_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), g, cnt, P, C, dacc, slab);
+    hipLaunchKernelGGL(mean_bias_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), g, cnt, P, C, dacc, slab, kMbRows);
     if (int rc = check_launch("mean_bias_bwd")) return rc;
     if (!dcvec) return T2H_OK;
     return launch_reduce_slabs(slab, blocks, C, 1, C, C, 0, dcvec, nullptr, nullptr, as_stream(stream));
