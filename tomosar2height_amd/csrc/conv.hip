@@ -508,7 +508,9 @@ WgradPlan wgrad_plan_for(long long P, int rows, int ncols) {
     // planes up to 128 x 128 (short reductions): 512 workgroups beat the full resident wave by 3-12 % (128->128 at 128^2:
     // 70 -> 61 us, 256->256 at 64^2: 70 -> 63) -- half the slabs to write and reduce, twice the main loop per epilogue;
     // from 256 x 256 up 1024 stays (512: +4-9 % slower there; 2048 wins or loses by shape within +-5 %)
-    const long long target = P <= 16384 ? 512 : 1024;
+    // (T2H_CONV_WGRAD_WGS: the A/B of DESIGN.md section 4 -- fewer workgroups = fewer split slabs = less traffic, more time)
+    static const long long forced = getenv("T2H_CONV_WGRAD_WGS") ? atoll(getenv("T2H_CONV_WGRAD_WGS")) : 0;
+    const long long target = forced > 0 ? forced : (P <= 16384 ? 512 : 1024);
     long long want = target / tiles;       // <= 1024 workgroups = one resident wave; 1025 would leave one running alone
                                          // (measured: 64->128 at 512^2, 5 tiles: 464 us with 1025 workgroups, 390 with 1020)
     if (want > 512) want = 512;
