@@ -114,6 +114,7 @@ class _ComposeStack(torch.autograd.Function):
         _transpose(w1_c, out[rows_prev:])                                      # [C_k, 2 C_k] -> [2 C_k, C_k]
         ctx.has_prev = a_prev is not None
         ctx.rows_prev = rows_prev
+        ctx.wc_param = wc                                  # (the parameter itself: mlp._wgrad looks at its .grad)
         ctx.save_for_backward(a_prev if a_prev is not None else wc_c, wc_c)
         return out
 
@@ -127,8 +128,7 @@ class _ComposeStack(torch.autograd.Function):
         if ctx.has_prev:
             if ctx.needs_input_grad[0]:
                 da = mlp.linear_dgrad_(gp, wc, torch.empty_like(a_prev))       # gp Wc
-            dwc = torch.empty_like(wc)
-            mlp.linear_wgrad_(gp, a_prev, dwc, None)                           # gp^T A_{k-1}
+            dwc, _ = mlp._wgrad(gp, a_prev, ctx.wc_param, None)                # gp^T A_{k-1} (straight into wc.grad where allowed)
         else:
             dwc = torch.empty_like(wc)
             _transpose(gp, dwc)
@@ -204,10 +204,12 @@ class _DeferredLevel(torch.autograd.Function):
         ctx.const_shape = const.shape
         ctx.mask_is_bits = mask_is_bits
         ctx.save_for_backward(saved_mask, a_all)
-        return out
+        # second output: the composed maps themselves for the next level's compose product -- its gradient then arrives HERE and
+        # this level's own share is accumulated into it by the weight-gradient kernel (no autograd add over [K, C])
+        return out, a_all.as_strided(a_all.size(), a_all.stride(), a_all.storage_offset())
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, ga_thru):
         h, a_all = ctx.saved_tensors
         state, idx, r = ctx.state, ctx.idx, ctx.r
         tile = state.tile
@@ -224,10 +226,15 @@ class _DeferredLevel(torch.autograd.Function):
         _lib.call("t2h_mean_bias_bwd", _lib.ptr(g), _lib.ptr(cnt), p, c, _lib.ptr(dacc), None if dconst is None else _lib.ptr(dconst),
                   _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=8 * p * c + 4 * p)
         x = state.S[lv][:, :k]
-        da = None
+        da = ga_thru
         if ctx.needs_input_grad[1]:
-            da = torch.empty_like(a_all)
-            mlp.linear_wgrad_(x, dacc, da, None)                           # x^T dacc
+            if ga_thru is not None and ga_thru.is_contiguous() and ga_thru.dtype == torch.float32:
+                mlp.linear_wgrad_(x, dacc, ga_thru, None, accumulate=True)  # x^T dacc, onto the next level's share
+            else:
+                da = torch.empty_like(a_all)
+                mlp.linear_wgrad_(x, dacc, da, None)                       # x^T dacc
+                if ga_thru is not None:
+                    da = da + ga_thru
         # into the gradient matrix of this resolution: the leading k columns; a later level of the same resolution (run before,
         # more columns) has initialised them already -> accumulate
         dS, seen = state.grad_matrix(lv)
@@ -336,8 +343,12 @@ class Deferred:
             self.const = (bc + b1).reshape(1, -1)
         else:
             self.const = mlp.linear(self.const, wc, bc) + b1.reshape(1, -1)   # const_k = const_{k-1} Wc_k^T + bc_k + b1_k
-        raster = _DeferredLevel.apply(q_rows, self.a_all, self.const, self.base if idx == 0 else None, self, idx, r)
+        raster, self.a_all = _DeferredLevel.apply(q_rows, self.a_all, self.const, self.base if idx == 0 else None, self, idx, r)
         self.n_done += 1
+        if self.n_done == len(self.levels_seq):
+            # last level: nobody composes further.  (Also breaks the cycle state -> a_all -> its autograd node -> state, which
+            # would leave the sum matrices of every step to the cyclic garbage collector.)
+            self.a_all = self.const = None
         return raster
 
 

@@ -82,8 +82,8 @@ class _PointGridLevel(nn.Module):
             else:
                 res, chs = later_res
                 state = deferred.Deferred(tile, [tile.level(x) for x in res], chs, c_last)
-            rows = plane.permute(0, 2, 3, 1).reshape(-1, ch)                      # the pixels as rows (a view if channels_last)
-            q = mlp.linear(rows, fa.weight, fa.bias)                              # fc_comm.0 on the pixels (alto.py:123)
+            # fc_comm.0 on the pixels (alto.py:123); the returned plane is the input plane for its further consumers
+            q, plane = mlp.linear_plane_thru(plane, fa.weight, fa.bias)
             raster = state.advance(q, r, fb, self.fc_c).reshape(plane.shape[0], r, r, ch).permute(0, 3, 1, 2)
             return (raster if self.channels_last else raster.contiguous()), state, plane
         if mlp.grid_first_applicable(tile, r, ch):

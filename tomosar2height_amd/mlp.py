@@ -237,6 +237,59 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return y.reshape(*lead, weight.shape[0])
 
 
+def _join_plane_grad(dy, w, gthru, shape_nhwc, was_cl):
+    """dplane = dy w (rows -> the NHWC plane) + gthru: the gradient of the plane's other consumers joins inside the data-gradient
+    kernel (accumulating epilogue) where it arrives as a dense NHWC tensor -- it was produced for this node alone (the autograd
+    engine hands a node the only reference to its summed input gradient) --, else by one add."""
+    from . import ops
+    b, r1, r2, c = shape_nhwc
+    if gthru is not None and gthru.dtype == torch.float32 and gthru.permute(0, 2, 3, 1).is_contiguous() and was_cl:
+        linear_dgrad_(dy, w, gthru.permute(0, 2, 3, 1).reshape(b * r1 * r2, c), accumulate=True)
+        return gthru
+    drows = linear_dgrad_(dy, w, torch.empty(b * r1 * r2, c, dtype=torch.float32, device=dy.device))
+    dplane = drows.reshape(b, r1, r2, c)
+    if gthru is not None:
+        dplane = dplane + ops.to_nhwc(gthru)
+    return ops.from_nhwc(dplane, was_cl)
+
+
+class _LinearPlaneThru(torch.autograd.Function):
+    """``(q, plane)``: q [B H W, N] = the pixels of ``plane`` [B, C, H, W] as rows through an nn.Linear (fc_comm.0 applied on the
+    grid, deferred.py); the second output is the plane itself for its other consumers, whose gradient joins this node's
+    inside its data-gradient kernel instead of by an autograd add over the plane."""
+
+    @staticmethod
+    def forward(ctx, plane, w, bias):
+        from . import ops
+        ctx.was_cl = ops._is_channels_last(plane)
+        p = ops.to_nhwc(plane)
+        _lib.require_device(p, what="linear_plane_thru")
+        b, h, wd, c = p.shape
+        rows = p.reshape(b * h * wd, c)
+        q = _empty(rows.shape[0], w.shape[0], rows)
+        linear_fwd_(rows, w, bias, q)
+        ctx.shape = (b, h, wd, c)
+        ctx.save_for_backward(rows, w, bias)
+        return q, ops._alias(plane)
+
+    @staticmethod
+    def backward(ctx, gq, gthru):
+        rows, w, bias = ctx.saved_tensors
+        if gq is None:
+            return gthru, None, None
+        gq = gq.contiguous()
+        dplane = gthru
+        if ctx.needs_input_grad[0]:
+            dplane = _join_plane_grad(gq, w, gthru, ctx.shape, ctx.was_cl)
+        dw, db = _wgrad(gq, rows, w, bias)
+        return dplane, dw, db
+
+
+def linear_plane_thru(plane, weight, bias):
+    """-> (q rows [B H W, N], plane): use the returned plane for every further consumer of the input plane."""
+    return _LinearPlaneThru.apply(plane, weight, bias)
+
+
 # ------------------------------------------------------------------------------------------------ ResnetBlockFC
 def _resblock_fwd(x, w0, b0, w1, b1, ws, out):
     """out (a [M, Cout] view) = shortcut(x) + fc_1(relu(fc_0(relu(x)))); returns Hr = relu(fc_0(relu(x)))."""
@@ -395,11 +448,7 @@ class _CommMLPGridFirst(torch.autograd.Function):
         dwa, dba = _wgrad(dq, rows, wa, ba)                                     # column sums of dq == of dh (taps sum to 1)
         dplane = None
         if ctx.needs_input_grad[0]:
-            drows = linear_dgrad_(dq, wa, torch.empty_like(rows))
-            dplane = drows.reshape(tile.B, r, r, rows.shape[1])
-            if gthru is not None:
-                dplane = dplane + ops.to_nhwc(gthru)                            # [r^2, C]: small next to the per-point tensors
-            dplane = ops.from_nhwc(dplane, ctx.was_cl)
+            dplane = _join_plane_grad(dq, wa, gthru, (tile.B, r, r, rows.shape[1]), ctx.was_cl)
         elif gthru is not None:
             dplane = gthru
         dlast = dwc = dbc = None
