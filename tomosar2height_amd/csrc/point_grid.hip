@@ -603,6 +603,19 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
     }
 }
 
+// wave-uniform lane reads (v_readlane: the index must be the same in every lane) and a lane-mask select
+__device__ inline float keep_if(unsigned long long lanes, float v) {      // lane l: v if bit l of the wave-uniform mask, else 0
+    float o;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(lanes));
+    return o;
+}
+__device__ inline float readlane_f(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), i);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // Hidden activations that never leave the chip (t2h_sample_relu_cellsums): for a coarse sampling level (many points per cell)
 // one WAVE owns (cell of the sampling level, 256-channel chunk).  It stages the 3 x 3 pixel neighbourhood of the cell -- every
 // tap of every point of the cell lies in it -- in LDS once (9 KB), then walks the cell's rows child by child (children = the
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
         const int bnd_hi = ci + 1 <= child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
         const int nc = min(64, child_hi - cb);
         for (int c = 0; c < nc; ++c) {
-            const int s = __shfl(bnd_lo, c), e = __shfl(bnd_hi, c);
+            const int s = __builtin_amdgcn_readlane(bnd_lo, c), e = __builtin_amdgcn_readlane(bnd_hi, c);
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
             int n = s;
             while (n < e) {
@@ -670,8 +683,8 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                 }
                 const int i0 = n - nb0, cnt = min(e - n, 64 - i0);        // rows of this child inside the current batch
                 auto row = [&](int i, int nrow) -> float4 {
-                    const float nw = __shfl(nw_l, i), ne = __shfl(ne_l, i), sw = __shfl(sw_l, i), se = __shfl(se_l, i);
-                    const float *t00 = T + __shfl(slot_l, i) * 256 + lane * 4;
+                    const float nw = readlane_f(nw_l, i), ne = readlane_f(ne_l, i), sw = readlane_f(sw_l, i), se = readlane_f(se_l, i);
+                    const float *t00 = T + __builtin_amdgcn_readlane(slot_l, i) * 256 + lane * 4;
                     const float4 v00 = *reinterpret_cast<const float4 *>(t00), v01 = *reinterpret_cast<const float4 *>(t00 + 256);
                     const float4 v10 = *reinterpret_cast<const float4 *>(t00 + 3 * 256), v11 = *reinterpret_cast<const float4 *>(t00 + 4 * 256);
                     float4 a;
@@ -1356,17 +1369,6 @@ __global__ __launch_bounds__(kCellThreads) void sample_bwd_cells_mfma_kernel(con
 //   K = 1: the workgroup is a 2 x 2 block of sampling cells, one per wave, added in wave order into the 4 x 4 neighbourhood
 //          of the block -- 16 slots per 4 cells written and re-read instead of 36 (r = 128: 8 rows per cell on average).
 // Fixed orders everywhere => deterministic.  Row values: fma(w, g, acc) with g = G or 0.
-__device__ inline float keep_if(unsigned long long lanes, float v) {      // lane l: v if bit l of the wave-uniform mask, else 0
-    float o;
-    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(v), "s"(lanes));
-    return o;
-}
-__device__ inline float readlane_f(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
-__device__ inline unsigned long long readlane_u64(unsigned long long v, int i) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), i);
-    return ((unsigned long long)hi << 32) | lo;
-}
 __device__ inline void fma4(float4 &a, float w, const float4 &g) {
     a.x = __fmaf_rn(w, g.x, a.x); a.y = __fmaf_rn(w, g.y, a.y); a.z = __fmaf_rn(w, g.z, a.z); a.w = __fmaf_rn(w, g.w, a.w);
 }
