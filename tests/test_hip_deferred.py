@@ -108,15 +108,19 @@ def _dense_tile(n=70000, seed=4):
     (256, 64, True, 60000, 1), (256, 64, False, 60000, 1), (512, 32, True, 60000, 1), (128, 64, False, 60000, 1),
     # the row walk with the cell's children split over the four waves (>= 64 rows per cell), two tiles, few rows per cell at
     # r = 128 (2 x 2 blocks of cells, one level of children), everything in one cell
-    (512, 32, True, 140000, 1), (256, 32, True, 90000, 2), (256, 128, True, 150000, 1), (256, 32, True, -1, 1), (256, 64, True, -1, 1)])
+    (512, 32, True, 140000, 1), (256, 32, True, 90000, 2), (256, 128, True, 150000, 1), (256, 32, True, -1, 1), (256, 64, True, -1, 1),
+    # five gradient planes (a deeper U-Net): the walk holds four, so the matrix-core partials with per-row gathers take it
+    (256, 32, True, 80000, -5)])
 def test_fused_sample_adjoint_from_sums(c2, r, use_bits, n, batch):
     """t2h_sample_bwd_from_sums == gather + mask, then the plain sample adjoint (both paths of the library), and == the float64
     adjoint of F.grid_sample applied to the masked gather."""
     from tomosar2height_amd import _lib, deferred, ops
+    five_planes = batch == -5
+    batch = abs(batch) if not five_planes else 1
     tile = _dense_tile() if n < 0 else _tile(n=n, batch=batch)
     g = torch.Generator().manual_seed(5)
     level = tile.level(r)
-    levels = [lv for lv in (0, 1, 2, 3) if lv <= level + 1]
+    levels = [lv for lv in (0, 1, 2, 3) if lv <= level + 1] + ([4] if five_planes else [])
     planes = [(torch.randn(tile.B * (256 >> lv) ** 2, c2, generator=g).to(_dev()), lv) for lv in levels]
     h = torch.relu(torch.randn(tile.n_points, c2, generator=g)).to(_dev())
     ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, level, c2)
