@@ -410,7 +410,9 @@ RowsPlan rows_plan(long long M, int N, int K) {
     int splits = 1;
     // fewer tiles than two per CU: split the reduction.  ~512 workgroups for planes from 256 x 256 up (768 / 1024 there:
     // +10-30 % slower), ~768 for the smaller ones (128->128 at 128^2: 65 -> 60 us; 256 / 384: slower)
-    const long long tgt = M <= 16384 ? 768 : 512;
+    static const long long tgt_small = getenv("T2H_CONV_ROWS_WGS_SMALL") ? atoll(getenv("T2H_CONV_ROWS_WGS_SMALL")) : 768;
+    static const long long tgt_large = getenv("T2H_CONV_ROWS_WGS_LARGE") ? atoll(getenv("T2H_CONV_ROWS_WGS_LARGE")) : 512;
+    const long long tgt = M <= 16384 ? tgt_small : tgt_large;
     if (tiles < tgt) {
         splits = (int)((tgt + tiles - 1) / tiles);
         const int max_splits = nk / 8 > 1 ? nk / 8 : 1;   // at least 8 slabs per split
