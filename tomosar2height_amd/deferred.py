@@ -29,7 +29,7 @@ import torch
 
 from . import _lib, mlp, ops
 
-DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "256"))
+DEFER_MIN_CHANNELS = int(os.environ.get("T2H_DEFER_MIN_CHANNELS", "128"))
 FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B: 0 = separate gather + sample adjoint
 CELLS_MFMA = os.environ.get("T2H_CELLS_MFMA", "1") != "0"                  # (mirrors the library's switch: the bit mask needs it)
 SIGN_BITS = os.environ.get("T2H_SIGN_BITS", "1") != "0"                    # A/B: 0 = keep the hidden activations for the mask
