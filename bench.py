@@ -46,6 +46,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
 # (t2h_segsum_fwd at the finest resolution + 2x2 pooling) and their joint backward
 # (since r03y the coarse levels' sums are formed on chip by t2h_sample_relu_cellsums, backward t2h_sample_bwd_from_sums)
 SCATTER_REDUCE_TAGS = ("t2h_sample_relu_cellsums[C=1024,r=32]", "t2h_sample_bwd_from_sums[C=1024,r=32]",
+                       "t2h_segsum_fwd[C=128,r=256]",       # the per-cell sums that still run as a kernel of their own (last level)
                        "t2h_segsum_fwd[C=1024,r=256]", "t2h_segsum_fwd[C=512,r=256]", "t2h_segmean_fwd[C=512,r=32]",
                        "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]", "t2h_pool_max_fwd", "t2h_pool_max_bwd")
 
