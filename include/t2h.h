@@ -159,9 +159,13 @@ int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float 
  * t2h_segsum_fwd; for levels with many points per cell (the walk is sequential inside a cell).  C % 256 == 0. */
 int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                              int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits, t2h_stream_t stream);
-/* t2h_segsum_bwd_multi folded into the row load of the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
+/* t2h_segsum_bwd_multi folded into the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
- * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace. */
+ * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace.  `mask`: the hidden activations [N, C]
+ * (mask_is_bits = 0) or their packed sign bits (mask_is_bits = 1, layout of t2h_sample_fwd_relu; C % 256 == 0).  With sign bits
+ * and <= 4 planes of distinct levels the kernel is a row walk -- the gathered gradient formed once per finest cell, the sign
+ * words used as lane masks, 3 x 3 register accumulators per wave, per-workgroup partials for one cell or a 2 x 2 block of cells
+ * -- otherwise slots x rows x channels products on the matrix cores with the gather in the row load.  Deterministic either way. */
 int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
                              const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim, const int32_t *off0, int B, int N,
                              int nbits, int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
