@@ -353,6 +353,7 @@ def test_direct_grad_accumulation_matches_autograd():
     tr.train_step(tiles[2])
     tr.accumulated_steps = 0                                                          # keep accumulating, no step
     tr.train_step(tiles[3])
+    tr.flush_gradients()                 # (the composed maps' share of the gradients: back-propagated once per window)
     got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
     ref = det_init_(TomoSAR2Height(cfg), seed=11).to(_dev())
     for t in tiles[2:]:
@@ -416,6 +417,7 @@ def test_hip_graph_replay_matches_eager():
             tr.capture_graph(tiles[1])
         for t in tiles[1:]:
             tr.train_step(t)
+        tr.flush_gradients()
         return tr.bucket.flat.clone(), float(tr.accumulated_loss)
 
     g_eager, l_eager = run(False)
@@ -448,6 +450,7 @@ def test_training_step_is_bit_reproducible():
             tr.capture_graph(tiles[1])
         for t in tiles[1:]:
             tr.train_step(t)
+        tr.flush_gradients()
         torch.cuda.synchronize()
         return tr.bucket.flat.clone(), float(tr.accumulated_loss)
 
@@ -580,6 +583,7 @@ def test_side_stream_wgrad_overlap_gives_identical_gradients():
         tr.overlap_wgrad = overlap
         for t in tiles[:-1]:
             assert tr.train_step(t) is False
+        tr.flush_gradients()
         grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
         assert (tr._side is not None) == overlap
         return grads
@@ -615,6 +619,7 @@ def test_tile_index_built_ahead_on_a_side_stream_gives_the_same_step():
                 nxt = tr.prepare(tiles[i + 1], side) if ahead else tiles[i + 1]       # issued before step i
             assert isinstance(cur["inputs"], TileIndex) == ahead
             tr.train_step(cur)
+        tr.flush_gradients()
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, float(tr.accumulated_loss)
 
@@ -622,3 +627,46 @@ def test_tile_index_built_ahead_on_a_side_stream_gives_the_same_step():
     assert la == lb
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_compose_cache_gives_the_same_accumulated_gradients():
+    """Trainer's ComposeCache: the composed weight maps of the deferred ALTO levels computed once per optimizer step and their
+    gradient back-propagated once on the sum over the step's tiles == composing and back-propagating per tile (the chain is
+    linear in its gradient): same losses bit for bit (same forward values), every gradient to fp32 re-association, and the
+    optimizer step sees the complete gradient."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    tiles = [{"inputs": synth_cloud(40000, seed=800 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(3)]
+
+    def run(cached):
+        model = det_init_(TomoSAR2Height(cfg), seed=16).to(_dev())
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=100, use_cloud=True)
+        if not cached:
+            tr.compose_cache = model.point_encoder.unet.compose_cache = None
+        else:
+            assert tr.compose_cache is not None
+        for t in tiles:
+            tr.train_step(t)
+        if cached:
+            assert len(tr.compose_cache.levels) >= 2, "the tile should be dense enough for deferred levels"
+        tr.flush_gradients()
+        torch.cuda.synchronize()
+        seen = []
+        tr.on_reduced = lambda flat: seen.append(flat.clone())
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        loss = float(tr.accumulated_loss)
+        tr.optimizer_boundary()
+        assert torch.equal(seen[0], torch.cat([g.reshape(-1) for g in [seen[0]]]))
+        return grads, loss, seen[0]
+
+    (a, la, fa), (b, lb, fb) = run(False), run(True)
+    assert la == lb
+    assert a.keys() == b.keys()
+    for k in a:
+        scale = a[k].abs().max().item() + 1e-20
+        assert (a[k] - b[k]).abs().max().item() <= 2e-5 * scale, k
+    assert (fa - fb).abs().max().item() <= 2e-5 * fa.abs().max().item()

@@ -80,8 +80,9 @@ class _PointGridLevel(nn.Module):
             if isinstance(c_last, deferred.Deferred):
                 state = c_last
             else:
-                res, chs = later_res
-                state = deferred.Deferred(tile, [tile.level(x) for x in res], chs, c_last)
+                res, chs = later_res[0], later_res[1]
+                cache = later_res[2] if len(later_res) > 2 else None
+                state = deferred.Deferred(tile, [tile.level(x) for x in res], chs, c_last, cache=cache)
             # fc_comm.0 on the pixels (alto.py:123); the returned plane is the input plane for its further consumers
             q, plane = mlp.linear_plane_thru(plane, fa.weight, fa.bias)
             raster = state.advance(q, r, fb, self.fc_c).reshape(plane.shape[0], r, r, ch).permute(0, 3, 1, 2)
@@ -226,12 +227,13 @@ class UNet(nn.Module):
                 res.append(r)
                 chs.append(up.out_channels)
         pos = 0
+        cache = getattr(self, "compose_cache", None)        # set by the Trainer (deferred.ComposeCache), else plain autograd
         for down in self.down_convs:
-            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, (res[pos:], chs[pos:]))
+            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, (res[pos:], chs[pos:], cache))
             skips.append(raster)
             pos += 1
         for i, up in enumerate(self.up_convs):
-            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, (res[pos:], chs[pos:]))
+            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, (res[pos:], chs[pos:], cache))
             pos += 1
         if self.down_convs[0].channels_last:
             return grid.conv1x1(plane, self.conv_final)

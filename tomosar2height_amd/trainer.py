@@ -99,6 +99,15 @@ class Trainer:
         self.overlap_conv_wgrad = os.environ.get("T2H_OVERLAP_CONV_WGRAD", "0") == "1"
         self._conv_side = None
 
+        # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
+        # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
+        # gradients are therefore complete after ``flush_gradients()`` / at ``optimizer_boundary()``, not after every tile.
+        self.compose_cache = None
+        unet = getattr(getattr(model, "point_encoder", None), "unet", None)
+        if os.environ.get("T2H_COMPOSE_CACHE", "1") != "0" and unet is not None and hasattr(unet, "forward_sorted"):
+            from . import deferred
+            self.compose_cache = unet.compose_cache = deferred.ComposeCache()
+
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
         self.accumulated_loss_dict = {"loss_ce": 0.0, "loss_l1": 0.0}
@@ -134,6 +143,7 @@ class Trainer:
         static = {k: example[k].to(dev).clone() for k in ("inputs", "image", "dsm") if example.get(k) is not None}
         self.model.train()
         saved = self.bucket.flat.clone()                   # warm-up / capture passes must not pollute the accumulators
+        saved_cache = self.compose_cache.snapshot() if self.compose_cache is not None else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                      # warm-up on a side stream, as torch.cuda.graphs prescribes
@@ -149,6 +159,8 @@ class Trainer:
             with mlp.direct_grad_accumulation(self.direct_accumulation):
                 (l1 + ce).backward()
         self.bucket.flat.copy_(saved)
+        if saved_cache is not None:
+            self.compose_cache.restore(saved_cache)
         self._graph = {"graph": graph, "static": static, "l1": l1.detach(), "ce": ce.detach(),
                        "shapes": {k: tuple(v.shape) for k, v in static.items()}}
         return graph
@@ -205,6 +217,7 @@ class Trainer:
                     # stream order on the current stream like any other result
                     torch.cuda.current_stream().wait_stream(st)
         if self.bucket is None:
+            self.flush_gradients()          # (the parameters behind the composed maps must have their gradient before the bucket is laid out)
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
             # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
             self.bucket = GradBucket(list(self.model.parameters()))
@@ -219,10 +232,16 @@ class Trainer:
         self.optimizer_boundary()
         return True
 
+    def flush_gradients(self):
+        """Make every parameter's ``.grad`` complete for the tiles seen so far (back-propagates what the ComposeCache holds)."""
+        if self.compose_cache is not None:
+            self.compose_cache.flush()
+
     def optimizer_boundary(self):
         """End of an optimizer step (trainer.py:78-89): [all-reduce(SUM) of the flat gradient bucket over the ranks,]
         ``optimizer.step()``, loss averaging, gradients to zero.  ``on_reduced(flat_grad)``, if set, sees the complete
         accumulated (and reduced) gradient just before the optimizer consumes it (tests, ``bench.py --check-dp``)."""
+        self.flush_gradients()
         if self.world > 1:
             self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
         if self.on_reduced is not None:
@@ -241,6 +260,8 @@ class Trainer:
                 raise ValueError(f"{bad} input point(s) of the last {self.optimize_every} tile(s) had x or y outside [0, 1) "
                                  "(or NaN): normalise / crop the tiles as dataset.py:270-278 does")
         self.optimizer.step()
+        if self.compose_cache is not None:
+            self.compose_cache.refresh()                                  # new weights -> new composed maps (in place)
         if self.scheduler is not None:
             self.scheduler.step()                                         # train.py:188-190: once per iteration
         with torch.no_grad():
@@ -258,6 +279,11 @@ class Trainer:
         self._reset_accumulators()
 
     def _reset_accumulators(self):
+        if self.compose_cache is not None and self.compose_cache.pending:    # (error path: drop what was accumulated)
+            for e in self.compose_cache.levels:
+                e["ga"].zero_()
+                e["gconst"].zero_()
+            self.compose_cache.pending = False
         self.accumulated_loss = 0.0
         self.accumulated_steps = 0
         self.accumulated_loss_dict = {k: 0.0 for k in self.accumulated_loss_dict}
