@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 7
+#define T2H_ABI_VERSION 8
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 
 typedef void *t2h_stream_t;
@@ -159,6 +159,12 @@ int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float 
  * t2h_segsum_fwd; for levels with many points per cell (the walk is sequential inside a cell).  C % 256 == 0. */
 int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                              int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits, t2h_stream_t stream);
+/* ... and, from the same registers, the sums one level coarser (`pooled_nhwc`, [B, R_sum/2, R_sum/2, C] with row stride ld_pooled;
+ * may be NULL; needs sum_level < level): what t2h_plane_sumpool2x2 would form from `sums_nhwc` with the same bits, without
+ * re-reading it. */
+int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
+                              int level, int sum_level, int C, float *sums_nhwc, int ld_sums, float *pooled_nhwc, int ld_pooled,
+                              void *sign_bits, t2h_stream_t stream);
 /* t2h_segsum_bwd_multi folded into the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace.  `mask`: the hidden activations [N, C]

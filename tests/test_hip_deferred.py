@@ -219,6 +219,19 @@ def test_on_chip_hidden_activations_equal_the_two_kernel_form(c, r, sum_level, d
     _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
               tile.nbits, tile.level(r), sum_level, c, blk.data_ptr(), blk.stride(0), _lib.ptr(bits), _lib.stream())
     assert torch.equal(bits, bits_ref)
+    if sum_level < tile.level(r):
+        # the same call with the pooled sums one level up: == t2h_plane_sumpool2x2 of its own finest sums, bit for bit
+        got2 = torch.full((tile.B * rs * rs, ktot), 3.0, device=_dev())
+        rs2 = rs // 2
+        pooled = torch.full((tile.B * rs2 * rs2, ktot), 5.0, device=_dev())
+        b2, p2 = got2[:, off:off + c], pooled[:, off:off + c]
+        _lib.call("t2h_sample_relu_cellsums2", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+                  tile.nbits, tile.level(r), sum_level, c, b2.data_ptr(), b2.stride(0), p2.data_ptr(), p2.stride(0),
+                  _lib.ptr(torch.zeros_like(bits_ref)), _lib.stream())
+        assert torch.equal(got2, got)
+        want2 = torch.full((tile.B * rs2 * rs2, ktot), 5.0, device=_dev())
+        deferred._sumpool_into(tile, got[:, off:off + c], sum_level, want2[:, off:off + c])
+        assert torch.equal(pooled, want2)
     if _lib.load().t2h_segmean_workspace_bytes(tile.B, tile.N, tile.nbits, sum_level, c) == 0:
         assert torch.equal(got, want)             # the two-kernel form sums a cell's rows in sequence too: same bits
     else:                                         # ... unless it takes the per-(cell, split) partials there: same sums, re-associated

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     "t2h_mean_bias_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "t2h_mean_bias_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "t2h_sample_relu_cellsums": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "t2h_sample_relu_cellsums2": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "t2h_sample_bwd_from_sums": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_fwd_relu": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

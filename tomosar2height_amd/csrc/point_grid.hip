@@ -628,7 +628,8 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                                                                  const float *__restrict__ pts, int dim,
                                                                  const int32_t *__restrict__ off0, int nbits, int level,
                                                                  int sum_level, int C, float *__restrict__ sums, int ld_sums,
-                                                                 unsigned long long *__restrict__ bits, int npts_m1) {
+                                                                 unsigned long long *__restrict__ bits, int npts_m1,
+                                                                 float *__restrict__ sums2, int ld_sums2) {
     extern __shared__ float nb_lds[];                                   // [waves][9][256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.y * 4 + wave;
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
     int nb0 = 0, slot_l = 0;
     float nw_l = 0.f, ne_l = 0.f, sw_l = 0.f, se_l = 0.f;
     bool have = false;
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f), p01 = pe;             // pooled-output state of the current quad of children
     // blockIdx.z: this workgroup's share of the children (dense cells would otherwise set the kernel's duration: one wave
     // walking 500+ rows while most of the chip has finished); the children's sums are independent, so nothing is reduced
     const int per_group = nchild / (int)gridDim.z, child_lo = (int)blockIdx.z * per_group, child_hi = child_lo + per_group;
@@ -719,6 +721,20 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
             const uint32_t cm = (uint32_t)(cb + c);                      // child's Morton code inside the cell
             const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
             *reinterpret_cast<float4 *>(sums + (((size_t)b * rs + fy) * rs + fx) * ld_sums + c0) = sum;
+            if (sums2) {
+                // the 2 x 2 pooled sums one level up, formed from the four children while they are in registers (children are
+                // visited in Morton order = the order (c0 + c1) + (c2 + c3) of plane_sumpool2x2_kernel: same bits)
+                const unsigned k4 = cm & 3u;
+                if (k4 == 0u) pe = sum;
+                else if (k4 == 1u) p01 = make_float4(pe.x + sum.x, pe.y + sum.y, pe.z + sum.z, pe.w + sum.w);
+                else if (k4 == 2u) pe = sum;
+                else {
+                    const float4 o = make_float4(p01.x + (pe.x + sum.x), p01.y + (pe.y + sum.y), p01.z + (pe.z + sum.z),
+                                                 p01.w + (pe.w + sum.w));
+                    const int rs2 = rs >> 1;
+                    *reinterpret_cast<float4 *>(sums2 + (((size_t)b * rs2 + (fy >> 1)) * rs2 + (fx >> 1)) * ld_sums2 + c0) = o;
+                }
+            }
         }
     }
 }
@@ -1877,7 +1893,16 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
 T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
                                      int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits,
                                      t2h_stream_t stream) {
+    return t2h_sample_relu_cellsums2(plane_nhwc, pts, dim, off0, B, N, nbits, level, sum_level, C, sums_nhwc, ld_sums, nullptr, 0,
+                                     sign_bits, stream);
+}
+
+T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
+                                      int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums,
+                                      float *pooled_nhwc, int ld_pooled, void *sign_bits, t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !off0 || !sums_nhwc || !sign_bits) return fail(T2H_ERR_ARG, "sample_relu_cellsums: null pointer");
+    if (pooled_nhwc && (sum_level >= level || ld_pooled < C || ld_pooled % 4 != 0 || ((uintptr_t)pooled_nhwc & 15)))
+        return fail(T2H_ERR_ARG, "sample_relu_cellsums: the pooled sums need sum_level < level and 16-byte aligned rows of >= C floats");
     int rc = check_level("sample_relu_cellsums", B, nbits, level, C);
     if (rc) return rc;
     if (dim < 2 || N < 0 || sum_level < 0 || sum_level > level || C % 256 != 0 || ld_sums < C || ld_sums % 4 != 0 ||
@@ -1889,10 +1914,12 @@ T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, 
     int groups = 1;                                                   // split the children until ~8192 workgroups exist (4096: +10 us at r = 64; 16384: +18 us at r = 32)
     const int nchild = 1 << (2 * (level - sum_level));
     static const int min_wgs = [] { const char* e = getenv("T2H_ON_CHIP_MIN_WGS"); return e ? atoi(e) : 8192; }();
-    while (groups < nchild && cells * ((chunks + 3) / 4) * groups < min_wgs) groups *= 2;
+    // (with pooled sums a workgroup's share of the children must hold whole quads)
+    while (groups < (pooled_nhwc ? nchild / 4 : nchild) && cells * ((chunks + 3) / 4) * groups < min_wgs) groups *= 2;
     hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4, groups), dim3(64 * waves),
                        (size_t)waves * 9 * 256 * sizeof(float), as_stream(stream), plane_nhwc, pts, dim, off0, nbits, level,
-                       sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1));
+                       sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1),
+                       pooled_nhwc, ld_pooled);
     return check_launch("sample_relu_cellsums");
 }
 

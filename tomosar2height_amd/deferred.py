@@ -166,11 +166,17 @@ class _DeferredLevel(torch.autograd.Function):
             lo, hi = state.off[idx + 1], state.off[idx + 2]
             levels = state.needed(idx + 1)
             finest = state._matrix(state.S, levels[0])[:, lo:hi]
-            _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
-                      tile.N, tile.nbits, tile.level(r), levels[0], c2, finest.data_ptr(), finest.stride(0), _lib.ptr(bits),
-                      _lib.stream(), nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0] + (c2 // 8) * tile.n_points,
+            # the next coarser needed resolution comes out of the same pass (the four children of a cell are in registers)
+            second = None
+            if len(levels) > 1 and levels[1] == levels[0] + 1 and levels[0] < tile.level(r):
+                second = state._matrix(state.S, levels[1])[:, lo:hi]
+            _lib.call("t2h_sample_relu_cellsums2", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+                      tile.N, tile.nbits, tile.level(r), levels[0], c2, finest.data_ptr(), finest.stride(0),
+                      None if second is None else second.data_ptr(), 0 if second is None else second.stride(0), _lib.ptr(bits),
+                      _lib.stream(), nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0] + (c2 // 8) * tile.n_points
+                      + (0 if second is None else 4 * c2 * second.shape[0]),
                       tag=_lib.timing() and f"t2h_sample_relu_cellsums[C={c2},r={r}]")
-            state.pool_down(idx + 1)
+            state.pool_down(idx + 1, start=1 if second is not None else 0)
             return _DeferredLevel._finish(ctx, state, idx, r, a_all, const, bits, True)
         h = torch.empty(tile.n_points, c2, dtype=torch.float32, device=q_rows.device)
         # the backward needs only the sign pattern of h: where its fused form will run, keep 1 bit per element (written by the
@@ -400,13 +406,14 @@ class Deferred:
         _segsum_into(self.tile, rows, levels[0], self._matrix(self.S, levels[0])[:, lo:hi])
         self.pool_down(src)
 
-    def pool_down(self, src):
-        """The source's sums at its coarser needed resolutions from the (already written) finest one, by 2x2 pooling."""
+    def pool_down(self, src, start=0):
+        """The source's sums at its coarser needed resolutions from the (already written) finest one, by 2x2 pooling;
+        ``start``: index of the coarsest needed resolution that is written already."""
         tile, (lo, hi) = self.tile, (self.off[src], self.off[src + 1])
         levels = self.needed(src)
-        cur_level = levels[0]
+        cur_level = levels[start]
         cur = self._matrix(self.S, cur_level)[:, lo:hi]
-        for lv in levels[1:]:
+        for lv in levels[start + 1:]:
             while cur_level < lv:
                 nxt_level = cur_level + 1
                 if nxt_level in levels:
