@@ -457,7 +457,8 @@ RowsPlan rows_plan_for(long long M, int Cin, int Cout) {
         // 512 -> 256 channels is a 1024 x 1024 x 512 GEMM: 64 tiles of 128 x 128 would occupy a quarter of the CUs)
         r.splits = 1; r.k_chunk = sh.K;
         const long long row_tiles = (M + 127) / 128;
-        while (r.bn > 32 && row_tiles * ((sh.N + r.bn - 1) / r.bn) < 256) r.bn >>= 1;
+        static const long long up_tiles = getenv("T2H_UPCONV_FWD_TILES") ? atoll(getenv("T2H_UPCONV_FWD_TILES")) : 256;
+        while (r.bn > 32 && row_tiles * ((sh.N + r.bn - 1) / r.bn) < up_tiles) r.bn >>= 1;
     }
     return r;
 }
