@@ -468,13 +468,24 @@ def main():
         j = state["j"] = state.get("j", -1) + 1                       # raw tiles handed out so far
         if source is None:
             return tiles[j % len(tiles)]
+        def produce(defer):
+            # empty windows are skipped, as the reference's loop does (train.py:150-151); the anchors are drawn inside the chunk,
+            # so with the synthetic chunk this never triggers
+            for _ in range(len(anchors)):
+                k = state["a"] = state.get("a", -1) + 1
+                cand = source.get(anchors[k % len(anchors)], defer_wait=defer) if defer else source.get(anchors[k % len(anchors)])
+                if bool(cand["is_valid"][0]):
+                    return cand
+            raise RuntimeError("--from-producer: no valid tile in the chunk")
         if not args.producer_prefetch:
-            t = source.get(anchors[j % len(anchors)])
+            t = produce(False)
         else:
             # tile j was produced (on the producer's side stream) while the previous step ran; produce tile j + 1 now, before
-            # the next step is issued, so that its crop runs beside the steps in flight and its host read does not wait
-            t = state.pop("pending", None) or source.get(anchors[j % len(anchors)])
-            state["pending"] = source.get(anchors[(j + 1) % len(anchors)])
+            # step j is issued, so that its crop runs beside the steps in flight and its host read does not wait.  The main
+            # stream waits for a tile only when it is USED (TileSource.wait), not when it is produced
+            t = state.pop("pending", None) or produce(True)
+            state["pending"] = produce(True)
+            source.wait(t)
         state["points"] += t["inputs"].shape[1]
         return t
 

@@ -156,7 +156,8 @@ int t2h_mean_bias_bwd(const float *g, const float *cnt, int64_t P, int C, float 
  * chip: per (cell of the sampling level, 256-channel chunk) one wave stages the cell's 3 x 3 pixel neighbourhood in LDS, walks the
  * cell's rows and emits the per-cell SUMS of relu(sample(plane)) at the finer resolution `sum_level` (into a column block with row
  * stride ld_sums) and the packed sign bits (layout of t2h_sample_fwd_relu).  Bit-identical to t2h_sample_fwd_relu +
- * t2h_segsum_fwd; for levels with many points per cell (the walk is sequential inside a cell).  C % 256 == 0. */
+ * t2h_segsum_fwd; for levels with many points per cell (the walk is sequential inside a cell).  C % 256 == 0.
+ * `sign_bits` may be NULL (forward-only callers, generator.py:142-147: nothing reads the signs, nothing is written). */
 int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                              int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits, t2h_stream_t stream);
 /* ... and, from the same registers, the sums one level coarser (`pooled_nhwc`, [B, R_sum/2, R_sum/2, C] with row stride ld_pooled;

@@ -173,3 +173,44 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         rc = getattr(lib, name)(*args)
         assert rc in (-1, -3), f"{name} returned {rc}"
         assert len(lib.t2h_last_error_string()) > 8
+
+
+def test_in_place_gradient_joins_only_into_solely_owned_buffers():
+    """mlp._join_plane_grad / deferred._DeferredLevel accumulate into the gradient tensor autograd hands them only
+    when nobody else still reads it (mlp.sole_owner).  torch's add backward hands the SAME tensor to both producers: the node
+    that runs first must not write into it."""
+    import torch
+    from tomosar2height_amd import mlp
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(mlp.sole_owner(g))
+            return g * 2
+
+    class ChannelsLastGrad(torch.autograd.Function):        # returns a permuted view of a fresh NHWC buffer, as grid.py does
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            d = torch.empty(1, 3, 3, 4)
+            d.copy_(g.permute(0, 2, 3, 1))
+            return d.permute(0, 3, 1, 2)
+
+    x = torch.randn(1, 4, 3, 3, requires_grad=True)
+    (Probe.apply(x) * 3).sum().backward()
+    assert seen == [True]
+    seen.clear()
+    z = Probe.apply(x) + Probe.apply(x * 1.5)              # one gradient buffer queued for two nodes
+    (z * z).sum().backward()
+    assert seen == [False, True]
+    seen.clear()
+    ChannelsLastGrad.apply(Probe.apply(x)).sum().backward()
+    assert seen == [True]

@@ -95,3 +95,29 @@ def test_bench_gpus_two_without_a_launcher():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
     assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"]
     assert d["config"]["optimizer_steps_in_timed_region"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """`python bench.py --gpus 8` as the driver will start it on an 8-GPU node, here with the eight ranks
+    sharing the one GPU over gloo (everything but the transport and the device placement is the 8-GPU path): the launcher, the
+    flat bucket + all-reduce per optimizer step (64 / 8 = 8 tiles per rank), check_dp, and what eight ranks cost the HOST
+    (CPU time per rank and tile, reported in `sustained`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("OMP_NUM_THREADS", None)                      # bench.py's launcher sets cores / ranks
+    out = os.path.join(ROOT, "gpurun_out", "bench_8rank_dry_run.json")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-gpu", "--steps", "8",
+           "--warmup", "2", "--profile-steps", "0", "--sustain-s", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, f"--- stdout\n{r.stdout[-4000:]}\n--- stderr\n{r.stderr[-6000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]) and len(lines[0]) <= 4096
+    d = json.loads(lines[0])
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        f.write(lines[0] + "\n")
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["points_per_tile"] == 131072
+    assert d["config"]["optimizer_steps_in_timed_region"] == 1                      # 8 tiles per rank = one 64-tile step
+    assert d["check_dp"]["max_rel_diff"] <= 2e-5 and d["check_dp"]["replicas_identical"], d["check_dp"]
+    assert d["sustained"]["host_cpu_ms_per_step"] > 0

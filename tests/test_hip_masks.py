@@ -346,8 +346,8 @@ def test_bottom_level_grid_first_vs_float64_with_the_same_masks():
     ck.finish("DownConv 256->512 @32^2 (grid-first), N=131072")
 
 
-@pytest.mark.parametrize("c,r", [(512, 32), (256, 64), (128, 128)])
-def test_grid_first_exchange_equals_point_first(c, r):
+@pytest.mark.parametrize("c,r,n_points", [(512, 32, 131072), (256, 64, 131072), (128, 128, 131072), (64, 256, 262144)])
+def test_grid_first_exchange_equals_point_first(c, r, n_points):
     """mlp.comm_mlp_grid_first against sample_plane + mlp.comm_mlp on the same plane, points and weights: the two
     associations of the same function.  Values to 1e-5; gradients to the resolution two fp32 evaluations of one ReLU layer
     have -- a hidden unit within 1e-7 of zero may take either side, and with 128 points per pixel one flipped unit moves a
@@ -356,8 +356,7 @@ def test_grid_first_exchange_equals_point_first(c, r):
     test_bottom_level_grid_first_vs_float64_with_the_same_masks (<= 1.6e-6 with the masks pinned)."""
     from tomosar2height_amd import mlp, ops
     from tomosar2height_amd.tile import TileIndex
-    dev = _dev()
-    n_points = 131072
+    dev = _dev()                          # (r = 256: bench.py --points 262144 runs grid-first there, 4 points per pixel)
     tile = TileIndex(synth_cloud(n_points, seed=9).to(dev), 256)
     lin = lambda o, i, s: det_init_(torch.nn.Linear(i, o), seed=s).to(dev)              # noqa: E731
     fa, fb, fc = lin(2 * c, c, 1), lin(c, 2 * c, 2), lin(c, c // 2, 3)

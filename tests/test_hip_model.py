@@ -670,3 +670,88 @@ def test_compose_cache_gives_the_same_accumulated_gradients():
         scale = a[k].abs().max().item() + 1e-20
         assert (a[k] - b[k]).abs().max().item() <= 2e-5 * scale, k
     assert (fa - fb).abs().max().item() <= 2e-5 * fa.abs().max().item()
+
+
+def _cache_setup(n_tiles=2, seed=16):
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    cfg = berlin_config()
+    tiles = [{"inputs": synth_cloud(40000, seed=820 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(n_tiles)]
+    model = det_init_(TomoSAR2Height(cfg), seed=seed).to(_dev())
+    model.set_channels_last(True)
+    return cfg, model, tiles
+
+
+def test_compose_cache_is_owned_by_its_trainer():
+    """the ComposeCache is visible to the network only inside its own Trainer's step.  (a) a second Trainer
+    on the same model (what bench.check_dp builds) neither steals nor loses gradients: both see the complete accumulated
+    gradient of their own tiles; (b) a plain ``model(...).backward()`` after a Trainer exists runs plain autograd and leaves
+    complete ``.grad`` (compared with a model no Trainer ever touched)."""
+    from tomosar2height_amd.trainer import Trainer
+    cfg, model, tiles = _cache_setup()
+    unet = model.point_encoder.unet
+    null = torch.optim.SGD(model.parameters(), lr=0.0)
+    seen = {}
+    a = Trainer(model, null, device=_dev(), optimize_every=2, use_cloud=True)
+    a.on_reduced = lambda flat: seen.__setitem__("a", flat.clone())
+    b = Trainer(model, null, device=_dev(), optimize_every=2, use_cloud=True)        # created while a is alive: must not disturb a
+    b.on_reduced = lambda flat: seen.__setitem__("b", flat.clone())
+    assert a.compose_cache is not None and b.compose_cache is not None and a.compose_cache is not b.compose_cache
+    assert getattr(unet, "compose_cache", None) is None
+    for t in tiles:
+        a.train_step(t)
+        assert getattr(unet, "compose_cache", None) is None, "the cache must not stay on the module between steps"
+    assert len(a.compose_cache.levels) >= 2 and not a.compose_cache.pending
+    for t in tiles:
+        b.train_step(t)
+    assert (seen["a"] - seen["b"]).abs().max().item() <= 2e-5 * seen["a"].abs().max().item()
+
+    # (b) plain autograd on the same model, compared with a model that never saw a Trainer
+    _, fresh, _ = _cache_setup()
+    for m in (model, fresh):
+        m.zero_grad(set_to_none=True)
+        pa, _ = m(input_cloud=tiles[0]["inputs"])
+        torch.nn.functional.l1_loss(pa.squeeze(), tiles[0]["dsm"].squeeze()).backward()
+    for (k, p), (_, q) in zip(model.named_parameters(), fresh.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad), k
+    assert not a.compose_cache.pending and not b.compose_cache.pending
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adamw", "flat_adamw"])
+def test_optimizer_stepped_outside_the_trainer_is_noticed(fused):
+    """an optimizer step issued by the CALLER on a model with a live ComposeCache.  With gradients pending in the
+    cache the next train_step raises (the maps they belong to are gone); with nothing pending the maps are recomputed from the
+    new weights (both optimizers bump the parameters' version counters -- FlatAdamW writes through raw pointers and bumps them
+    explicitly): the next step equals that of a cache-less trainer on the same weights."""
+    from tomosar2height_amd.optim import FlatAdamW
+    from tomosar2height_amd.trainer import Trainer
+    cfg, model, tiles = _cache_setup()
+    opt = (FlatAdamW if fused else torch.optim.AdamW)(model.parameters(), lr=1e-3)
+    tr = Trainer(model, opt, device=_dev(), optimize_every=100, use_cloud=True)
+    tr.train_step(tiles[0])                                # (the very first tile flushes at once: the bucket is laid out from it)
+    tr.train_step(tiles[1])
+    assert tr.compose_cache.pending
+    opt.step()                                             # the misuse: gradients of tile 1 are still in the cache
+    with pytest.raises(RuntimeError, match="unflushed"):
+        tr.train_step(tiles[0])
+
+    cfg, model, tiles = _cache_setup()
+    opt = (FlatAdamW if fused else torch.optim.AdamW)(model.parameters(), lr=1e-3)
+    tr = Trainer(model, opt, device=_dev(), optimize_every=100, use_cloud=True)
+    tr.train_step(tiles[0])
+    tr.flush_gradients()
+    opt.step()                                             # legal: nothing pending; the trainer was not told
+    tr.bucket.zero_()
+    tr.train_step(tiles[1])
+    tr.flush_gradients()
+    got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=False)
+    pa, _ = model(input_cloud=tiles[1]["inputs"])           # plain autograd on the stepped weights
+    torch.nn.functional.l1_loss(pa.squeeze(), tiles[1]["dsm"].squeeze()).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            scale = p.grad.abs().max().item() + 1e-20
+            assert (got[k] - p.grad).abs().max().item() <= 2e-5 * scale, k

@@ -60,9 +60,11 @@ __global__ __launch_bounds__(256) void mean_bias_bwd_kernel(const float *__restr
     const int col = threadIdx.x % cols, slot = threadIdx.x / cols;
     const int64_t p0 = (int64_t)blockIdx.x * kMbRows;
     const int rows = (int)min((int64_t)kMbRows, P - p0);
-    for (int c4 = col; c4 < C4; c4 += cols) {
+    // (uniform trip count: every thread reaches both barriers of every pass, also when C / 4 is not a multiple of `cols`)
+    for (int c4base = 0; c4base < C4; c4base += cols) {
+        const int c4 = c4base + col;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (slot < slots) {
+        if (slot < slots && c4 < C4) {
             for (int i = slot; i < rows; i += slots) {
                 const float n = cnt[p0 + i];
                 const float4 v = reinterpret_cast<const float4 *>(g + (size_t)(p0 + i) * C)[c4];
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void mean_bias_bwd_kernel(const float *__restr
         __syncthreads();
         red[threadIdx.x] = s;
         __syncthreads();
-        if (slab && slot == 0) {
+        if (slab && slot == 0 && c4 < C4) {
             float4 t = red[col];
             for (int q = 1; q < slots; ++q) {
                 const float4 u = red[q * cols + col];

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                     a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
                     const unsigned long long w0 = __ballot(a.x > 0.f), w1 = __ballot(a.y > 0.f);
                     const unsigned long long w2 = __ballot(a.z > 0.f), w3 = __ballot(a.w > 0.f);
-                    if (lane == 0) {
+                    if (lane == 0 && bits) {                              // (null under no_grad: nothing will read the signs)
                         unsigned long long *dst = bits + ((size_t)chunk * ((size_t)npts_m1 + 1) + nrow) * 4;
                         dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
                     }
@@ -1900,7 +1900,7 @@ T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, 
 T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
                                       int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums,
                                       float *pooled_nhwc, int ld_pooled, void *sign_bits, t2h_stream_t stream) {
-    if (!plane_nhwc || !pts || !off0 || !sums_nhwc || !sign_bits) return fail(T2H_ERR_ARG, "sample_relu_cellsums: null pointer");
+    if (!plane_nhwc || !pts || !off0 || !sums_nhwc) return fail(T2H_ERR_ARG, "sample_relu_cellsums: null pointer");
     if (pooled_nhwc && (sum_level >= level || ld_pooled < C || ld_pooled % 4 != 0 || ((uintptr_t)pooled_nhwc & 15)))
         return fail(T2H_ERR_ARG, "sample_relu_cellsums: the pooled sums need sum_level < level and 16-byte aligned rows of >= C floats");
     int rc = check_level("sample_relu_cellsums", B, nbits, level, C);

@@ -157,12 +157,17 @@ class _DeferredLevel(torch.autograd.Function):
         c2 = q_rows.shape[1]
         if idx == 0:
             state.write_sums(0, base_rows.contiguous())
+        # forward only (model.eval() under no_grad, generator.py:142-147): nothing will read the sign pattern -- do not write it
+        need_bwd = any(ctx.needs_input_grad[:4])
         bits_ok = (SIGN_BITS and c2 % 256 == 0 and FUSED_SAMPLE_BWD and CELLS_MFMA and tile.n_points > 0 and
                    _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, tile.level(r), c2) > 0)
-        if bits_ok and ON_CHIP_HIDDEN and tile.n_points >= ON_CHIP_MIN_PTS_PER_CELL * tile.B * r * r:
+        on_chip = (bits_ok if need_bwd else (c2 % 256 == 0 and tile.n_points > 0)) and ON_CHIP_HIDDEN
+        if on_chip and tile.n_points >= ON_CHIP_MIN_PTS_PER_CELL * tile.B * r * r:
             # coarse sampling level: interpolation, ReLU, sign bits and the per-cell sums of the finest needed resolution in one
             # pass over the cells -- the hidden activations are never written to memory (t2h_sample_relu_cellsums)
-            bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
+            bits = None
+            if need_bwd:
+                bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
             lo, hi = state.off[idx + 1], state.off[idx + 2]
             levels = state.needed(idx + 1)
             finest = state._matrix(state.S, levels[0])[:, lo:hi]
@@ -172,9 +177,10 @@ class _DeferredLevel(torch.autograd.Function):
                 second = state._matrix(state.S, levels[1])[:, lo:hi]
             _lib.call("t2h_sample_relu_cellsums2", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
                       tile.N, tile.nbits, tile.level(r), levels[0], c2, finest.data_ptr(), finest.stride(0),
-                      None if second is None else second.data_ptr(), 0 if second is None else second.stride(0), _lib.ptr(bits),
-                      _lib.stream(), nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0] + (c2 // 8) * tile.n_points
-                      + (0 if second is None else 4 * c2 * second.shape[0]),
+                      None if second is None else second.data_ptr(), 0 if second is None else second.stride(0),
+                      None if bits is None else _lib.ptr(bits), _lib.stream(),
+                      nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0]
+                      + (0 if bits is None else (c2 // 8) * tile.n_points) + (0 if second is None else 4 * c2 * second.shape[0]),
                       tag=_lib.timing() and f"t2h_sample_relu_cellsums[C={c2},r={r}]")
             state.pool_down(idx + 1, start=1 if second is not None else 0)
             return _DeferredLevel._finish(ctx, state, idx, r, a_all, const, bits, True)
@@ -182,7 +188,7 @@ class _DeferredLevel(torch.autograd.Function):
         # the backward needs only the sign pattern of h: where its fused form will run, keep 1 bit per element (written by the
         # sample kernel's ballots) and let h go after the per-cell sums -- 1/32 of the bytes to keep and to re-read
         bits = None
-        if bits_ok:
+        if bits_ok and need_bwd:
             bits = torch.empty(tile.n_points * (c2 // 256) * 4, dtype=torch.int64, device=q_rows.device)
         _lib.call("t2h_sample_fwd_relu", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, tile.B, tile.N, r, c2, _lib.ptr(h),
                   None if bits is None else _lib.ptr(bits), _lib.stream(),
@@ -242,7 +248,7 @@ class _DeferredLevel(torch.autograd.Function):
             dconst = None
             state.cache.pending = True
         elif ctx.needs_input_grad[1]:
-            if ga_thru is not None and ga_thru.is_contiguous() and ga_thru.dtype == torch.float32:
+            if ga_thru is not None and ga_thru.is_contiguous() and ga_thru.dtype == torch.float32 and mlp.sole_owner(ga_thru):
                 mlp.linear_wgrad_(x, dacc, ga_thru, None, accumulate=True)  # x^T dacc, onto the next level's share
             else:
                 da = torch.empty_like(a_all)

@@ -237,13 +237,26 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return y.reshape(*lead, weight.shape[0])
 
 
+def sole_owner(g) -> bool:
+    """True if the gradient tensor ``g`` a backward() received is referenced by nobody but the engine's hand-off to THIS node, so
+    that accumulating into it in place cannot be seen elsewhere.  Not so when a consumer of the forward value returned its own
+    incoming gradient unchanged to several inputs (``z = y + other``: torch hands the SAME tensor to both producers) -- the
+    buffer is then still queued for another node.  The C++ reference count tells: 2 = the engine's input list + the Python
+    argument; the same for the base of a view (a channels_last gradient is a permuted view of its NHWC buffer)."""
+    if g._use_count() > 2:
+        return False
+    base = g._base
+    return base is None or base._use_count() <= 2
+
+
 def _join_plane_grad(dy, w, gthru, shape_nhwc, was_cl):
     """dplane = dy w (rows -> the NHWC plane) + gthru: the gradient of the plane's other consumers joins inside the data-gradient
-    kernel (accumulating epilogue) where it arrives as a dense NHWC tensor -- it was produced for this node alone (the autograd
-    engine hands a node the only reference to its summed input gradient) --, else by one add."""
+    kernel (accumulating epilogue) where it arrives as a dense NHWC tensor that nobody else still reads (``sole_owner``), else
+    by one add into a fresh tensor."""
     from . import ops
     b, r1, r2, c = shape_nhwc
-    if gthru is not None and gthru.dtype == torch.float32 and gthru.permute(0, 2, 3, 1).is_contiguous() and was_cl:
+    if (gthru is not None and gthru.dtype == torch.float32 and gthru.permute(0, 2, 3, 1).is_contiguous() and was_cl
+            and sole_owner(gthru)):
         linear_dgrad_(dy, w, gthru.permute(0, 2, 3, 1).reshape(b * r1 * r2, c), accumulate=True)
         return gthru
     drows = linear_dgrad_(dy, w, torch.empty(b * r1 * r2, c, dtype=torch.float32, device=dy.device))

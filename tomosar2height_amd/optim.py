@@ -93,6 +93,9 @@ class FlatAdamW(torch.optim.AdamW):
                       step, 1 if zero_grad else 0, _lib.stream(), nbytes=plan["bytes"])
             for p in plan["live"]:
                 self.state[p]["step"] += 1
+            # the kernel wrote the weights through raw pointers: tell autograd, as an in-place torch op would (anything
+            # that caches functions of the weights keys on ``_version`` -- deferred.ComposeCache -- and saved-tensor checks)
+            torch.autograd.graph.increment_version(plan["live"])
         return loss
 
     def load_state_dict(self, state_dict):

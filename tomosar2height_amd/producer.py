@@ -108,18 +108,40 @@ class TileSource:
         self.flip_augm, self.rotate_augm = flip_augm, rotate_augm
         self.rng = rng if rng is not None else np.random
         self.stream = stream
+        self._joined = False
 
-    def get(self, anchor):
+    def get(self, anchor, defer_wait: bool = False):
+        """``defer_wait`` (side stream only): do not make the caller's stream wait now; the tile carries a ``ready`` event and
+        the consumer calls ``TileSource.wait(tile)`` when it USES the tile -- so that a step issued between production and
+        use does not wait for the production."""
         if self.stream is None:
             return self._produce(anchor)
         main = torch.cuda.current_stream()
+        if not self._joined:
+            # the chunk upload and the producers' persistent buffers (_count, _out, _zshift) were initialised on the caller's
+            # stream: the side stream must see them before its first crop (afterwards only the side stream touches them)
+            self.stream.wait_stream(main)
+            self._joined = True
         with torch.cuda.stream(self.stream):
             out = self._produce(anchor)
-        main.wait_stream(self.stream)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
         for v in out.values():
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(main)                             # allocated on the side stream, consumed on the main one
+        if defer_wait:
+            out["ready"] = ready
+        else:
+            main.wait_event(ready)
         return out
+
+    @staticmethod
+    def wait(tile):
+        """Make the current stream wait for a tile produced with ``defer_wait=True`` (no-op otherwise); returns the tile."""
+        ev = tile.pop("ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return tile
 
     def _produce(self, anchor):
         rot = int(self.rng.choice(4)) if self.rotate_augm else 0

@@ -11,6 +11,7 @@ single-device accumulated gradient.  Parameters that never receive a gradient
 (``up_convs[depth-2].{upconv,fc_comm,fc_c}``, alto.py:241-242) are a static set and stay out of the bucket, so
 AdamW skips them exactly as it does in the reference.
 """
+import contextlib
 import os
 from collections import defaultdict
 
@@ -102,11 +103,14 @@ class Trainer:
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
         # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
         # gradients are therefore complete after ``flush_gradients()`` / at ``optimizer_boundary()``, not after every tile.
+        # Ownership: the cache belongs to THIS trainer and is visible to the network only while one of its own steps runs
+        # (``_own_cache``): a forward / backward issued by anybody else -- a second Trainer on the same model, a plain
+        # ``model(...).backward()`` -- never routes gradients into it and sees complete ``.grad`` (plain autograd).
         self.compose_cache = None
-        unet = getattr(getattr(model, "point_encoder", None), "unet", None)
-        if os.environ.get("T2H_COMPOSE_CACHE", "1") != "0" and unet is not None and hasattr(unet, "forward_sorted"):
+        self._unet = getattr(getattr(model, "point_encoder", None), "unet", None)
+        if os.environ.get("T2H_COMPOSE_CACHE", "1") != "0" and self._unet is not None and hasattr(self._unet, "forward_sorted"):
             from . import deferred
-            self.compose_cache = unet.compose_cache = deferred.ComposeCache()
+            self.compose_cache = deferred.ComposeCache()
 
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
@@ -114,6 +118,23 @@ class Trainer:
         self.last_avg_loss = 0.0
         self.last_avg_loss_dict = {"loss_ce": 0.0, "loss_l1": 0.0}
         self.use_cloud, self.use_image, self.use_footprint = use_cloud, use_image, use_footprint
+
+    # ------------------------------------------------------------------------------------------ compose cache
+    @contextlib.contextmanager
+    def _own_cache(self):
+        """Make this trainer's ComposeCache the one the ALTO U-Net uses for the forward passes issued inside (their backward
+        keeps the cache the forward saw).  Refuses to run inside another trainer's step on the same network."""
+        if self.compose_cache is None:
+            yield
+            return
+        prev = getattr(self._unet, "compose_cache", None)
+        if prev is not None and prev is not self.compose_cache:
+            raise RuntimeError("Trainer: another Trainer's step is active on this network (nested train_step)")
+        self._unet.compose_cache = self.compose_cache
+        try:
+            yield
+        finally:
+            self._unet.compose_cache = prev
 
     # ------------------------------------------------------------------------------------------ loss
     def _losses(self, data, mask_threshold):
@@ -146,18 +167,19 @@ class Trainer:
         saved_cache = self.compose_cache.snapshot() if self.compose_cache is not None else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                      # warm-up on a side stream, as torch.cuda.graphs prescribes
-            for _ in range(2):
+        with self._own_cache():
+            with torch.cuda.stream(side):                  # warm-up on a side stream, as torch.cuda.graphs prescribes
+                for _ in range(2):
+                    l1, ce = self._losses(static, 0.0001)
+                    with mlp.direct_grad_accumulation(self.direct_accumulation):
+                        (l1 + ce).backward()
+            del l1, ce                                     # drop the warm-up autograd graph (and its AccumulateGrad nodes)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):     # capture on the stream the warm-up ran on
                 l1, ce = self._losses(static, 0.0001)
                 with mlp.direct_grad_accumulation(self.direct_accumulation):
                     (l1 + ce).backward()
-        del l1, ce                                         # drop the warm-up autograd graph (and its AccumulateGrad nodes)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):         # capture on the stream the warm-up ran on
-            l1, ce = self._losses(static, 0.0001)
-            with mlp.direct_grad_accumulation(self.direct_accumulation):
-                (l1 + ce).backward()
         self.bucket.flat.copy_(saved)
         if saved_cache is not None:
             self.compose_cache.restore(saved_cache)
@@ -197,7 +219,8 @@ class Trainer:
             loss_l1, loss_ce = g["l1"], g["ce"]
             loss = loss_l1 + loss_ce
         else:
-            loss_l1, loss_ce = self._losses(data, 0.0001)                 # trainer.py:63-69
+            with self._own_cache():
+                loss_l1, loss_ce = self._losses(data, 0.0001)             # trainer.py:63-69
             loss = loss_l1 + loss_ce
             side = None
             if self.overlap_wgrad and self.bucket is not None and loss.is_cuda:
@@ -261,7 +284,10 @@ class Trainer:
                                  "(or NaN): normalise / crop the tiles as dataset.py:270-278 does")
         self.optimizer.step()
         if self.compose_cache is not None:
-            self.compose_cache.refresh()                                  # new weights -> new composed maps (in place)
+            # new weights -> new composed maps, in place.  (A forward would notice by itself -- every optimizer, FlatAdamW
+            # included, bumps the parameters' version counters, which ComposeCache.get compares -- but a replayed hipGraph
+            # runs no Python per tile.)
+            self.compose_cache.refresh()
         if self.scheduler is not None:
             self.scheduler.step()                                         # train.py:188-190: once per iteration
         with torch.no_grad():
