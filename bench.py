@@ -40,6 +40,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak
+# csrc/conv_bx3.hip forms an fp32 product from six bf16 MFMAs: its ceiling in ALGORITHMIC (fp32-equivalent) flops is the dense
+# bf16 peak / 6 -- the same fraction as executed bf16 flops / 2.5 PF
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_BX3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6
 # the scatter-reduce kernels north_star names: the largest scatter_mean, and pool_local -- which since r02 has no kernel of
 # its own: the segmented max / its backward run in the loaders of the fused trunk block kernels (csrc/trunk.hip)
 # r03: with the deferred point update (deferred.py) the wide scatter_means run as per-cell SUMS of the hidden activations
@@ -262,22 +266,24 @@ def infer_bench(args, world, rank, dev, group):
 def kernel_tables(timeline, n_steps):
     """(per-tag rows, per-symbol rows) from a KernelTimeline over ``n_steps`` tile-steps, both sorted by time."""
     def row(name, d):
+        peak_tf = MFMA_BX3_PEAK_TFLOPS if str(d.get("symbol", name)).startswith("bx3_") else MFMA_F32_PEAK_TFLOPS
         avg_us = 1e3 * d["ms"] / d["calls"]
         per_b, per_f = d["bytes"] / d["calls"], d["flops"] / d["calls"]
         gbs = per_b / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
         tfs = per_f / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
         # the roofline that bounds the launch: arithmetic intensity against the machine balance (157.3 TF / 8 TB/s)
-        mfma = per_f > 0 and per_f / max(per_b, 1) > MFMA_F32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+        mfma = per_f > 0 and per_f / max(per_b, 1) > peak_tf * 1e3 / HBM_PEAK_GBS
         return {"kernel": name, "launches_per_step": round(d["calls"] / n_steps, 2), "avg_us": round(avg_us, 2),
                 "bytes_per_launch": int(per_b), "flops_per_launch": int(per_f), "GBps": round(gbs, 1),
-                "TFLOPs": round(tfs, 2), "bound": "mfma" if mfma else "hbm",
-                "frac": round(tfs / MFMA_F32_PEAK_TFLOPS if mfma else gbs / HBM_PEAK_GBS, 4),
+                "TFLOPs": round(tfs, 2), "bound": "mfma" if mfma else "hbm", "peak_tflops": round(peak_tf, 1),
+                "frac": round(tfs / peak_tf if mfma else gbs / HBM_PEAK_GBS, 4),
                 "ms_per_step": round(d["ms"] / n_steps, 4)}
 
     per_tag = timeline.summary()
     per_symbol = {}
     for name, d in per_tag.items():
-        s = per_symbol.setdefault(d["symbol"], {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0, "entry_points": set()})
+        s = per_symbol.setdefault(d["symbol"], {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0, "entry_points": set(),
+                                                "symbol": d["symbol"]})
         for k in ("calls", "ms", "bytes", "flops"):
             s[k] += d[k]
         s["entry_points"].add(name.split("[")[0])
@@ -290,7 +296,7 @@ def kernel_tables(timeline, n_steps):
 def roof(k, traffic=None):
     mfma = k["bound"] == "mfma"
     return {"kernel": k["kernel"], "bound": k["bound"], "achieved": k["TFLOPs"] if mfma else k["GBps"],
-            "peak": MFMA_F32_PEAK_TFLOPS if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s",
+            "peak": k.get("peak_tflops", MFMA_F32_PEAK_TFLOPS) if mfma else HBM_PEAK_GBS, "unit": "TFLOP/s" if mfma else "GB/s",
             "frac": k["frac"], "traffic": traffic, "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"]}
 
 

@@ -85,6 +85,121 @@ def test_conv3x3_data_and_weight_gradient(shape):
     assert torch.equal(dw, dw0)
 
 
+# ---- the bf16 matrix-core path with the exact 3-way operand split (csrc/conv_bx3.hip) ------------------------------------------
+# (B, H, W, Cin, Cout): one tile, several chunks, batch > 1, non-square, every BN (32 / 64 / 128 / 2 x 128) and every wgrad
+# grouping (Cout = 32, 64, 96, 128, 256), H = 4 (tile = plane height)
+BX3_SHAPES = [(1, 32, 32, 32, 32), (1, 64, 64, 64, 128), (2, 16, 32, 32, 64), (1, 4, 64, 128, 32), (1, 32, 128, 96, 96),
+              (3, 8, 32, 64, 256), (1, 128, 128, 32, 64)]
+
+
+@pytest.fixture
+def bx3_everywhere(monkeypatch):
+    from tomosar2height_amd import grid
+    monkeypatch.setattr(grid, "CONV_PRECISION", "bf16x3")
+    monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 0)
+    monkeypatch.setattr(grid, "BX3_WGRAD", True)
+    return grid
+
+
+@pytest.mark.parametrize("shape", BX3_SHAPES)
+def test_conv3x3_bx3_against_float64(shape, bx3_everywhere):
+    """Forward (bias, ReLU, accumulate), data gradient (mask, accumulate) and weight / bias gradient of the split-bf16 kernels
+    against float64 F.conv2d -- the SAME tolerance as the fp32 MFMA kernels (2e-5 of the max-norm): the split is exact, the
+    accumulation fp32."""
+    grid = bx3_everywhere
+    b, h, w, cin, cout = shape
+    assert grid.bx3_applicable(b, h, w, cin, cout)
+    g = torch.Generator().manual_seed(11 + sum(shape))
+    x = torch.randn(b, cin, h, w, generator=g).double().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    bias = torch.randn(cout, generator=g).double().requires_grad_(True)
+    gy = torch.randn(b, cout, h, w, generator=g)
+    want = F.conv2d(x, wt, bias, padding=1)
+    want.backward(gy.double())
+    xd, wd, gyd = _cl(x.detach().float()), _cl(wt.detach().float()), _cl(gy)
+    from tomosar2height_amd import _lib
+    with _lib.KernelTimeline() as tl:
+        y = grid._empty_cl(b, cout, h, w, _dev())
+        grid.conv3x3_fwd_(xd, wd, bias.detach().float().to(_dev()), y, relu=True)
+        dx = grid._empty_cl(b, cin, h, w, _dev())
+        grid.conv3x3_dgrad_(gyd, wd, dx)
+        dw = torch.empty(cout, cin, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+        db = torch.empty(cout, device=_dev())
+        grid.conv3x3_wgrad_(gyd, xd, dw, db)
+    torch.cuda.synchronize()
+    assert sorted(r[5].split("<")[0] for r in tl.records if r[5].startswith("bx3")) == ["bx3_rows_kernel", "bx3_rows_kernel", "bx3_wgrad_kernel"]
+    _close(y, F.relu(want.detach()))
+    _close(dx, x.grad)
+    _close(dw, wt.grad)
+    _close(db, bias.grad)
+    base = torch.randn(b, cout, h, w, generator=g)
+    y2 = _cl(base.clone())
+    grid.conv3x3_fwd_(xd, wd, None, y2, accumulate=True)
+    _close(y2, base.double() + F.conv2d(x.detach(), wt.detach(), None, padding=1))
+    mask = torch.randn(b, cin, h, w, generator=g)
+    base = torch.randn(b, cin, h, w, generator=g)
+    dx2 = _cl(base.clone())
+    grid.conv3x3_dgrad_(gyd, wd, dx2, mask=_cl(mask), accumulate=True)
+    _close(dx2, base.double() + x.grad * (mask > 0))
+    dw0, db0 = dw.clone(), db.clone()
+    grid.conv3x3_wgrad_(gyd, xd, dw, db, accumulate=True)
+    assert torch.equal(dw, dw0 + dw0) and torch.equal(db, db0 + db0)          # same slabs, same order: exact doubling
+    grid.conv3x3_wgrad_(gyd, xd, dw, None)
+    assert torch.equal(dw, dw0)
+
+
+def test_conv3x3_bx3_error_is_fp32_grade(bx3_everywhere):
+    """The claim behind routing fp32 convolutions through bf16 MFMAs: against float64 the split path's error, relative to
+    sum |a b| of each output, is the fp32 fma chain's (measured 1.5-2.1e-7 for both; bound here 4e-7), for inputs with sign changes
+    and three decades of dynamic range; and NaN / Inf propagate."""
+    grid = bx3_everywhere
+    g = torch.Generator().manual_seed(5)
+    b, cin, cout, h, w = 1, 64, 128, 64, 64
+    x = torch.randn(b, cin, h, w, generator=g) * torch.logspace(-1.5, 1.5, cin).view(1, -1, 1, 1)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    want = F.conv2d(x.double(), wt.double(), None, padding=1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
+    errs = {}
+    for mode in ("bf16x3", "fp32"):
+        grid.CONV_PRECISION = mode
+        y = grid._empty_cl(b, cout, h, w, _dev())
+        grid.conv3x3_fwd_(_cl(x), _cl(wt), None, y)
+        errs[mode] = ((y.cpu().double() - want).abs() / mag).max().item()
+    grid.CONV_PRECISION = "bf16x3"
+    print(f"[bx3] max |err| / sum|a b| vs float64: {errs}")
+    assert errs["bf16x3"] <= 4e-7 and errs["fp32"] <= 4e-7
+    x2 = x.clone()
+    x2[0, 3, 10, 10], x2[0, 5, 40, 40] = float("nan"), float("inf")
+    y = grid._empty_cl(b, cout, h, w, _dev())
+    grid.conv3x3_fwd_(_cl(x2), _cl(wt), None, y)
+    yc = y.cpu()
+    assert torch.isnan(yc[0, :, 9:12, 9:12]).all() and not torch.isfinite(yc[0, :, 39:42, 39:42]).any()
+    assert torch.isfinite(yc[0, :, 20:30, 20:30]).all()
+
+
+def test_split_weight_cache_follows_the_weight(bx3_everywhere):
+    """The split weights are recomputed when the weight's version counter or storage moves (optimizer steps -- FlatAdamW bumps
+    the counter --, load_state_dict), in place (a captured hipGraph keeps its pointers), and not otherwise."""
+    grid = bx3_everywhere
+    g = torch.Generator().manual_seed(9)
+    x = _cl(torch.randn(1, 32, 32, 32, generator=g))
+    w = torch.nn.Parameter(_cl(torch.randn(32, 32, 3, 3, generator=g) * 0.1))
+    buf = grid.split_weights.get(w, False)
+    ptr = buf.data_ptr()
+    snap = buf.clone()
+    assert grid.split_weights.get(w, False).data_ptr() == ptr and torch.equal(buf, snap)
+    with torch.no_grad():
+        w.mul_(2.0)                                                         # in-place update: version bump
+    buf2 = grid.split_weights.get(w, False)
+    assert buf2.data_ptr() == ptr and not torch.equal(buf2, snap)
+    y = grid._empty_cl(1, 32, 32, 32, _dev())
+    grid.conv3x3_fwd_(x, w.detach(), None, y)                               # (a detached alias is another tensor object: own entry)
+    _close(y, F.conv2d(x.cpu().double(), w.detach().cpu().double(), None, padding=1))
+    w.data.zero_()                                                          # raw write without a version bump ...
+    grid.split_weights.refresh()                                            # ... is what refresh() is for (hipGraph replay)
+    assert int(grid.split_weights.get(w, False).abs().sum().item()) == 0
+
+
 def test_conv3x3_is_deterministic():
     from tomosar2height_amd import grid
     g = torch.Generator().manual_seed(3)

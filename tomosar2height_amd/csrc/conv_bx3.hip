@@ -1,0 +1,561 @@
+// 3x3 grid convolutions (stride 1, zero padding 1) on the bf16 matrix cores with an EXACT 3-way split of both operands:
+// fp32-grade results at up to 2.67x the rate of v_mfma_f32_32x32x2_f32 (conv.hip), for planes at least 32 pixels wide
+// (reference: conv3x3 of alto.py:59-61,157-182 with F.relu at alto.py:98-99,226-227; ConvDecoder pixel.py:20-32).
+//
+// Arithmetic.  x = x1 + x2 + x3 exactly, x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (round to nearest even; both
+// differences are exact in fp32: 24 = 8 + 8 + 8 significant bits, the residuals carry their own signs).  Of the nine partial
+// products a_i b_j of a product a b the six with i + j <= 4 are formed (a3b1, a1b3, a2b2, a2b1, a1b2, a1b1); the three dropped
+// ones are below 2^-25 |a b|.  A bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so
+// the result differs from conv.hip's fp32 fma chain in rounding ORDER only: measured against float64 (profiles/
+// conv_bf16x3_lab.hip, tests/test_hip_conv.py) both sit at 1.5-2e-7 of sum |a b|.  6 MFMAs x 32 cycles per 16 k of a 32 x 32
+// tile = 12 cycles per k against 32.
+//
+// Layout as conv.hip: activations NHWC [B,H,W,C], weights [Cout][3][3][Cin], H and W powers of two.
+//
+//   fwd / dgrad ("rows"): a workgroup owns 4 image rows x 32 columns x BN output channels.  Per 32-channel chunk of the
+//     reduction it reads the (4 + 2) x 34 pixel HALO tile once (fp32), splits it once and keeps it in LDS as three bf16 images
+//     (80-byte pixel stride, an odd multiple of 16 B: the ds_read_b128 fragments of every tap are conflict-free); the nine taps
+//     are shifted fragment reads of that image -- nothing is converted or re-fetched in the MFMA loop.  The weights are split
+//     ONCE per optimizer step (t2h_conv3x3_bx3_prepare) into the byte order of the MFMA B fragments, so a (tap, 16-channel)
+//     slab is a linear 3 KB run per 32 output channels: LDS-DMA (global_load_lds_dwordx4), double buffered.  The data
+//     gradient is the same kernel on flipped + transposed prepared weights, with the ReLU mask / accumulate in its epilogue.
+//   wgrad: dW[co][tap][ci] = sum_p dY[p][co] X[p + off(tap)][ci] reduces over PIXELS, so both MFMA operands need 8 consecutive
+//     pixels of one channel per lane: ds_read_b64_tr_b16, the hardware transpose read, from the same [pixel][channel] bf16 images
+//     (row strides chosen so that four consecutive pixel rows tile the 256-byte bank row).  A workgroup owns a 32-channel
+//     chunk of Cin and up to 128 of Cout, walks image-row segments of 32 pixels (X halo: 3 x 34 pixels) and keeps all
+//     (Cout / 32) x 9 output tiles in registers; partial sums of the pixel ranges go to slabs, summed in a fixed order by
+//     reduce_slabs (deterministic, no atomics); the bias gradient (column sums of dY) comes out of the dY staging pass.
+#include <stdlib.h>
+#include "t2h_common.h"
+#include "gemm_args.h"
+#include "gemm_tile.h"
+
+namespace t2h {
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int NT = 256;
+constexpr int TW = 32;        // tile width in pixels = rows of one MFMA tile
+constexpr int CC = 32;        // reduction channels per staged chunk
+
+// ---- the split -----------------------------------------------------------------------------------------------------------
+__device__ inline unsigned pack_bf16x2(float a, float b) {             // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<unsigned *>(&r);
+}
+__device__ inline float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ inline float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+// two floats -> three packed bf16 pairs (high, middle, low part)
+__device__ inline void split3(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = pack_bf16x2(a, b);
+    const float ra = __fsub_rn(a, bf_lo(p1)), rb = __fsub_rn(b, bf_hi(p1));        // exact
+    p2 = pack_bf16x2(ra, rb);
+    const float sa = __fsub_rn(ra, bf_lo(p2)), sb = __fsub_rn(rb, bf_hi(p2));      // exact
+    p3 = pack_bf16x2(sa, sb);
+}
+
+// ---- weight preparation: [Cout][9][Cin] fp32 -> MFMA B-fragment order, three bf16 planes --------------------------------------
+// slab (chunk c of 32 reduction channels, tap t, half q) x [tile of 32 output channels][plane][lane][8 bf16]; lane (r = l & 31,
+// h = l >> 5) holds B[k = 8 h + j][col r].  Forward: k = input channel, col = output channel, W[col][tap][k].  Transposed (data
+// gradient): k = output channel, col = input channel, tap flipped: W[k][8 - tap][col].
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restrict__ w, int Cin, int Cout,
+                                                         unsigned *__restrict__ wf) {
+    const int Kc = TRANSPOSED ? Cout : Cin, Nc = TRANSPOSED ? Cin : Cout;
+    const int ntile = Nc / 32;
+    const long long total = (long long)(Kc / 16) * 9 * ntile * 64;        // one thread per (slab, tile, lane)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int tile = (int)((t >> 6) % ntile);
+    const long long slab = (t >> 6) / ntile;                              // (c * 9 + tap) * 2 + q
+    const int q = (int)(slab & 1), tap = (int)((slab >> 1) % 9), c = (int)((slab >> 1) / 9);
+    const int r = lane & 31, h = lane >> 5;
+    const int n = tile * 32 + r, k0 = c * 32 + q * 16 + 8 * h;
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a, b;
+        if (!TRANSPOSED) {
+            a = w[((size_t)n * 9 + tap) * Cin + k0 + 2 * j];
+            b = w[((size_t)n * 9 + tap) * Cin + k0 + 2 * j + 1];
+        } else {
+            a = w[((size_t)(k0 + 2 * j) * 9 + (8 - tap)) * Cin + n];
+            b = w[((size_t)(k0 + 2 * j + 1) * 9 + (8 - tap)) * Cin + n];
+        }
+        split3(a, b, p1[j], p2[j], p3[j]);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((slab * ntile + tile) * 3) * 64 + lane;
+    dst[0] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
+// ---- fwd / dgrad --------------------------------------------------------------------------------------------------------------
+struct RowsArgs {
+    const float *x;          // [B,H,W,Kc] fp32: the input (fwd) or dY (dgrad)
+    const unsigned *wf;      // prepared weights
+    const float *bias;       // [Nc] or null
+    const float *mask;       // [B,H,W,Nc] or null: result *= (mask > 0)
+    float *y;                // [B,H,W,Nc]
+    int B, H, W, Kc, Nc, flags;
+};
+
+constexpr int PXB = 80;      // bytes per pixel and plane of the halo image: 32 bf16 + 16 B of padding
+
+template <int TH, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
+    constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
+    constexpr int HP = (TH + 2) * (TW + 2);                              // halo pixels
+    constexpr int PLANE = HP * PXB;                                      // bytes per bf16 plane
+    constexpr int BSLAB = (BN / 32) * 3 * 1024;                          // bytes per weight slab
+    constexpr int HALO_BYTES = 3 * PLANE;
+    constexpr int LDS_BYTES = HALO_BYTES + 2 * BSLAB;
+    static_assert(LDS_BYTES >= 4 * 32 * 36 * 4, "the epilogue's patches live in the same array");
+    static_assert(WAVES_M * WAVES_N == 4 && TM * WAVES_M == TH && TN * WAVES_N * 32 == BN, "wave layout");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char *halo = lds, *bbuf = lds + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // XCD-aware order: a contiguous run of tiles per XCD (neighbouring tiles share halo pixels and all share the weights in L2)
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned qq = nb / 8, rr = nb % 8, xx = bid % 8, i8 = bid / 8;
+    unsigned t = (xx < rr ? xx * (qq + 1) : rr * (qq + 1) + (xx - rr) * qq) + i8;
+    const int ntn = p.Nc / BN;
+    const int tn = t % ntn; t /= ntn;
+    const int tiles_x = p.W / TW;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int tiles_y = p.H / TH;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, n0 = tn * BN;
+    const int nchunk = p.Kc / CC;
+
+    // halo staging: 8 float4 per pixel and chunk
+    constexpr int NF4 = HP * 8, PER = (NF4 + NT - 1) / NT;
+    float4 hreg[PER];
+    auto halo_load = [&](int c) {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            const int idx = tid + f * NT;
+            const int px = idx >> 3, c4 = idx & 7;
+            const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.Kc + c * CC + c4 * 4);
+            hreg[f] = v;
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            const int idx = tid + f * NT;
+            if (idx < NF4) {
+                const int px = idx >> 3, c4 = idx & 7;
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3(hreg[f].x, hreg[f].y, a1, a2, a3);
+                split3(hreg[f].z, hreg[f].w, b1, b2, b3);
+                unsigned char *d = halo + px * PXB + c4 * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a3, b3);
+            }
+        }
+    };
+    // weight slab s = (chunk * 9 + tap) * 2 + q: (Nc / 32) x 3 KB; this workgroup's BN / 32 tiles of it are one linear run
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * 3 * 1024;
+    const size_t slab_stride = (size_t)(p.Nc / 32) * 3 * 1024;
+    auto issue_b = [&](int s, unsigned char *dst) {
+        const unsigned char *src = wbase + (size_t)s * slab_stride;
+        constexpr int PIECES = BSLAB / 1024;                             // 1 KB per wave instruction, dealt round-robin to the waves
+#pragma unroll
+        for (int j = 0; j < (PIECES + 3) / 4; ++j)
+            if (j * 4 + wave < PIECES)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + (j * 256 + tid) * 16), (lds_void *)(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
+
+    const int r = lane & 31, h = lane >> 5;
+    halo_load(0);
+    int s = 0;                                                           // running slab index
+    const int last = nchunk * 18 - 1;
+    for (int c = 0; c < nchunk; ++c) {
+        halo_store();                                                    // (the previous chunk's last barrier has passed)
+        if (c == 0) issue_b(0, bbuf);                                    // (later chunks: issued by the previous chunk's last step)
+        if (c + 1 < nchunk) halo_load(c + 1);                            // in flight under this chunk's MFMAs
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int q = 0; q < 2; ++q, ++s) {
+                const unsigned char *cur = bbuf + (s & 1) * BSLAB;
+                if (s < last) issue_b(s + 1, bbuf + ((s + 1) & 1) * BSLAB);
+                uint4 af[TM][3], bfr[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
+                    const unsigned char *a = halo + px * PXB + q * 32 + h * 16;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bfr[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * 3 + pl) * 1024 + lane * 16);
+                __builtin_amdgcn_sched_barrier(0);                       // all fragment reads in flight before the first MFMA
+                // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
+                constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ia[e]]),
+                                                                                 *reinterpret_cast<bf16x8 *>(&bfr[j][ib[e]]), acc[i][j], 0, 0, 0);
+                __syncthreads();                                         // (also drains the next slab's DMA: vmcnt(0))
+            }
+        }
+    }
+
+    // epilogue: one 32 x 32 tile at a time through the wave's LDS patch -> float4 rows along the output channels
+    float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + ec;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + col);
+            const size_t pix0 = ((size_t)b * p.H + y0 + wm * TM + i) * p.W + x0;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
+                const size_t o = (pix0 + pass * 8 + er) * p.Nc + col;
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.mask) {
+                    const float4 mk = *reinterpret_cast<const float4 *>(p.mask + o);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+                float4 *dst = reinterpret_cast<float4 *>(p.y + o);
+                if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                *dst = v;
+            }
+        }
+}
+
+// ---- wgrad ----------------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *dy;         // [B,H,W,Cout]
+    const float *x;          // [B,H,W,Cin]
+    float *slab;             // [splits][Cout][9 Cin]
+    float *colslab;          // [splits][Cout] or null
+    int H, W, Cin, Cout;
+    int n_units, units_per_split;
+};
+
+// COT = 32-channel tiles of Cout per workgroup (4, 2 or 1): the workgroup's (COT x 9) output tiles are dealt to the four waves
+// as (co tile, contiguous tap range)
+template <int COT>
+__global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
+    constexpr int WPC = 4 / COT;                                         // waves per co tile
+    constexpr int TMAX = (9 + WPC - 1) / WPC;                            // taps per wave, at most
+    constexpr int YS = COT == 1 ? 64 : 64 * COT + 64;                    // dY image: bytes per pixel row (4 rows tile the bank row)
+    constexpr int XS = 64;                                               // X image: 32 bf16 per pixel, no padding
+    constexpr int YPLANE = 32 * YS, XHP = 3 * (TW + 2), XPLANE = XHP * XS;
+    constexpr int LDS_BYTES = 3 * YPLANE + 3 * XPLANE;
+    static_assert(LDS_BYTES >= 4 * 32 * 36 * 4, "the epilogue's patches live in the same array");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char *yimg = lds, *ximg = lds + 3 * YPLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x, ci0 = blockIdx.y * CC, co0 = blockIdx.z * (32 * COT);
+    const int u_beg = split * p.units_per_split, u_end = min(p.n_units, u_beg + p.units_per_split);
+    const int segs = p.W / TW;
+
+    const int cot = wave / WPC, sub = wave % WPC;                         // this wave's co tile and tap range
+    const int tap_lo = (9 * sub + WPC - 1) / WPC, tap_hi = (9 * (sub + 1) + WPC - 1) / WPC;
+
+    // staging registers: X halo 3 x 34 pixels x 8 float4; dY 32 pixels x (8 COT) float4
+    constexpr int XF4 = XHP * 8, XPER = (XF4 + NT - 1) / NT;
+    constexpr int YPER = COT;
+    float4 xr[XPER], yr[YPER];
+    auto load_unit = [&](int u) {
+        const int xs = u % segs, row = u / segs;                         // row = b * H + y
+        const int y = row & (p.H - 1), x0 = xs * TW;
+#pragma unroll
+        for (int f = 0; f < XPER; ++f) {
+            const int idx = tid + f * NT;
+            const int px = idx >> 3, c4 = idx & 7;
+            const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
+            const int gy = y + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < XF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(row + hy - 1) * p.W + gx) * p.Cin + ci0 + c4 * 4);
+            xr[f] = v;
+        }
+#pragma unroll
+        for (int f = 0; f < YPER; ++f) {
+            const int idx = tid + f * NT;
+            const int px = idx / (8 * COT), c4 = idx % (8 * COT);
+            yr[f] = *reinterpret_cast<const float4 *>(p.dy + ((size_t)row * p.W + x0 + px) * p.Cout + co0 + c4 * 4);
+        }
+    };
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_colsum = p.colslab != nullptr && blockIdx.y == 0;
+    auto store_unit = [&]() {
+#pragma unroll
+        for (int f = 0; f < XPER; ++f) {
+            const int idx = tid + f * NT;
+            if (idx < XF4) {
+                const int px = idx >> 3, c4 = idx & 7;
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3(xr[f].x, xr[f].y, a1, a2, a3);
+                split3(xr[f].z, xr[f].w, b1, b2, b3);
+                unsigned char *d = ximg + px * XS + c4 * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(d + XPLANE) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(d + 2 * XPLANE) = make_uint2(a3, b3);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < YPER; ++f) {
+            const int idx = tid + f * NT;
+            const int px = idx / (8 * COT), c4 = idx % (8 * COT);
+            unsigned a1, a2, a3, b1, b2, b3;
+            split3(yr[f].x, yr[f].y, a1, a2, a3);
+            split3(yr[f].z, yr[f].w, b1, b2, b3);
+            unsigned char *d = yimg + px * YS + c4 * 8;
+            *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2 *>(d + 2 * YPLANE) = make_uint2(a3, b3);
+            if (do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
+        }
+    };
+
+    f32x16 acc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+        for (int z = 0; z < 16; ++z) acc[t][z] = 0.0f;
+
+    // transposed fragment reads: 16-lane group g = lane >> 4 takes the block of 4 pixels x 16 channels with pixel base 8 (g >> 1)
+    // and channel base 16 (g & 1); lane 4 q + p of the group supplies the address of pixel row q, channels 4 p .. 4 p + 3 and
+    // receives channel (lane & 15) of the four pixels.  Two reads (pixels +0..3, +4..7) make the 8 k of one MFMA operand.
+    const int g = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    const int kpix = 8 * (g >> 1) + gq;                                   // pixel (k) of this lane's address inside a 16-pixel step
+    const int choff = (16 * (g & 1) + 4 * gp) * 2;                        // byte offset of its four channels
+    auto tr8 = [&](const unsigned char *a, int row_stride) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(a));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(a + 4 * row_stride));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return *reinterpret_cast<const bf16x8 *>(&v);
+    };
+
+    if (u_beg < u_end) load_unit(u_beg);
+    for (int u = u_beg; u < u_end; ++u) {
+        store_unit();
+        if (u + 1 < u_end) load_unit(u + 1);                             // in flight under this unit's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                                    // two 16-pixel steps
+            bf16x8 af[3];
+            const unsigned char *ya = yimg + (16 * s + kpix) * YS + cot * 64 + choff;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = tr8(ya + pl * YPLANE, YS);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                const int tap = tap_lo + t;
+                if (tap < tap_hi) {                                       // wave-uniform
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const unsigned char *xa = ximg + (ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
+                    bf16x8 bfr[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
+                    constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia[e]], bfr[ib[e]], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                  // every wave has read the images
+    }
+
+    // bias gradient: the threads that share a channel group are summed in a fixed order
+    if (do_colsum) {
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = csum;
+        __syncthreads();
+        constexpr int CG = 8 * COT;
+        if (tid < CG) {
+            float4 tsum = red[tid];
+            for (int j = tid + CG; j < NT; j += CG) { tsum.x += red[j].x; tsum.y += red[j].y; tsum.z += red[j].z; tsum.w += red[j].w; }
+            *reinterpret_cast<float4 *>(p.colslab + (size_t)split * p.Cout + co0 + tid * 4) = tsum;
+        }
+        __syncthreads();
+    }
+
+    // slab tile (co tile, tap): rows co, columns tap * Cin + ci0 .. + 31
+    float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    const int er = lane >> 3, ec = (lane & 7) * 4, r = lane & 31, h = lane >> 5;
+    float *sbase = p.slab + (size_t)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int tap = tap_lo + t;
+        if (tap < tap_hi) {
+#pragma unroll
+            for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[t][z];
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
+                const int co = co0 + cot * 32 + pass * 8 + er;
+                *reinterpret_cast<float4 *>(sbase + ((size_t)co * 9 + tap) * p.Cin + ci0 + ec) = v;
+            }
+        }
+    }
+}
+
+bool al16(const void *q) { return (uintptr_t)q % 16 == 0; }
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// geometry both directions need: planes at least one 4 x 32 tile, channel counts in multiples of 32
+int check_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
+    if (B < 1 || !pow2(H) || !pow2(W) || H < 4 || W < TW || H > 32768 || W > 32768 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32)
+        return fail(T2H_ERR_ARG, "%s: needs power-of-two H >= 4, W >= 32 and Cin, Cout multiples of 32 (B=%d H=%d W=%d %d->%d)", what, B,
+                    H, W, Cin, Cout);
+    if ((long long)B * H * W > (1LL << 30)) return fail(T2H_ERR_ARG, "%s: more than 2^30 pixels", what);
+    return T2H_OK;
+}
+
+int launch_rows(const RowsArgs &a, hipStream_t s, const char *what) {
+    const int bn = a.Nc % 128 == 0 ? 128 : (a.Nc % 64 == 0 ? 64 : 32);
+    const long long tiles = (long long)a.B * (a.H / 4) * (a.W / TW) * (a.Nc / bn);
+    if (tiles > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
+    if (bn == 128) { hipLaunchKernelGGL((bx3_rows_kernel<4, 128, 2, 2>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,128,2,2>"); }
+    else if (bn == 64) { hipLaunchKernelGGL((bx3_rows_kernel<4, 64, 2, 2>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,64,2,2>"); }
+    else { hipLaunchKernelGGL((bx3_rows_kernel<4, 32, 4, 1>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,32,4,1>"); }
+    return check_launch(what);
+}
+
+struct WgradPlan { int cot, splits, units_per_split, n_units; };
+WgradPlan bx3_wgrad_plan(int B, int H, int W, int Cin, int Cout) {
+    WgradPlan p{};
+    p.cot = Cout % 128 == 0 ? 4 : (Cout % 64 == 0 ? 2 : 1);
+    p.n_units = B * H * (W / TW);
+    const long long groups = (long long)(Cin / CC) * (Cout / (32 * p.cot));
+    static const long long target = getenv("T2H_BX3_WGRAD_WGS") ? atoll(getenv("T2H_BX3_WGRAD_WGS")) : 512;
+    long long splits = target / groups;
+    if (splits < 1) splits = 1;
+    if (splits > p.n_units) splits = p.n_units;
+    p.units_per_split = (int)((p.n_units + splits - 1) / splits);
+    p.splits = (p.n_units + p.units_per_split - 1) / p.units_per_split;
+    return p;
+}
+
+}  // namespace
+}  // namespace t2h
+
+using namespace t2h;
+
+T2H_API int t2h_conv3x3_bx3_supported(int B, int H, int W, int Cin, int Cout) {
+    return B >= 1 && pow2(H) && pow2(W) && H >= 4 && W >= TW && H <= 32768 && W <= 32768 && Cin >= 32 && Cout >= 32 && Cin % 32 == 0 &&
+           Cout % 32 == 0 && (long long)B * H * W <= (1LL << 30);
+}
+
+T2H_API size_t t2h_conv3x3_bx3_weights_bytes(int Cin, int Cout) {
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
+    return (size_t)Cout * 9 * Cin * 6;                                   // three bf16 planes
+}
+
+T2H_API int t2h_conv3x3_bx3_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream) {
+    if (!w || !wf) return fail(T2H_ERR_ARG, "conv3x3_bx3_prepare: null pointer");
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || !al16(wf))
+        return fail(T2H_ERR_ARG, "conv3x3_bx3_prepare: Cin=%d, Cout=%d must be multiples of 32, wf 16-byte aligned", Cin, Cout);
+    const int Kc = transposed ? Cout : Cin, Nc = transposed ? Cin : Cout;
+    const long long total = (long long)(Kc / 16) * 9 * (Nc / 32) * 64;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (transposed) hipLaunchKernelGGL(bx3_prepare_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), w, Cin, Cout, static_cast<unsigned *>(wf));
+    else hipLaunchKernelGGL(bx3_prepare_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), w, Cin, Cout, static_cast<unsigned *>(wf));
+    return check_launch("conv3x3_bx3_prepare");
+}
+
+T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
+                                int flags, t2h_stream_t stream) {
+    if (!x || !wf || !y) return fail(T2H_ERR_ARG, "conv3x3_bx3_fwd: null pointer");
+    if (int rc = check_bx3("conv3x3_bx3_fwd", B, H, W, Cin, Cout)) return rc;
+    if (!al16(x) || !al16(wf) || !al16(y) || (bias && !al16(bias))) return fail(T2H_ERR_ARG, "conv3x3_bx3_fwd: pointers must be 16-byte aligned");
+    RowsArgs a{};
+    a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = nullptr; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout;
+    a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
+    return launch_rows(a, as_stream(stream), "conv3x3_bx3_fwd");
+}
+
+T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, const float *mask, int B, int H, int W, int Cin,
+                                  int Cout, int flags, t2h_stream_t stream) {
+    if (!dy || !wf_t || !dx) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad: null pointer");
+    if (int rc = check_bx3("conv3x3_bx3_dgrad", B, H, W, Cin, Cout)) return rc;
+    if (!al16(dy) || !al16(wf_t) || !al16(dx) || (mask && !al16(mask))) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad: pointers must be 16-byte aligned");
+    RowsArgs a{};
+    a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
+    a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin;
+    a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
+    return launch_rows(a, as_stream(stream), "conv3x3_bx3_dgrad");
+}
+
+T2H_API size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_conv3x3_bx3_supported(B, H, W, Cin, Cout)) return 0;
+    WgradPlan p = bx3_wgrad_plan(B, H, W, Cin, Cout);
+    return (size_t)p.splits * ((size_t)Cout * 9 * Cin + Cout) * sizeof(float);
+}
+
+T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
+                                  int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: null pointer");
+    if (int rc = check_bx3("conv3x3_bx3_wgrad", B, H, W, Cin, Cout)) return rc;
+    if (!al16(dy) || !al16(x)) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: pointers must be 16-byte aligned");
+    const size_t need = t2h_conv3x3_bx3_wgrad_workspace_bytes(B, H, W, Cin, Cout);
+    if (!workspace || workspace_bytes < need || !al16(workspace))
+        return fail(T2H_ERR_WORKSPACE, "conv3x3_bx3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    WgradPlan p = bx3_wgrad_plan(B, H, W, Cin, Cout);
+    const int Ncols = 9 * Cin;
+    float *slab = static_cast<float *>(workspace);
+    float *colslab = slab + (size_t)p.splits * Cout * Ncols;
+    WgradArgs a{};
+    a.dy = dy; a.x = x; a.slab = slab; a.colslab = db ? colslab : nullptr;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
+    dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
+    if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
+    if (p.cot == 4) { hipLaunchKernelGGL(bx3_wgrad_kernel<4>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4>"); }
+    else if (p.cot == 2) { hipLaunchKernelGGL(bx3_wgrad_kernel<2>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2>"); }
+    else { hipLaunchKernelGGL(bx3_wgrad_kernel<1>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1>"); }
+    if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
+    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s);
+}

@@ -97,11 +97,75 @@ def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
             and x.dtype == torch.float32 and _pow2(x.shape[2]) and _pow2(x.shape[3]))
 
 
+# ---- the same convolutions on the bf16 matrix cores with an exact 3-way operand split (csrc/conv_bx3.hip) --------------------
+# T2H_CONV_PRECISION=fp32 keeps every 3x3 convolution on conv.hip's fp32 MFMA kernels (A/B; same tolerance either way: the
+# split is exact and the accumulation fp32 -- tests/test_hip_conv.py measures both against float64).  Planes of at least
+# T2H_BX3_MIN_PIXELS pixels (default: 256 x 256, where the kernels were measured 1.4-1.8x faster; profiles/conv_bf16x3_lab.hip).
+CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "bf16x3")
+BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(256 * 256)))
+if CONV_PRECISION not in ("fp32", "bf16x3"):
+    raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected 'fp32' or 'bf16x3'")
+
+
+def bx3_applicable(b: int, h: int, wd: int, cin: int, cout: int) -> bool:
+    return (CONV_PRECISION == "bf16x3" and h * wd >= BX3_MIN_PIXELS
+            and bool(_lib.load().t2h_conv3x3_bx3_supported(b, h, wd, cin, cout)))
+
+
+class SplitWeightCache:
+    """The three bf16 planes of a convolution weight in MFMA operand order (``t2h_conv3x3_bx3_prepare``): a function of the
+    weight alone, so computed when the weight changes (its version counter / storage moves: every optimizer, FlatAdamW included,
+    bumps the counter) instead of per tile.  The buffers are updated IN PLACE, so a captured hipGraph keeps reading current
+    values after ``refresh()`` (called by ``Trainer.optimizer_boundary``; a replayed graph runs no Python per tile)."""
+
+    def __init__(self):
+        self.entries = {}          # (id(weight), transposed) -> [weakref, version, data_ptr, buffer]
+
+    def get(self, w: torch.Tensor, transposed: bool) -> torch.Tensor:
+        import weakref
+        key = (id(w), bool(transposed))
+        e = self.entries.get(key)
+        cout, cin = w.shape[0], w.shape[1]
+        if e is None or e[0]() is not w:
+            nbytes = int(_lib.load().t2h_conv3x3_bx3_weights_bytes(cin, cout))
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf]
+        if e[1] != w._version or e[2] != w.data_ptr():
+            self._prepare(w, transposed, e[3])
+            e[1], e[2] = w._version, w.data_ptr()
+        return e[3]
+
+    @staticmethod
+    def _prepare(w, transposed, buf):
+        cout, cin = w.shape[0], w.shape[1]
+        _lib.call("t2h_conv3x3_bx3_prepare", _lib.ptr(w), cin, cout, 1 if transposed else 0, _lib.ptr(buf), _lib.stream(),
+                  nbytes=10 * w.numel())
+
+    def refresh(self):
+        """Re-split every live weight into its existing buffer."""
+        for (_, transposed), e in list(self.entries.items()):
+            w = e[0]()
+            if w is not None:
+                self._prepare(w, transposed, e[3])
+                e[1], e[2] = w._version, w.data_ptr()
+
+
+split_weights = SplitWeightCache()
+BX3_WGRAD = os.environ.get("T2H_BX3_WGRAD", "1") != "0"        # A/B: 0 = weight gradients stay on conv.hip
+
+
 def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
     """y [B,Cout,H,W] (channels_last) = [y +] act(conv3x3(x, w) + bias); raw kernel call on NHWC-dense tensors."""
     b, cin, h, wd = x.shape
     cout = w.shape[0]
     lib = _lib.load()
+    if bx3_applicable(b, h, wd, cin, cout):
+        flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
+        _lib.call("t2h_conv3x3_bx3_fwd", _lib.ptr(x), _lib.ptr(split_weights.get(w, False)),
+                  _lib.ptr(bias) if bias is not None else None, _lib.ptr(y), b, h, wd, cin, cout, flags, _lib.stream(),
+                  nbytes=4 * (x.numel() + y.numel() + w.numel()), flops=2 * 9 * cin * cout * b * h * wd,
+                  tag=_lib.timing() and f"t2h_conv3x3_fwd[{cin}->{cout},{h}x{wd}]")
+        return y
     nws = _lib.ws_bytes("t2h_conv3x3_fwd_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, x.device)
     flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
@@ -116,6 +180,12 @@ def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
     b, cout, h, wd = gy.shape
     cin = w.shape[1]
     lib = _lib.load()
+    if bx3_applicable(b, h, wd, cin, cout):
+        _lib.call("t2h_conv3x3_bx3_dgrad", _lib.ptr(gy), _lib.ptr(split_weights.get(w, True)), _lib.ptr(dx),
+                  _lib.ptr(mask) if mask is not None else None, b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.stream(),
+                  nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel()),
+                  flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
+        return dx
     nws = _lib.ws_bytes("t2h_conv3x3_dgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(mask) if mask is not None else None,
@@ -129,6 +199,15 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
     b, cout, h, wd = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
+    entry = "t2h_conv3x3_bx3_wgrad" if (BX3_WGRAD and bx3_applicable(b, h, wd, cin, cout)) else "t2h_conv3x3_wgrad"
+    if entry == "t2h_conv3x3_bx3_wgrad":
+        nws = _lib.ws_bytes("t2h_conv3x3_bx3_wgrad_workspace_bytes", b, h, wd, cin, cout)
+        ws = _lib.workspace(nws, gy.device)
+        _lib.call(entry, _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
+                  b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
+                  nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
+                  tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
+        return
     nws = _lib.ws_bytes("t2h_conv3x3_wgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
