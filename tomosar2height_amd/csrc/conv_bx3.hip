@@ -44,7 +44,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int NT = 256;
 constexpr int TW = 32;        // tile width in pixels = rows of one MFMA tile
-constexpr int CC = 32;        // reduction channels per staged chunk
+constexpr int CC = 32;        // reduction channels per staged chunk (wgrad; fwd / dgrad: template parameter CCH)
 
 // ---- the split -----------------------------------------------------------------------------------------------------------
 __device__ inline unsigned pack_bf16x2(float a, float b) {             // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -64,7 +64,7 @@ __device__ inline void split3(float a, float b, unsigned &p1, unsigned &p2, unsi
 }
 
 // ---- weight preparation: [Cout][9][Cin] fp32 -> MFMA B-fragment order, three bf16 planes --------------------------------------
-// slab (chunk c of 32 reduction channels, tap t, half q) x [tile of 32 output channels][plane][lane][8 bf16]; lane (r = l & 31,
+// slab (16-channel step c16 of the reduction, tap t) x [tile of 32 output channels][plane][lane][8 bf16]; lane (r = l & 31,
 // h = l >> 5) holds B[k = 8 h + j][col r].  Forward: k = input channel, col = output channel, W[col][tap][k].  Transposed (data
 // gradient): k = output channel, col = input channel, tap flipped: W[k][8 - tap][col].
 template <bool TRANSPOSED>
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
     if (t >= total) return;
     const int lane = (int)(t & 63);
     const int tile = (int)((t >> 6) % ntile);
-    const long long slab = (t >> 6) / ntile;                              // (c * 9 + tap) * 2 + q
-    const int q = (int)(slab & 1), tap = (int)((slab >> 1) % 9), c = (int)((slab >> 1) / 9);
+    const long long slab = (t >> 6) / ntile;                              // c16 * 9 + tap
+    const int tap = (int)(slab % 9), c16 = (int)(slab / 9);
     const int r = lane & 31, h = lane >> 5;
-    const int n = tile * 32 + r, k0 = c * 32 + q * 16 + 8 * h;
+    const int n = tile * 32 + r, k0 = c16 * 16 + 8 * h;
     unsigned p1[4], p2[4], p3[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -110,10 +110,14 @@ struct RowsArgs {
     int B, H, W, Kc, Nc, flags;
 };
 
-constexpr int PXB = 80;      // bytes per pixel and plane of the halo image: 32 bf16 + 16 B of padding
-
-template <int TH, int BN, int WAVES_M, int WAVES_N>
+// TH image rows x 32 columns x BN output channels per workgroup, CCH reduction channels per staged halo chunk.  Two shapes are
+// used: 4 rows / 32 channels (80-byte pixel stride) and -- for planes with enough tiles to fill the chip -- 8 rows / 16
+// channels (48-byte stride; half the barriers, LDS fragment bytes and weight-slab traffic per MFMA).  Both keep the halo
+// images + two weight slabs under 80 KB: two workgroups per CU, one staging while the other computes.
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH>
 __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
+    constexpr int PXB = CCH * 2 + 16;     // bytes per pixel and plane of the halo image: CCH bf16 + 16 B (an odd multiple of 16 B)
+    constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = 9 * NQ;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
     constexpr int HP = (TH + 2) * (TW + 2);                              // halo pixels
     constexpr int PLANE = HP * PXB;                                      // bytes per bf16 plane
@@ -138,21 +142,21 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     const int tiles_y = p.H / TH;
     const int ty = t % tiles_y, b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH, n0 = tn * BN;
-    const int nchunk = p.Kc / CC;
+    const int nchunk = p.Kc / CCH;
 
-    // halo staging: 8 float4 per pixel and chunk
-    constexpr int NF4 = HP * 8, PER = (NF4 + NT - 1) / NT;
+    // halo staging: F4 float4 per pixel and chunk
+    constexpr int NF4 = HP * F4, PER = (NF4 + NT - 1) / NT;
     float4 hreg[PER];
     auto halo_load = [&](int c) {
 #pragma unroll
         for (int f = 0; f < PER; ++f) {
             const int idx = tid + f * NT;
-            const int px = idx >> 3, c4 = idx & 7;
+            const int px = idx / F4, c4 = idx % F4;
             const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.Kc + c * CC + c4 * 4);
+                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.Kc + c * CCH + c4 * 4);
             hreg[f] = v;
         }
     };
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         for (int f = 0; f < PER; ++f) {
             const int idx = tid + f * NT;
             if (idx < NF4) {
-                const int px = idx >> 3, c4 = idx & 7;
+                const int px = idx / F4, c4 = idx % F4;
                 unsigned a1, a2, a3, b1, b2, b3;
                 split3(hreg[f].x, hreg[f].y, a1, a2, a3);
                 split3(hreg[f].z, hreg[f].w, b1, b2, b3);
@@ -172,10 +176,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             }
         }
     };
-    // weight slab s = (chunk * 9 + tap) * 2 + q: (Nc / 32) x 3 KB; this workgroup's BN / 32 tiles of it are one linear run
+    // weight slab (16-channel step c16, tap) = c16 * 9 + tap: (Nc / 32) x 3 KB; this workgroup's BN / 32 tiles are one linear run.
+    // Step st of chunk c: tap = st / NQ, q = st % NQ, c16 = c * NQ + q
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * 3 * 1024;
     const size_t slab_stride = (size_t)(p.Nc / 32) * 3 * 1024;
-    auto issue_b = [&](int s, unsigned char *dst) {
+    auto issue_b = [&](int c, int st, unsigned char *dst) {
+        const int s = (c * NQ + st % NQ) * 9 + st / NQ;
         const unsigned char *src = wbase + (size_t)s * slab_stride;
         constexpr int PIECES = BSLAB / 1024;                             // 1 KB per wave instruction, dealt round-robin to the waves
 #pragma unroll
@@ -194,20 +200,21 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 
     const int r = lane & 31, h = lane >> 5;
     halo_load(0);
-    int s = 0;                                                           // running slab index
-    const int last = nchunk * 18 - 1;
+    int s = 0;                                                           // running step count (selects the weight buffer)
     for (int c = 0; c < nchunk; ++c) {
         halo_store();                                                    // (the previous chunk's last barrier has passed)
-        if (c == 0) issue_b(0, bbuf);                                    // (later chunks: issued by the previous chunk's last step)
+        if (c == 0) issue_b(0, 0, bbuf);                                 // (later chunks: issued by the previous chunk's last step)
         if (c + 1 < nchunk) halo_load(c + 1);                            // in flight under this chunk's MFMAs
         __syncthreads();
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int q = 0; q < 2; ++q, ++s) {
+            for (int q = 0; q < NQ; ++q, ++s) {
                 const unsigned char *cur = bbuf + (s & 1) * BSLAB;
-                if (s < last) issue_b(s + 1, bbuf + ((s + 1) & 1) * BSLAB);
+                const int st = tap * NQ + q;
+                if (st + 1 < NSTEP) issue_b(c, st + 1, bbuf + ((s + 1) & 1) * BSLAB);
+                else if (c + 1 < nchunk) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
                 uint4 af[TM][3], bfr[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -453,13 +460,30 @@ int check_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
     return T2H_OK;
 }
 
+#define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_)                                                                                  \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_>), dim3((unsigned)tiles), dim3(NT), 0, s, a);           \
+        note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                       \
+    } while (0)
+
 int launch_rows(const RowsArgs &a, hipStream_t s, const char *what) {
     const int bn = a.Nc % 128 == 0 ? 128 : (a.Nc % 64 == 0 ? 64 : 32);
-    const long long tiles = (long long)a.B * (a.H / 4) * (a.W / TW) * (a.Nc / bn);
+    // 8-row tiles where they still give every CU its two workgroups twice over (512 x 512 planes: 1024 tiles); measured on
+    // 64->128 / 128->64 / 64->32 at 512^2: 203 -> 185, 239 -> 194, 76 -> 72 us, and slower at 256^2 (256 tiles: one per CU)
+    static const long long min_tiles8 = getenv("T2H_BX3_TILES8") ? atoll(getenv("T2H_BX3_TILES8")) : 1024;
+    const long long tiles8 = a.H % 8 == 0 ? (long long)a.B * (a.H / 8) * (a.W / TW) * (a.Nc / bn) : 0;
+    const bool tall = tiles8 >= min_tiles8 && a.Kc % 16 == 0;
+    const long long tiles = tall ? tiles8 : (long long)a.B * (a.H / 4) * (a.W / TW) * (a.Nc / bn);
     if (tiles > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
-    if (bn == 128) { hipLaunchKernelGGL((bx3_rows_kernel<4, 128, 2, 2>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,128,2,2>"); }
-    else if (bn == 64) { hipLaunchKernelGGL((bx3_rows_kernel<4, 64, 2, 2>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,64,2,2>"); }
-    else { hipLaunchKernelGGL((bx3_rows_kernel<4, 32, 4, 1>), dim3((unsigned)tiles), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,32,4,1>"); }
+    if (tall) {
+        if (bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16);
+        else if (bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16);
+        else BX3_LAUNCH(8, 32, 4, 1, 16);
+    } else {
+        if (bn == 128) BX3_LAUNCH(4, 128, 2, 2, 32);
+        else if (bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32);
+        else BX3_LAUNCH(4, 32, 4, 1, 32);
+    }
     return check_launch(what);
 }
 
