@@ -343,7 +343,8 @@ int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int
 /* The same three convolutions on the bf16 matrix cores with an EXACT 3-way bf16 split of both operands (six bf16 MFMAs per
  * product, fp32 accumulate: fp32-grade results, same tolerance as the kernels above; csrc/conv_bx3.hip), for planes with
  * W >= 32, H >= 4 and Cin, Cout multiples of 32 (t2h_conv3x3_bx3_supported).  Same reference calls (alto.py:59-61,98-99,
- * 157-182,226-227; pixel.py:20-32), same layouts.  The weights are split once per optimizer step into the byte order of the
+ * 157-182,226-227; pixel.py:20-32), same layouts; planes with fewer tiles than the chip has workgroups split the reduction into
+ * slabs in the caller's workspace, summed in a fixed order (deterministic).  The weights are split once per optimizer step into the byte order of the
  * MFMA operand: t2h_conv3x3_bx3_prepare(w [Cout][3][3][Cin], transposed = 0 for fwd / 1 for dgrad) -> wf of
  * t2h_conv3x3_bx3_weights_bytes; activations are split inside the kernels, once per staged element.
  *   fwd    y  = [y +] act(conv(x, w) + bias)          flags: T2H_RELU_OUT, T2H_ACCUM
@@ -352,10 +353,12 @@ int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int
 int t2h_conv3x3_bx3_supported(int B, int H, int W, int Cin, int Cout);
 size_t t2h_conv3x3_bx3_weights_bytes(int Cin, int Cout);
 int t2h_conv3x3_bx3_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream);
+size_t t2h_conv3x3_bx3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout);     /* 0 unless the reduction is split */
 int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
-                        int flags, t2h_stream_t stream);
+                        int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+size_t t2h_conv3x3_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_transposed, float *dx, const float *mask, int B, int H, int W, int Cin,
-                          int Cout, int flags, t2h_stream_t stream);
+                          int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
                           int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);

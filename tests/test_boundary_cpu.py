@@ -144,8 +144,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_conv3x3_dgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_conv3x3_wgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_conv3x3_bx3_prepare": (n, 32, 32, 0, n, n),
-        "t2h_conv3x3_bx3_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
-        "t2h_conv3x3_bx3_dgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
+        "t2h_conv3x3_bx3_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
+        "t2h_conv3x3_bx3_dgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_conv3x3_bx3_wgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_upconv2x2_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
         "t2h_upconv2x2_fwd_add": (n, n, n, n, n, 1, 32, 32, 32, 32, 0, n),

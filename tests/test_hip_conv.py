@@ -87,9 +87,10 @@ def test_conv3x3_data_and_weight_gradient(shape):
 
 # ---- the bf16 matrix-core path with the exact 3-way operand split (csrc/conv_bx3.hip) ------------------------------------------
 # (B, H, W, Cin, Cout): one tile, several chunks, batch > 1, non-square, every BN (32 / 64 / 128 / 2 x 128) and every wgrad
-# grouping (Cout = 32, 64, 96, 128, 256), H = 4 (tile = plane height)
+# grouping (Cout = 32, 64, 96, 128, 256), H = 4 (tile = plane height), and the ALTO bottom levels, whose reduction is split into
+# slabs (512 channels at 32 x 32: 16 splits; 256 -> 512; 512 -> 256 at 64 x 64)
 BX3_SHAPES = [(1, 32, 32, 32, 32), (1, 64, 64, 64, 128), (2, 16, 32, 32, 64), (1, 4, 64, 128, 32), (1, 32, 128, 96, 96),
-              (3, 8, 32, 64, 256), (1, 128, 128, 32, 64)]
+              (3, 8, 32, 64, 256), (1, 128, 128, 32, 64), (1, 32, 32, 512, 512), (1, 32, 32, 256, 512), (1, 64, 64, 512, 256)]
 
 
 @pytest.fixture

@@ -82,8 +82,10 @@ SIGNATURES = {
     "t2h_conv3x3_bx3_supported": (_i, [_i] * 5),
     "t2h_conv3x3_bx3_weights_bytes": (_sz, [_i, _i]),
     "t2h_conv3x3_bx3_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "t2h_conv3x3_bx3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "t2h_conv3x3_bx3_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2h_conv3x3_bx3_fwd_workspace_bytes": (_sz, [_i] * 5),
+    "t2h_conv3x3_bx3_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_conv3x3_bx3_dgrad_workspace_bytes": (_sz, [_i] * 5),
+    "t2h_conv3x3_bx3_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_conv3x3_bx3_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "t2h_conv3x3_bx3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

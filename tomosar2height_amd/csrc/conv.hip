@@ -531,6 +531,15 @@ WgradPlan conv_wgrad_plan(long long P, int Cin, int Cout) { return wgrad_plan_fo
 bool al16(const void *q) { return (uintptr_t)q % 16 == 0; }
 
 }  // namespace
+
+int launch_reduce_rows_epilogue(const float *slabs, int splits, long long stride, long long M, int N, const EpilogueArgs &e,
+                                hipStream_t s) {
+    const long long total = M * (N / 4);
+    hipLaunchKernelGGL(reduce_rows_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, splits, stride,
+                       (int)M, N, e);
+    return check_launch("reduce_rows_epilogue");
+}
+
 }  // namespace t2h
 
 using namespace t2h;

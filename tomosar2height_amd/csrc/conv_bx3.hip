@@ -106,8 +106,9 @@ struct RowsArgs {
     const unsigned *wf;      // prepared weights
     const float *bias;       // [Nc] or null
     const float *mask;       // [B,H,W,Nc] or null: result *= (mask > 0)
-    float *y;                // [B,H,W,Nc]
+    float *y;                // [B,H,W,Nc], or the slab base when the reduction is split
     int B, H, W, Kc, Nc, flags;
+    int splits, chunks_per_split;   // splits > 1: grid = tiles x splits, partial sums to y + split * B H W Nc (no epilogue)
 };
 
 // TH image rows x 32 columns x BN output channels per workgroup, CCH reduction channels per staged halo chunk.  Two shapes are
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     const unsigned nb = gridDim.x, bid = blockIdx.x;
     const unsigned qq = nb / 8, rr = nb % 8, xx = bid % 8, i8 = bid / 8;
     unsigned t = (xx < rr ? xx * (qq + 1) : rr * (qq + 1) + (xx - rr) * qq) + i8;
+    const int split = t % p.splits; t /= p.splits;                      // (the splits of a tile side by side: same halo pixels)
     const int ntn = p.Nc / BN;
     const int tn = t % ntn; t /= ntn;
     const int tiles_x = p.W / TW;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     const int tiles_y = p.H / TH;
     const int ty = t % tiles_y, b = t / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH, n0 = tn * BN;
-    const int nchunk = p.Kc / CCH;
+    const int c_beg = split * p.chunks_per_split, c_end = min(p.Kc / CCH, c_beg + p.chunks_per_split);
 
     // halo staging: F4 float4 per pixel and chunk
     constexpr int NF4 = HP * F4, PER = (NF4 + NT - 1) / NT;
@@ -199,12 +201,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
 
     const int r = lane & 31, h = lane >> 5;
-    halo_load(0);
+    halo_load(c_beg);
     int s = 0;                                                           // running step count (selects the weight buffer)
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_beg; c < c_end; ++c) {
         halo_store();                                                    // (the previous chunk's last barrier has passed)
-        if (c == 0) issue_b(0, 0, bbuf);                                 // (later chunks: issued by the previous chunk's last step)
-        if (c + 1 < nchunk) halo_load(c + 1);                            // in flight under this chunk's MFMAs
+        if (c == c_beg) issue_b(c, 0, bbuf);                             // (later chunks: issued by the previous chunk's last step)
+        if (c + 1 < c_end) halo_load(c + 1);                             // in flight under this chunk's MFMAs
         __syncthreads();
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 const unsigned char *cur = bbuf + (s & 1) * BSLAB;
                 const int st = tap * NQ + q;
                 if (st + 1 < NSTEP) issue_b(c, st + 1, bbuf + ((s + 1) & 1) * BSLAB);
-                else if (c + 1 < nchunk) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
+                else if (c + 1 < c_end) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
                 uint4 af[TM][3], bfr[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
+    float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.Nc);      // (split == 0 unless the reduction is split)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                     v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                 }
                 if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                float4 *dst = reinterpret_cast<float4 *>(p.y + o);
+                float4 *dst = reinterpret_cast<float4 *>(ybase + o);
                 if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
                 *dst = v;
             }
@@ -460,31 +463,65 @@ int check_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
     return T2H_OK;
 }
 
-#define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_)                                                                                  \
-    do {                                                                                                                    \
-        hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_>), dim3((unsigned)tiles), dim3(NT), 0, s, a);           \
-        note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                       \
-    } while (0)
-
-int launch_rows(const RowsArgs &a, hipStream_t s, const char *what) {
-    const int bn = a.Nc % 128 == 0 ? 128 : (a.Nc % 64 == 0 ? 64 : 32);
+struct RowsPlan { bool tall; int bn, splits, chunks_per_split; long long tiles; };
+RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc) {
+    RowsPlan r{};
+    r.bn = Nc % 128 == 0 ? 128 : (Nc % 64 == 0 ? 64 : 32);
     // 8-row tiles where they still give every CU its two workgroups twice over (512 x 512 planes: 1024 tiles); measured on
     // 64->128 / 128->64 / 64->32 at 512^2: 203 -> 185, 239 -> 194, 76 -> 72 us, and slower at 256^2 (256 tiles: one per CU)
     static const long long min_tiles8 = getenv("T2H_BX3_TILES8") ? atoll(getenv("T2H_BX3_TILES8")) : 1024;
-    const long long tiles8 = a.H % 8 == 0 ? (long long)a.B * (a.H / 8) * (a.W / TW) * (a.Nc / bn) : 0;
-    const bool tall = tiles8 >= min_tiles8 && a.Kc % 16 == 0;
-    const long long tiles = tall ? tiles8 : (long long)a.B * (a.H / 4) * (a.W / TW) * (a.Nc / bn);
-    if (tiles > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
-    if (tall) {
-        if (bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16);
-        else if (bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16);
+    const long long tiles8 = H % 8 == 0 ? (long long)B * (H / 8) * (W / TW) * (Nc / r.bn) : 0;
+    r.tall = tiles8 >= min_tiles8;
+    r.tiles = r.tall ? tiles8 : (long long)B * (H / 4) * (W / TW) * (Nc / r.bn);
+    // small planes with many channels: fewer tiles than the chip holds workgroups -> split the reduction over whole 32-channel
+    // chunks into slabs (summed in a fixed order by reduce_rows_epilogue, which also applies the epilogue): deterministic
+    r.splits = 1;
+    const int nchunk = Kc / (r.tall ? 16 : 32);
+    static const long long target = getenv("T2H_BX3_ROWS_WGS") ? atoll(getenv("T2H_BX3_ROWS_WGS")) : 512;
+    if (!r.tall && r.tiles < target / 2) {
+        long long want = (target + r.tiles - 1) / r.tiles;
+        if (want > nchunk) want = nchunk;
+        if (want > 32) want = 32;
+        r.splits = (int)(want < 1 ? 1 : want);
+    }
+    r.chunks_per_split = (nchunk + r.splits - 1) / r.splits;
+    r.splits = (nchunk + r.chunks_per_split - 1) / r.chunks_per_split;
+    return r;
+}
+
+#define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_)                                                                                  \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_>), dim3((unsigned)grid), dim3(NT), 0, s, a);            \
+        note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                       \
+    } while (0)
+
+// `a`: x, wf, bias, mask, y, geometry and epilogue flags; splits the reduction into `ws` when the plan says so
+int launch_rows(RowsArgs a, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
+    const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc);
+    const long long grid = r.tiles * r.splits;
+    if (grid > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
+    const long long M = (long long)a.B * a.H * a.W;
+    EpilogueArgs e{};
+    if (r.splits > 1) {
+        const size_t need = (size_t)r.splits * M * a.Nc * sizeof(float);
+        if (!ws || ws_bytes < need || !al16(ws)) return fail(T2H_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
+        e.C = a.y; e.bias = a.bias; e.mask = a.mask; e.M = (int)M; e.N = a.Nc; e.ldc = a.Nc; e.ldm = a.Nc;
+        e.accum = a.flags & F_ACCUM; e.relu_out = a.flags & F_RELU_OUT;
+        a.y = static_cast<float *>(ws); a.bias = nullptr; a.mask = nullptr; a.flags = 0;
+    }
+    a.splits = r.splits; a.chunks_per_split = r.chunks_per_split;
+    if (r.tall) {
+        if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16);
+        else if (r.bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16);
         else BX3_LAUNCH(8, 32, 4, 1, 16);
     } else {
-        if (bn == 128) BX3_LAUNCH(4, 128, 2, 2, 32);
-        else if (bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32);
+        if (r.bn == 128) BX3_LAUNCH(4, 128, 2, 2, 32);
+        else if (r.bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32);
         else BX3_LAUNCH(4, 32, 4, 1, 32);
     }
-    return check_launch(what);
+    if (int rc = check_launch(what)) return rc;
+    if (r.splits > 1) return launch_reduce_rows_epilogue(static_cast<const float *>(ws), r.splits, M * a.Nc, M, a.Nc, e, s);
+    return T2H_OK;
 }
 
 struct WgradPlan { int cot, splits, units_per_split, n_units; };
@@ -493,7 +530,9 @@ WgradPlan bx3_wgrad_plan(int B, int H, int W, int Cin, int Cout) {
     p.cot = Cout % 128 == 0 ? 4 : (Cout % 64 == 0 ? 2 : 1);
     p.n_units = B * H * (W / TW);
     const long long groups = (long long)(Cin / CC) * (Cout / (32 * p.cot));
-    static const long long target = getenv("T2H_BX3_WGRAD_WGS") ? atoll(getenv("T2H_BX3_WGRAD_WGS")) : 512;
+    // ~512 workgroups; planes up to 128 x 128 (few units per workgroup either way): 256 -- half the slabs to write and reduce
+    static const long long forced = getenv("T2H_BX3_WGRAD_WGS") ? atoll(getenv("T2H_BX3_WGRAD_WGS")) : 0;
+    const long long target = forced > 0 ? forced : ((long long)H * W <= 128 * 128 ? 256 : 512);
     long long splits = target / groups;
     if (splits < 1) splits = 1;
     if (splits > p.n_units) splits = p.n_units;
@@ -529,8 +568,20 @@ T2H_API int t2h_conv3x3_bx3_prepare(const float *w, int Cin, int Cout, int trans
     return check_launch("conv3x3_bx3_prepare");
 }
 
+T2H_API size_t t2h_conv3x3_bx3_fwd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_conv3x3_bx3_supported(B, H, W, Cin, Cout)) return 0;
+    const RowsPlan r = bx3_rows_plan(B, H, W, Cin, Cout);
+    return r.splits > 1 ? (size_t)r.splits * B * H * W * Cout * sizeof(float) : 0;
+}
+
+T2H_API size_t t2h_conv3x3_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_conv3x3_bx3_supported(B, H, W, Cin, Cout)) return 0;
+    const RowsPlan r = bx3_rows_plan(B, H, W, Cout, Cin);
+    return r.splits > 1 ? (size_t)r.splits * B * H * W * Cin * sizeof(float) : 0;
+}
+
 T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bias, float *y, int B, int H, int W, int Cin, int Cout,
-                                int flags, t2h_stream_t stream) {
+                                int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!x || !wf || !y) return fail(T2H_ERR_ARG, "conv3x3_bx3_fwd: null pointer");
     if (int rc = check_bx3("conv3x3_bx3_fwd", B, H, W, Cin, Cout)) return rc;
     if (!al16(x) || !al16(wf) || !al16(y) || (bias && !al16(bias))) return fail(T2H_ERR_ARG, "conv3x3_bx3_fwd: pointers must be 16-byte aligned");
@@ -538,11 +589,11 @@ T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bia
     a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
-    return launch_rows(a, as_stream(stream), "conv3x3_bx3_fwd");
+    return launch_rows(a, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
 }
 
 T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, const float *mask, int B, int H, int W, int Cin,
-                                  int Cout, int flags, t2h_stream_t stream) {
+                                  int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!dy || !wf_t || !dx) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad: null pointer");
     if (int rc = check_bx3("conv3x3_bx3_dgrad", B, H, W, Cin, Cout)) return rc;
     if (!al16(dy) || !al16(wf_t) || !al16(dx) || (mask && !al16(mask))) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad: pointers must be 16-byte aligned");
@@ -550,7 +601,7 @@ T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, 
     a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
     a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
-    return launch_rows(a, as_stream(stream), "conv3x3_bx3_dgrad");
+    return launch_rows(a, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
 }
 
 T2H_API size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

@@ -216,4 +216,8 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
                         float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0);
 
+// reduce_rows_epilogue_kernel of conv.hip: out[r, c] = [out +] act( sum_z slabs[z][r, c] + bias[c] ) * (mask > 0), splits in order
+int launch_reduce_rows_epilogue(const float *slabs, int splits, long long stride, long long M, int N, const EpilogueArgs &e,
+                                hipStream_t s);
+
 }  // namespace t2h

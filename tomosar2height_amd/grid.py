@@ -102,7 +102,7 @@ def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
 # split is exact and the accumulation fp32 -- tests/test_hip_conv.py measures both against float64).  Planes of at least
 # T2H_BX3_MIN_PIXELS pixels (default: 256 x 256, where the kernels were measured 1.4-1.8x faster; profiles/conv_bf16x3_lab.hip).
 CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "bf16x3")
-BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(256 * 256)))
+BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(32 * 32)))
 if CONV_PRECISION not in ("fp32", "bf16x3"):
     raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected 'fp32' or 'bf16x3'")
 
@@ -161,8 +161,10 @@ def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
     lib = _lib.load()
     if bx3_applicable(b, h, wd, cin, cout):
         flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
+        nws = _lib.ws_bytes("t2h_conv3x3_bx3_fwd_workspace_bytes", b, h, wd, cin, cout)
+        ws = _lib.workspace(nws, x.device)
         _lib.call("t2h_conv3x3_bx3_fwd", _lib.ptr(x), _lib.ptr(split_weights.get(w, False)),
-                  _lib.ptr(bias) if bias is not None else None, _lib.ptr(y), b, h, wd, cin, cout, flags, _lib.stream(),
+                  _lib.ptr(bias) if bias is not None else None, _lib.ptr(y), b, h, wd, cin, cout, flags, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (x.numel() + y.numel() + w.numel()), flops=2 * 9 * cin * cout * b * h * wd,
                   tag=_lib.timing() and f"t2h_conv3x3_fwd[{cin}->{cout},{h}x{wd}]")
         return y
@@ -181,8 +183,11 @@ def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
     cin = w.shape[1]
     lib = _lib.load()
     if bx3_applicable(b, h, wd, cin, cout):
+        nws = _lib.ws_bytes("t2h_conv3x3_bx3_dgrad_workspace_bytes", b, h, wd, cin, cout)
+        ws = _lib.workspace(nws, gy.device)
         _lib.call("t2h_conv3x3_bx3_dgrad", _lib.ptr(gy), _lib.ptr(split_weights.get(w, True)), _lib.ptr(dx),
-                  _lib.ptr(mask) if mask is not None else None, b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.stream(),
+                  _lib.ptr(mask) if mask is not None else None, b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0,
+                  _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel()),
                   flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
         return dx
