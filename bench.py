@@ -89,6 +89,10 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the headline (configs[1]); infer = configs[4]: Munich cloud+image forward only")
     ap.add_argument("--batch", type=int, default=1, help="tiles per forward in --mode infer")
+    ap.add_argument("--train-batch", type=int, default=1,
+                    help="tiles of the accumulation window per forward / backward (micro-batch; a SECOND line beside the B = 1 "
+                         "headline: the reference feeds tiles one at a time only because N varies, tomosar2height.yaml:40).  With "
+                         "> 1 the resident tiles get DIFFERENT point counts (mean = --points) and run as ragged batches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
@@ -451,8 +455,10 @@ def main():
         span = 512.0 * (args.chunk_tiles - 1)
         anchors = np.floor(np.random.RandomState(11 + rank).uniform(0, span, (4096, 2))) + np.array([ch["left"], ch["bottom"]])
     else:
-        for i in range(args.tile_pool):
-            t = berlin_tile(seed=1000 * rank + i, n_points=args.points, clustered=not args.uniform_xy, with_image=args.use_image)
+        ragged = (-0.10, 0.06, -0.04, 0.08)               # --train-batch > 1: point counts around --points, mean = --points
+        for i in range(args.tile_pool if args.train_batch == 1 else max(args.tile_pool, 2 * args.train_batch) // 4 * 4):
+            n_i = args.points if args.train_batch == 1 else int(round(args.points * (1.0 + ragged[i % 4])))
+            t = berlin_tile(seed=1000 * rank + i, n_points=n_i, clustered=not args.uniform_xy, with_image=args.use_image)
             tiles.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
 
     state = {"i": 0, "optimizer_steps": 0, "points": 0}
@@ -496,14 +502,20 @@ def main():
         return t
 
     def run(n_steps, events=None):
-        for _ in range(n_steps):
-            if trainer.train_step(next_tile()):
+        """``n_steps`` TILE-steps; with --train-batch B they are issued B at a time (never across an optimizer boundary)."""
+        done = 0
+        while done < n_steps:
+            k = min(args.train_batch, n_steps - done, trainer.local_every - trainer.accumulated_steps)
+            batch = [next_tile() for _ in range(k)]
+            if trainer.train_step(batch if k > 1 else batch[0]):
                 state["optimizer_steps"] += 1
-            state["i"] += 1
+            state["i"] += k
+            done += k
             if events is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 events.append(ev)
+                state.setdefault("event_tiles", []).append(k)
 
     def fence():
         torch.cuda.synchronize()
@@ -541,6 +553,7 @@ def main():
     if args.sustain_s > 0 and not args.hip_graph:
         n_sus = max(8, int(round(args.sustain_s / (elapsed / args.steps))))       # same count on every rank (elapsed is the max)
         evs = [torch.cuda.Event(enable_timing=True)]
+        state["event_tiles"] = []
         fence()
         evs[0].record()
         ts0 = time.perf_counter()
@@ -553,8 +566,10 @@ def main():
             tmax = torch.tensor([sus_elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sus_elapsed = float(tmax.item())
-        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n_sus)]           # GPU time between consecutive step ends
-        q = max(1, n_sus // 4)
+        calls = state.pop("event_tiles")
+        per = [evs[i].elapsed_time(evs[i + 1]) / calls[i] for i in range(len(calls))]      # GPU time per tile between call ends
+        q = max(1, len(per) // 4)
+        state.pop("event_tiles", None)
         sustained = {"steps": n_sus, "seconds": round(sus_elapsed, 2), "ms_per_step": round(1e3 * sus_elapsed / n_sus, 3),
                      "tiles_per_s": round(world * n_sus / sus_elapsed, 3),
                      "first_quartile_ms": round(sum(per[:q]) / q, 3), "last_quartile_ms": round(sum(per[-q:]) / q, 3),
@@ -611,10 +626,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: Berlin cloud+image" if args.use_image
                                     else "BASELINE.json configs[1]: Berlin cloud-only")
-                                   + f", {args.mlp_precision} per-point GEMMs, B=1 tile, "
-                                   f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
+                                   + f", {args.mlp_precision} per-point GEMMs, "
+                                   + ("B=1 tile, " if args.train_batch == 1 else
+                                      f"micro-batches of {args.train_batch} tiles with different point counts (ragged; SECOND line, not the "
+                                      "B=1 headline), mean ")
+                                   + f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
                                    f"optimize_every={args.optimize_every}",
-                       "points_per_tile": args.points, "optimize_every": args.optimize_every,
+                       "points_per_tile": args.points, "optimize_every": args.optimize_every, "train_batch": args.train_batch,
                        "optimizer_steps_in_timed_region": timed_optimizer_steps, "optimizer": opt_name,
                        "optimizer_boundary_ms": round(boundary_ms, 3),
                        "parallelism": f"dp{world}", "collective": (dist.get_backend(group) if world > 1 else None),

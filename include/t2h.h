@@ -42,6 +42,7 @@ extern "C" {
 
 #define T2H_ABI_VERSION 9
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
+#define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
 typedef void *t2h_stream_t;
 
@@ -80,6 +81,18 @@ size_t t2h_tile_workspace_bytes(int B, int N, int nbits);
 int t2h_tile_build(const float *cloud, int dim, int B, int N, int nbits, float *pts_sorted, int32_t *perm,
                    int32_t *cell, int32_t *off0, int32_t *status, void *workspace, size_t workspace_bytes,
                    t2h_stream_t stream);
+/* RAGGED batches: B tiles with different point counts in one index -- the tiles of the reference's 64-tile accumulation
+ * window (trainer.py:72-89), which it runs one at a time only because N varies per tile (tomosar2height.yaml:40,
+ * generator.py:44).  `cloud` [total, dim] holds the tiles back to back; tile b = rows [starts[b], starts[b+1]) (`starts`: HOST
+ * array of B + 1 ints, starts[0] = 0, every tile non-empty, B <= T2H_MAX_RAGGED_TILES).  Per tile the same stable sort and
+ * the same outputs as t2h_tile_build (rows of tile b stay in its row range; cell = b 4^nbits + Morton code; perm = index
+ * inside the tile), and pts_sorted rows have out_dim = dim + 1 floats: the last one holds the tile index as int bits.
+ * EVERY point-side entry point below takes such a batch as (B, N = -total): N < 0 means "-N rows in all, tile boundaries
+ * from off0 / cell / the pts rows" (sums inside a tile are those of the single-tile call: bit-identical results per tile). */
+size_t t2h_tile_ragged_workspace_bytes(int B, int64_t total_rows, int max_rows, int nbits);
+int t2h_tile_build_ragged(const float *cloud, int dim, int B, const int32_t *starts, int nbits, float *pts_sorted, int out_dim,
+                          int32_t *perm, int32_t *cell, int32_t *off0, int32_t *status, void *workspace,
+                          size_t workspace_bytes, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pool_local (scatter_max + gather)                              pointnet.py:92-99

@@ -101,6 +101,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
     cases = {
         "t2h_coordinate2index": (n, 3, 10, 16, n, n),
         "t2h_tile_build": (n, 3, 1, 10, 8, n, n, n, n, n, n, 0, n),
+        "t2h_tile_build_ragged": (n, 3, 2, n, 8, n, 4, n, n, n, n, n, 0, n),
         "t2h_pool_max_fwd": (n, 32, n, 1, 8, 32, n, 32, n, n),
         "t2h_pool_max_bwd": (n, 32, n, n, 1, 8, 32, 0, n, 32, n),
         "t2h_pool_mean": (n, 32, n, 1, 8, 32, 0, n, 32, n),

@@ -26,6 +26,8 @@ SIGNATURES = {
     "t2h_coordinate2index": (_i, [_vp, _i, _i64, _i, _vp, _vp]),
     "t2h_tile_workspace_bytes": (_sz, [_i, _i, _i]),
     "t2h_tile_build": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "t2h_tile_ragged_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "t2h_tile_build_ragged": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "t2h_pool_winner_stride": (_i, [_i]),
     "t2h_pool_max_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "t2h_pool_max_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void sample_fwd_kernel(const float *__res
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t n = t >> lg;
     if (n >= npts) return;
-    int b = (int)(n / N);
+    int b = N > 0 ? (int)(n / N) : __float_as_int(pts[n * dim + dim - 1]);    // ragged batch: tile id in the row's last float
     Taps tp = make_taps(pts[n * dim + 0], pts[n * dim + 1], r);
     // ATen: nw = (x1-ix)*(y1-iy), ne = (ix-x0)*(y1-iy), sw = (x1-ix)*(iy-y0), se = (ix-x0)*(iy-y0)
     float nw = __fmul_rn(tp.wx0, tp.wy0), ne = __fmul_rn(tp.wx1, tp.wy0);
@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__(kThreads) void sample_bwd_atomic_kernel(const float
     int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     int64_t n = t >> lg;
     if (n >= npts) return;
-    int b = (int)(n / N);
+    int b = N > 0 ? (int)(n / N) : __float_as_int(pts[n * dim + dim - 1]);    // ragged batch: tile id in the row's last float
     Taps tp = make_taps(pts[n * dim + 0], pts[n * dim + 1], r);
     float nw = tp.wx0 * tp.wy0, ne = tp.wx1 * tp.wy0, sw = tp.wx0 * tp.wy1, se = tp.wx1 * tp.wy1;
     bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
@@ -1618,9 +1618,9 @@ static bool cells_mfma(int C) {
 struct CoarsePlan { bool use; int S; int lgG; int chunks; };
 static CoarsePlan coarse_plan(int B, int N, int nbits, int level, int C, int min_pts_per_cell = 16) {
     CoarsePlan p{false, 1, 0, 1};
-    if (C % 4 != 0 || N <= 0) return p;
+    if (C % 4 != 0 || N == 0) return p;
     int64_t cells = (int64_t)1 << (2 * (nbits - level));
-    if ((int64_t)N < (int64_t)min_pts_per_cell * cells) return p;
+    if ((int64_t)rows_per_tile(B, N) < (int64_t)min_pts_per_cell * cells) return p;      // (ragged batches: the average tile)
     p.use = true;
     int cc = cell_chunk_channels(C);
     p.chunks = (C + cc - 1) / cc;
@@ -1827,7 +1827,7 @@ T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *le
     if (!gplanes_nhwc || !levels || !lds || !cell || !gfeat) return fail(T2H_ERR_ARG, "segsum_bwd_multi: null pointer");
     if (n_planes < 1 || n_planes > kMaxMultiPlanes)
         return fail(T2H_ERR_ARG, "segsum_bwd_multi: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
-    if (B < 1 || N < 0 || nbits < 1 || nbits > T2H_MAX_NBITS || C < 1) return fail(T2H_ERR_ARG, "segsum_bwd_multi: unsupported shape");
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || C < 1) return fail(T2H_ERR_ARG, "segsum_bwd_multi: unsupported shape");
     MultiPlanes mp{};
     mp.n = n_planes;
     for (int q = 0; q < n_planes; ++q) {
@@ -1838,7 +1838,7 @@ T2H_API int t2h_segsum_bwd_multi(const float *const *gplanes_nhwc, const int *le
     }
     if (C % 4 == 0 && ((mask && ((uintptr_t)mask & 15)) || (addend && ((uintptr_t)addend & 15)) || ((uintptr_t)gfeat & 15)))
         return fail(T2H_ERR_ARG, "segsum_bwd_multi: rows must be 16-byte aligned");
-    const int64_t npts = (int64_t)B * N;
+    const int64_t npts = rows_of(B, N);
     if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
@@ -1861,8 +1861,7 @@ T2H_API int t2h_segmean_bwd_add(const float *gplane_nhwc, const int32_t *cell, c
     if (addend && C % 4 == 0 && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "segmean_bwd: addend must be 16-byte aligned");
     int rc = check_level("segmean_bwd", B, nbits, level, C);
     if (rc) return rc;
-    if (N < 0) return fail(T2H_ERR_ARG, "segmean_bwd: N < 0");
-    int64_t npts = (int64_t)B * N;
+    int64_t npts = rows_of(B, N);
     if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
@@ -1877,8 +1876,8 @@ T2H_API int t2h_segmean_bwd_add(const float *gplane_nhwc, const int32_t *cell, c
 T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                            t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd: null pointer");
-    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_fwd: unsupported shape");
-    int64_t npts = (int64_t)B * N;
+    if (dim < 2 || B < 1 || r < 1 || C < 1 || (N < 0 && dim < 3)) return fail(T2H_ERR_ARG, "sample_fwd: unsupported shape");
+    int64_t npts = rows_of(B, N);
     if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
@@ -1905,10 +1904,10 @@ T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts,
         return fail(T2H_ERR_ARG, "sample_relu_cellsums: the pooled sums need sum_level < level and 16-byte aligned rows of >= C floats");
     int rc = check_level("sample_relu_cellsums", B, nbits, level, C);
     if (rc) return rc;
-    if (dim < 2 || N < 0 || sum_level < 0 || sum_level > level || C % 256 != 0 || ld_sums < C || ld_sums % 4 != 0 ||
+    if (dim < 2 || sum_level < 0 || sum_level > level || C % 256 != 0 || ld_sums < C || ld_sums % 4 != 0 ||
         ((uintptr_t)plane_nhwc & 15) || ((uintptr_t)sums_nhwc & 15) || ((uintptr_t)sign_bits & 15))
         return fail(T2H_ERR_ARG, "sample_relu_cellsums: needs C %% 256 == 0, sum_level <= level, 16-byte aligned rows");
-    if ((int64_t)B * N == 0) return fail(T2H_ERR_ARG, "sample_relu_cellsums: empty tile");
+    if (rows_of(B, N) == 0) return fail(T2H_ERR_ARG, "sample_relu_cellsums: empty tile");
     const int64_t cells = (int64_t)B << (2 * (nbits - level));
     const int chunks = C / 256, waves = chunks < 4 ? chunks : 4;
     int groups = 1;                                                   // split the children until ~8192 workgroups exist (4096: +10 us at r = 64; 16384: +18 us at r = 32)
@@ -1918,7 +1917,7 @@ T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts,
     while (groups < (pooled_nhwc ? nchild / 4 : nchild) && cells * ((chunks + 3) / 4) * groups < min_wgs) groups *= 2;
     hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4, groups), dim3(64 * waves),
                        (size_t)waves * 9 * 256 * sizeof(float), as_stream(stream), plane_nhwc, pts, dim, off0, nbits, level,
-                       sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)((int64_t)B * N - 1),
+                       sum_level, C, sums_nhwc, ld_sums, static_cast<unsigned long long *>(sign_bits), (int)(rows_of(B, N) - 1),
                        pooled_nhwc, ld_pooled);
     return check_launch("sample_relu_cellsums");
 }
@@ -1933,7 +1932,7 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: 1..%d planes, got %d", kMaxMultiPlanes, n_planes);
     int rc = check_level("sample_bwd_from_sums", B, nbits, level, C);
     if (rc) return rc;
-    if (dim < 2 || N < 0 || C % 4 != 0 || ((uintptr_t)mask & 15)) return fail(T2H_ERR_ARG, "sample_bwd_from_sums: unsupported shape");
+    if (dim < 2 || C % 4 != 0 || ((uintptr_t)mask & 15)) return fail(T2H_ERR_ARG, "sample_bwd_from_sums: unsupported shape");
     if (mask_is_bits && (C % 256 != 0 || !cells_mfma(C)))
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: packed sign bits need C %% 256 == 0 (and the matrix-core partials)");
     const float *maskf = static_cast<const float *>(mask);
@@ -1968,7 +1967,7 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
         int folded = 0;
         for (int q = 0; q < n_planes; ++q) folded += levels[q] >= tl;
         // rows per workgroup (average) against table entries: build when it replaces more row loads than it costs
-        const int64_t rows_per_wg = (int64_t)B * N / (groups * cp.S > 0 ? groups * cp.S : 1);
+        const int64_t rows_per_wg = rows_of(B, N) / (groups * cp.S > 0 ? groups * cp.S : 1);
         if (folded > 0 && rows_per_wg * table_on >= entries) tlevel = tl;
     }
     static const int walk_on = getenv("T2H_CELLS_WALK") ? atoi(getenv("T2H_CELLS_WALK")) : 1;
@@ -1977,9 +1976,9 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
         int wl = level - 1;
         for (int q = 0; q < n_planes; ++q) wl = levels[q] < wl ? levels[q] : wl;
         // few rows per sampling cell: one workgroup per 2 x 2 block of cells (walk_on == 2 / 3 force one of the forms)
-        const bool blocks = walk_on == 3 || (walk_on == 1 && (int64_t)B * N < 64 * groups);
+        const bool blocks = walk_on == 3 || (walk_on == 1 && rows_of(B, N) < 64 * groups);
         const unsigned long long *bw = static_cast<const unsigned long long *>(mask);
-        const int npts_m1 = (int)((int64_t)B * N - 1);
+        const int npts_m1 = (int)(rows_of(B, N) - 1);
         GroupCfg g = group_cfg<4>(C);
         if (blocks) {
             hipLaunchKernelGGL(sample_bwd_walk_kernel<1>, dim3((unsigned)(groups >> 2), C / 256), dim3(256), 0, as_stream(stream), pts,
@@ -1996,10 +1995,10 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
     }
     if (mask_is_bits)
         hipLaunchKernelGGL((sample_bwd_cells_mfma_kernel<true, true>), dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)B * N);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)rows_of(B, N));
     else if (cells_mfma(C))
         hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
-                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)B * N);
+                           as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.S, partial, mp, cell, maskf, tlevel, (size_t)rows_of(B, N));
     else
         hipLaunchKernelGGL(sample_bwd_cells_kernel<true>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                            (size_t)P * G * sizeof(float4), as_stream(stream), nullptr, pts, dim, off0, nbits, level, C, cp.lgG, cp.S,
@@ -2013,10 +2012,10 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
 T2H_API int t2h_sample_fwd_relu(const float *plane_nhwc, const float *pts, int dim, int B, int N, int r, int C, float *out,
                                 void *sign_bits, t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !out) return fail(T2H_ERR_ARG, "sample_fwd_relu: null pointer");
-    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_fwd_relu: unsupported shape");
+    if (dim < 2 || B < 1 || r < 1 || C < 1 || (N < 0 && dim < 3)) return fail(T2H_ERR_ARG, "sample_fwd_relu: unsupported shape");
     if (sign_bits && (C % 256 != 0 || ((uintptr_t)sign_bits & 15)))
         return fail(T2H_ERR_ARG, "sample_fwd_relu: the packed sign bits need C %% 256 == 0 and a 16-byte aligned buffer");
-    int64_t npts = (int64_t)B * N;
+    int64_t npts = rows_of(B, N);
     if (npts == 0) return T2H_OK;
     T2H_DISPATCH_VEC(C,
         { GroupCfg g = group_cfg<4>(C);
@@ -2041,7 +2040,7 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
     if (addend && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "sample_bwd: addend must be 16-byte aligned");
     int rc = check_level("sample_bwd", B, nbits, level, C);
     if (rc) return rc;
-    if (dim < 2 || N < 0) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
+    if (dim < 2) return fail(T2H_ERR_ARG, "sample_bwd: unsupported shape");
     int64_t groups = (int64_t)B << (2 * (nbits - level));
     CoarsePlan cp = coarse_plan(B, N, nbits, level, C, kSampleBwdMinPts);
     if (cp.use) {
@@ -2053,7 +2052,7 @@ T2H_API int t2h_sample_bwd_add(const float *gout, const float *pts, int dim, con
         if (cells_mfma(C))
             hipLaunchKernelGGL(sample_bwd_cells_mfma_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads), 0,
                                as_stream(stream), gout, pts, dim, off0, nbits, level, C, cp.S, partial, MultiPlanes{}, nullptr,
-                               nullptr, -1, (size_t)B * N);
+                               nullptr, -1, (size_t)rows_of(B, N));
         else
             hipLaunchKernelGGL(sample_bwd_cells_kernel<false>, dim3((unsigned)groups, cp.S * cp.chunks), dim3(kCellThreads),
                                (size_t)P * G * sizeof(float4), as_stream(stream), gout, pts, dim, off0, nbits, level, C,
@@ -2084,7 +2083,7 @@ T2H_API int t2h_sample_adjoint_build(const float *pts, int dim, const int32_t *o
     if (!pts || !off0 || !offsets || !entries) return fail(T2H_ERR_ARG, "sample_adjoint_build: null pointer");
     int rc = check_level("sample_adjoint_build", B, nbits, level, 1);
     if (rc) return rc;
-    if (dim < 2 || N < 0 || (int64_t)B * N > ((int64_t)1 << 28)) return fail(T2H_ERR_ARG, "sample_adjoint_build: unsupported shape");
+    if (dim < 2 || rows_of(B, N) > ((int64_t)1 << 28)) return fail(T2H_ERR_ARG, "sample_adjoint_build: unsupported shape");
     if ((uintptr_t)entries & 7) return fail(T2H_ERR_ARG, "sample_adjoint_build: entries must be 8-byte aligned");
     const int64_t npix = (int64_t)B << (2 * (nbits - level));
     const int64_t nblocks = (npix + 15) / 16;
@@ -2119,8 +2118,8 @@ T2H_API int t2h_sample_bwd_adjoint(const float *gout, const int32_t *offsets, co
 T2H_API int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, int N, int r, int C,
                                   float *gplane_nhwc, t2h_stream_t stream) {
     if (!gout || !pts || !gplane_nhwc) return fail(T2H_ERR_ARG, "sample_bwd_atomic: null pointer");
-    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_bwd_atomic: unsupported shape");
-    int64_t npts = (int64_t)B * N;
+    if (dim < 2 || B < 1 || N < 0 || r < 1 || C < 1) return fail(T2H_ERR_ARG, "sample_bwd_atomic: unsupported shape (equal-N batches only)");
+    int64_t npts = rows_of(B, N);
     if (npts == 0) return T2H_OK;
     int lg = group_log2(C, 1);
     hipLaunchKernelGGL(sample_bwd_atomic_kernel, dim3(grid_for(npts, lg)), dim3(kThreads), 0, as_stream(stream), gout, pts,

@@ -24,6 +24,13 @@ const char *noted_kernel();
 
 inline hipStream_t as_stream(t2h_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// (B, N) of the point-side entry points: B tiles of N rows each -- or, N < 0, a RAGGED batch of B tiles with -N rows in all
+// (t2h_tile_build_ragged: tile boundaries are in off0 / the cell codes, and a row's tile index is kept as int bits in the LAST
+// float of its pts row).  The reference trains with batch = 1 because N varies per tile (tomosar2height.yaml:40); the tiles of
+// its 64-tile accumulation window are independent, so they can share launches.
+inline int64_t rows_of(int B, int N) { return N >= 0 ? (int64_t)B * N : -(int64_t)N; }
+inline int rows_per_tile(int B, int N) { return N >= 0 ? N : (int)(-(int64_t)N / (B > 0 ? B : 1)); }
+
 // ---- Morton helpers: x in even bits, y in odd bits (up to 16 bits per coordinate) --------------
 __host__ __device__ inline uint32_t part1by1(uint32_t v) {
     v &= 0x0000ffffu;

@@ -609,6 +609,8 @@ class _PointTrunk(torch.autograd.Function):
             ctx.save_for_backward(pts, *params, *nets, *pooled[1:], *hrs, *winners)
             return out
         ctx.fused = False
+        if pts.shape[1] != w_pos.shape[1]:                 # (a ragged TileIndex keeps the tile index in one more column)
+            pts = pts[:, :w_pos.shape[1]].contiguous()
         cats, hrs, winners = [], [], []
         cat0 = _empty(m, w_pos.shape[0], pts)
         linear_fwd_(pts, w_pos, b_pos, cat0)                                   # pointnet.py:72

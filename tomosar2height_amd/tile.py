@@ -20,9 +20,17 @@ class TileIndex:
     inside a cell differs from the reference (stable sort: original order is kept inside a finest cell).
     """
 
-    def __init__(self, cloud: torch.Tensor, plane_resolution: int, status: torch.Tensor = None):
+    def __init__(self, cloud, plane_resolution: int, status: torch.Tensor = None):
         """``status``: optional persistent int32 ``[2]`` device tensor; ``status[1]`` keeps a running total of
-        out-of-domain points over all tiles built with it (read it with one sync whenever convenient)."""
+        out-of-domain points over all tiles built with it (read it with one sync whenever convenient).
+
+        ``cloud``: ``[B, N, dim]`` -- or a list / tuple of ``[1, N_i, dim]`` (``[N_i, dim]``) clouds with DIFFERENT point
+        counts: a ragged batch (``t2h_tile_build_ragged``).  The reference runs the tiles of its 64-tile accumulation window
+        one at a time because N varies per tile (tomosar2height.yaml:40); here they share one index and one set of launches.
+        A ragged index reports ``N = -total_rows`` (the library's convention for such batches) and ``n_points`` rows."""
+        if isinstance(cloud, (list, tuple)):
+            self._init_ragged(cloud, plane_resolution, status)
+            return
         if cloud.dim() != 3 or cloud.shape[-1] < 2:
             raise ValueError(f"expected a [B, N, dim>=2] point tensor, got {tuple(cloud.shape)}")
         if cloud.dtype != torch.float32:
@@ -55,6 +63,52 @@ class TileIndex:
         self.device = dev
         self._adjoint = {}
 
+    def _init_ragged(self, clouds, plane_resolution, status):
+        clouds = [c.reshape(-1, c.shape[-1]) for c in clouds]
+        if not clouds or any(c.dtype != torch.float32 for c in clouds) or len({c.shape[1] for c in clouds}) != 1:
+            raise TypeError("a ragged batch is a non-empty list of float32 [1, N_i, dim] clouds of one dim")
+        if any(c.shape[0] < 1 for c in clouds):
+            raise ValueError("every tile of a ragged batch must hold at least one point (skip invalid tiles, train.py:150-151)")
+        self.R = int(plane_resolution)
+        self.nbits = _log2_exact(self.R)
+        if not 1 <= self.nbits <= 10:
+            raise ValueError("plane resolution must be in [2, 1024]")
+        flat = torch.cat(clouds, 0).contiguous()
+        _lib.require_device(flat, what="TileIndex")
+        import ctypes
+        self.B = len(clouds)
+        counts = [int(c.shape[0]) for c in clouds]
+        starts = [0]
+        for n in counts:
+            starts.append(starts[-1] + n)
+        total, in_dim = starts[-1], flat.shape[1]
+        self.counts, self.starts = counts, starts
+        self.N = -total                                       # the library's "ragged batch, -N rows in all" (include/t2h.h)
+        self.dim = in_dim + 1                                 # sorted rows carry their tile index in one more float
+        dev = flat.device
+        cells = self.B * (1 << (2 * self.nbits))
+        self.pts = torch.empty(total, self.dim, dtype=torch.float32, device=dev)
+        self.perm = torch.empty(total, dtype=torch.int32, device=dev)
+        self.cell = torch.empty(total, dtype=torch.int32, device=dev)
+        self.off0 = torch.empty(cells + 1, dtype=torch.int32, device=dev)
+        if status is None:
+            status = torch.zeros(2, dtype=torch.int32, device=dev)
+        elif status.dtype != torch.int32 or status.numel() != 2 or status.device != dev:
+            raise ValueError("status must be an int32 [2] tensor on the points' device")
+        self.status = status
+        ws_bytes = int(_lib.load().t2h_tile_ragged_workspace_bytes(self.B, total, max(counts), self.nbits))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        host_starts = (ctypes.c_int32 * (self.B + 1))(*starts)
+        _lib.call("t2h_tile_build_ragged", _lib.ptr(flat), in_dim, self.B, ctypes.cast(host_starts, ctypes.c_void_p), self.nbits,
+                  _lib.ptr(self.pts), self.dim, _lib.ptr(self.perm), _lib.ptr(self.cell), _lib.ptr(self.off0),
+                  _lib.ptr(self.status), _lib.ptr(ws), ws_bytes, _lib.stream(), nbytes=16 * total + 4 * cells)
+        self.device = dev
+        self._adjoint = {}
+
+    @property
+    def ragged(self) -> bool:
+        return self.N < 0
+
     def sample_adjoint(self, level: int):
         """``(offsets, entries)`` of the transposed bilinear-sampling matrix at ALTO level ``level`` (CSR over the pixels,
         ``t2h_sample_adjoint_build``), built on first use and kept for the tile's lifetime: every further sample backward
@@ -73,7 +127,7 @@ class TileIndex:
 
     @property
     def n_points(self) -> int:
-        return self.B * self.N
+        return -self.N if self.N < 0 else self.B * self.N
 
     # -------------------------------------------------------------------------------------- built ahead of its step
     @classmethod
@@ -140,6 +194,8 @@ class TileIndex:
 
     def sort_rows(self, feat: torch.Tensor) -> torch.Tensor:
         """[B, N, C] original order -> [B*N, C] sorted order (test/interop helper, not on the hot path)."""
+        if self.N < 0:
+            raise NotImplementedError("sort_rows / unsort_rows: equal-N batches only (test / interop helpers)")
         b, n, c = feat.shape
         idx = (self.perm.long() + torch.arange(b, device=feat.device).repeat_interleave(n) * n)
         return feat.reshape(b * n, c)[idx].contiguous()

@@ -139,6 +139,8 @@ class Trainer:
     # ------------------------------------------------------------------------------------------ loss
     def _losses(self, data, mask_threshold):
         device = self.device
+        if isinstance(data, (list, tuple)):
+            return self._losses_micro_batch(data, mask_threshold)
         input_cloud = data.get("inputs").to(device) if self.use_cloud else None
         input_image = data.get("image").to(device) if self.use_image else None
         dsm_gt = data.get("dsm").to(device)[None, ...]
@@ -148,6 +150,25 @@ class Trainer:
             loss_ce = self.weight_ce * self.loss_ce(pb.squeeze(), (dsm_gt.squeeze() > mask_threshold).float())
         else:
             loss_ce = torch.zeros((), device=device)      # (a fill kernel: capturable, unlike torch.tensor(0.0))
+        return loss_l1, loss_ce
+
+    def _losses_micro_batch(self, tiles, mask_threshold):
+        """Several tiles of one accumulation window in ONE forward / backward.  The reference runs them one by one only because
+        their point counts differ (tomosar2height.yaml:40); they are independent, and it SUMS their gradients (trainer.py:69-89),
+        so the loss of the micro-batch is the SUM of the per-tile mean losses: every tile has the same number of pixels, hence
+        sum_b mean_b = B x (mean over the whole batch).  The clouds go to the model as a list -> one ragged ``TileIndex``."""
+        device, nb = self.device, len(tiles)
+        clouds = [t.get("inputs").to(device) for t in tiles] if self.use_cloud else None
+        if clouds is not None and len({c.shape[1] for c in clouds}) == 1:
+            clouds = torch.cat(clouds, 0)                  # equal point counts: the plain [B, N, 3] batch
+        image = torch.cat([t.get("image").to(device) for t in tiles], 0) if self.use_image else None
+        dsm_gt = torch.cat([t.get("dsm").to(device).reshape(1, *t.get("dsm").shape[-2:]) for t in tiles], 0).float()
+        pa, pb = self.model(input_cloud=clouds, input_image=image)
+        loss_l1 = nb * self.loss_l1(pa.reshape(dsm_gt.shape), dsm_gt)
+        if self.use_footprint:
+            loss_ce = nb * self.weight_ce * self.loss_ce(pb.reshape(dsm_gt.shape), (dsm_gt > mask_threshold).float())
+        else:
+            loss_ce = torch.zeros((), device=device)
         return loss_l1, loss_ce
 
     # ------------------------------------------------------------------------------------------ hipGraph
@@ -209,9 +230,17 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------ train
     def train_step(self, data) -> bool:
-        """One tile: forward, loss, backward.  Returns True when this call ended with an optimizer step."""
+        """One tile -- or a LIST of tiles of the same accumulation window as one micro-batch (``_losses_micro_batch``: same
+        accumulated gradient as feeding them one by one, to fp32 re-association) --: forward, loss, backward.  Returns True
+        when this call ended with an optimizer step."""
         self.model.train()
-        if self._graph_matches(data):
+        n_tiles = len(data) if isinstance(data, (list, tuple)) else 1
+        if n_tiles > 1 and (self.accumulated_steps + n_tiles > self.local_every):
+            raise ValueError(f"a micro-batch of {n_tiles} tiles would cross the optimizer step boundary "
+                             f"({self.accumulated_steps} of {self.local_every} tiles accumulated)")
+        if n_tiles == 1 and isinstance(data, (list, tuple)):
+            data = data[0]
+        if n_tiles == 1 and self._graph_matches(data):
             g = self._graph
             for k, buf in g["static"].items():
                 buf.copy_(data[k], non_blocking=True)
@@ -245,7 +274,7 @@ class Trainer:
             # their .grad are views into one flat buffer that the wgrad kernels accumulate into directly
             self.bucket = GradBucket(list(self.model.parameters()))
 
-        self.accumulated_steps += 1
+        self.accumulated_steps += n_tiles
         self.accumulated_loss += loss.detach()
         self.accumulated_loss_dict["loss_ce"] += loss_ce.detach()
         self.accumulated_loss_dict["loss_l1"] += loss_l1.detach()
