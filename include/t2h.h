@@ -362,7 +362,9 @@ int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float *db, int
  * t2h_conv3x3_bx3_weights_bytes; activations are split inside the kernels, once per staged element.
  *   fwd    y  = [y +] act(conv(x, w) + bias)          flags: T2H_RELU_OUT, T2H_ACCUM
  *   dgrad  dx = [dx +] conv_transpose(dy, w) * (mask > 0)     flags: T2H_ACCUM
- *   wgrad  dw = [dw +] sum_p dy[p] (x) x[p+tap]; db = [db +] sum_p dy[p] (db may be NULL); flags: T2H_ACCUM; deterministic slabs */
+ *   wgrad  dw = [dw +] sum_p dy[p] (x) x[p+tap]; db = [db +] sum_p dy[p] (db may be NULL); flags: T2H_ACCUM; deterministic slabs
+ * T2H_BF16 (all three): only the leading bf16 part of both operands, ONE MFMA per product -- the arithmetic of BASELINE
+ * configs[2] ("bf16 ... GEMMs on MFMA": operands rounded to bf16, fp32 accumulate, fp32 tensors), ~2e-3 relative. */
 int t2h_conv3x3_bx3_supported(int B, int H, int W, int Cin, int Cout);
 size_t t2h_conv3x3_bx3_weights_bytes(int Cin, int Cout);
 int t2h_conv3x3_bx3_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream);

@@ -174,15 +174,17 @@ def test_cloud_image_bf16_matches_the_oracle_at_full_size():
     with torch.no_grad():
         pa32, _ = model(input_cloud=cloud, input_image=image)
     _heights_check(pa32, pa_ref, "cloud+image fp32")
-    mlp.set_precision("bf16")
+    model.set_mlp_precision("bf16")                  # what bench.py --mlp-precision bf16 sets: per-point GEMMs AND 3x3 convolutions
     try:
+        from tomosar2height_amd import grid
+        assert grid.CONV_PRECISION == "bf16"
         pa, _ = model(input_cloud=cloud, input_image=image)
         torch.nn.functional.l1_loss(pa.squeeze(), tile["dsm"].squeeze().to(dev)).backward()
         err = _heights_check(pa, pa_ref, f"cloud+image bf16 ({mlp.trunk_precision()})", tol=BF16_HEIGHT_TOL)
         assert err > 1e-6, "bf16 mode produced fp32-identical heights: the flag is not reaching the kernels"
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     finally:
-        mlp.set_precision("fp32")
+        model.set_mlp_precision("fp32")
 
 
 @pytest.fixture(scope="module")

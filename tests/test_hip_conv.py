@@ -178,6 +178,39 @@ def test_conv3x3_bx3_error_is_fp32_grade(bx3_everywhere):
     assert torch.isfinite(yc[0, :, 20:30, 20:30]).all()
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64, 64, 128), (2, 16, 32, 32, 64), (1, 32, 32, 256, 512)])
+def test_conv3x3_bf16_mode(shape, bx3_everywhere):
+    """BASELINE configs[2]'s arithmetic on the same kernels (T2H_BF16: operands rounded to bf16 once, ONE MFMA per product, fp32
+    accumulate): forward, data and weight gradient within 1e-2 of the float64 result's max-norm (bf16: 8 significant bits; measured
+    ~2e-3) -- and measurably different from the exact split, i.e. the flag reaches the kernels."""
+    grid = bx3_everywhere
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(3 + sum(shape))
+    x = torch.randn(b, cin, h, w, generator=g).double().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).double().requires_grad_(True)
+    bias = torch.randn(cout, generator=g).double().requires_grad_(True)
+    gy = torch.randn(b, cout, h, w, generator=g)
+    want = F.conv2d(x, wt, bias, padding=1)
+    want.backward(gy.double())
+    xd, wd, gyd = _cl(x.detach().float()), _cl(wt.detach().float()), _cl(gy)
+    grid.set_conv_precision("bf16")
+    try:
+        y = grid._empty_cl(b, cout, h, w, _dev())
+        grid.conv3x3_fwd_(xd, wd, bias.detach().float().to(_dev()), y)
+        dx = grid._empty_cl(b, cin, h, w, _dev())
+        grid.conv3x3_dgrad_(gyd, wd, dx)
+        dw = torch.empty(cout, cin, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+        db = torch.empty(cout, device=_dev())
+        grid.conv3x3_wgrad_(gyd, xd, dw, db)
+    finally:
+        grid.set_conv_precision(None)
+    for got, ref in ((y, want.detach()), (dx, x.grad), (dw, wt.grad)):
+        _close(got, ref, tol=1e-2)
+        err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err > 2e-5, "bf16 mode gave fp32-grade results: the flag is not reaching the kernels"
+    _close(db, bias.grad)                                                 # (the bias gradient is summed in fp32 from the fp32 rows)
+
+
 def test_split_weight_cache_follows_the_weight(bx3_everywhere):
     """The split weights are recomputed when the weight's version counter or storage moves (optimizer steps -- FlatAdamW bumps
     the counter --, load_state_dict), in place (a captured hipGraph keeps its pointers), and not otherwise."""

@@ -384,7 +384,7 @@ def test_config3_cloud_image_bf16_mlp():
         want, _ = ref(input_cloud=cloud, input_image=image)
         fp32, _ = model(input_cloud=cloud.to(_dev()), input_image=image.to(_dev()))
     _close(fp32.cpu().numpy(), want.numpy(), what="fp32 height")
-    mlp.set_precision("bf16")
+    model.set_mlp_precision("bf16")                    # per-point GEMMs and 3x3 convolutions (grid.set_conv_precision)
     try:
         pa, _ = model(input_cloud=cloud.to(_dev()), input_image=image.to(_dev()))
         loss = pa.abs().mean()
@@ -394,7 +394,7 @@ def test_config3_cloud_image_bf16_mlp():
         assert err > 1e-5, "bf16 mode produced fp32-identical output: the flag is not reaching the kernels"
         assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     finally:
-        mlp.set_precision("fp32")
+        model.set_mlp_precision("fp32")
 
 
 def test_hip_graph_replay_matches_eager():

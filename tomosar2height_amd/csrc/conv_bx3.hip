@@ -115,17 +115,19 @@ struct RowsArgs {
 // used: 4 rows / 32 channels (80-byte pixel stride) and -- for planes with enough tiles to fill the chip -- 8 rows / 16
 // channels (48-byte stride; half the barriers, LDS fragment bytes and weight-slab traffic per MFMA).  Both keep the halo
 // images + two weight slabs under 80 KB: two workgroups per CU, one staging while the other computes.
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH>
+// NPL = 3: the exact split (six MFMAs per product).  NPL = 1: operands rounded to bf16 once (T2H_BF16, BASELINE configs[2]:
+// one MFMA per product, a third of the LDS images and weight traffic) -- the same kernel without the residual planes.
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL>
 __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     constexpr int PXB = CCH * 2 + 16;     // bytes per pixel and plane of the halo image: CCH bf16 + 16 B (an odd multiple of 16 B)
     constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = 9 * NQ;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
     constexpr int HP = (TH + 2) * (TW + 2);                              // halo pixels
     constexpr int PLANE = HP * PXB;                                      // bytes per bf16 plane
-    constexpr int BSLAB = (BN / 32) * 3 * 1024;                          // bytes per weight slab
-    constexpr int HALO_BYTES = 3 * PLANE;
-    constexpr int LDS_BYTES = HALO_BYTES + 2 * BSLAB;
-    static_assert(LDS_BYTES >= 4 * 32 * 36 * 4, "the epilogue's patches live in the same array");
+    constexpr int BSLAB = (BN / 32) * NPL * 1024;                        // bytes per weight slab
+    constexpr int HALO_BYTES = NPL * PLANE;
+    constexpr int LDS_WORK = HALO_BYTES + 2 * BSLAB;
+    constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (the epilogue's patches live in the same array)
     static_assert(WAVES_M * WAVES_N == 4 && TM * WAVES_M == TH && TN * WAVES_N * 32 == BN, "wave layout");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
     unsigned char *halo = lds, *bbuf = lds + HALO_BYTES;
@@ -173,8 +175,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 split3(hreg[f].z, hreg[f].w, b1, b2, b3);
                 unsigned char *d = halo + px * PXB + c4 * 8;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a3, b3);
+                if (NPL == 3) {
+                    *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a3, b3);
+                }
             }
         }
     };
@@ -188,8 +192,11 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         constexpr int PIECES = BSLAB / 1024;                             // 1 KB per wave instruction, dealt round-robin to the waves
 #pragma unroll
         for (int j = 0; j < (PIECES + 3) / 4; ++j)
-            if (j * 4 + wave < PIECES)
-                __builtin_amdgcn_global_load_lds((glb_void *)(src + (j * 256 + tid) * 16), (lds_void *)(dst + (j * 4 + wave) * 1024), 16, 0, 0);
+            if (j * 4 + wave < PIECES) {
+                // piece = (tile, plane); the prepared weights always hold three planes per tile
+                const int piece = j * 4 + wave, spiece = NPL == 3 ? piece : piece * 3;
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + spiece * 1024 + lane * 16), (lds_void *)(dst + piece * 1024), 16, 0, 0);
+            }
     };
 
     f32x16 acc[TM][TN];
@@ -217,24 +224,24 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 const int st = tap * NQ + q;
                 if (st + 1 < NSTEP) issue_b(c, st + 1, bbuf + ((s + 1) & 1) * BSLAB);
                 else if (c + 1 < c_end) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
-                uint4 af[TM][3], bfr[TN][3];
+                uint4 af[TM][NPL], bfr[TN][NPL];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
                     const unsigned char *a = halo + px * PXB + q * 32 + h * 16;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
+                    for (int pl = 0; pl < NPL; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bfr[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * 3 + pl) * 1024 + lane * 16);
+                    for (int pl = 0; pl < NPL; ++pl)
+                        bfr[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * NPL + pl) * 1024 + lane * 16);
                 __builtin_amdgcn_sched_barrier(0);                       // all fragment reads in flight before the first MFMA
                 // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
                 constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int e = 0; e < 6; ++e)
+                for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -291,17 +298,17 @@ struct WgradArgs {
 
 // COT = 32-channel tiles of Cout per workgroup (4, 2 or 1): the workgroup's (COT x 9) output tiles are dealt to the four waves
 // as (co tile, contiguous tap range)
-template <int COT>
+template <int COT, int NPL>
 __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     constexpr int WPC = 4 / COT;                                         // waves per co tile
     constexpr int TMAX = (9 + WPC - 1) / WPC;                            // taps per wave, at most
     constexpr int YS = COT == 1 ? 64 : 64 * COT + 64;                    // dY image: bytes per pixel row (4 rows tile the bank row)
     constexpr int XS = 64;                                               // X image: 32 bf16 per pixel, no padding
     constexpr int YPLANE = 32 * YS, XHP = 3 * (TW + 2), XPLANE = XHP * XS;
-    constexpr int LDS_BYTES = 3 * YPLANE + 3 * XPLANE;
-    static_assert(LDS_BYTES >= 4 * 32 * 36 * 4, "the epilogue's patches live in the same array");
+    constexpr int LDS_WORK = NPL * YPLANE + NPL * XPLANE;
+    constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (epilogue patches, column-sum scratch)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-    unsigned char *yimg = lds, *ximg = lds + 3 * YPLANE;
+    unsigned char *yimg = lds, *ximg = lds + NPL * YPLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x, ci0 = blockIdx.y * CC, co0 = blockIdx.z * (32 * COT);
@@ -349,8 +356,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
                 split3(xr[f].z, xr[f].w, b1, b2, b3);
                 unsigned char *d = ximg + px * XS + c4 * 8;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2 *>(d + XPLANE) = make_uint2(a2, b2);
-                *reinterpret_cast<uint2 *>(d + 2 * XPLANE) = make_uint2(a3, b3);
+                if (NPL == 3) {
+                    *reinterpret_cast<uint2 *>(d + XPLANE) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2 *>(d + 2 * XPLANE) = make_uint2(a3, b3);
+                }
             }
         }
 #pragma unroll
@@ -362,8 +371,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             split3(yr[f].z, yr[f].w, b1, b2, b3);
             unsigned char *d = yimg + px * YS + c4 * 8;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
-            *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
-            *reinterpret_cast<uint2 *>(d + 2 * YPLANE) = make_uint2(a3, b3);
+            if (NPL == 3) {
+                *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(d + 2 * YPLANE) = make_uint2(a3, b3);
+            }
             if (do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
         }
     };
@@ -394,22 +405,22 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                                    // two 16-pixel steps
-            bf16x8 af[3];
+            bf16x8 af[NPL];
             const unsigned char *ya = yimg + (16 * s + kpix) * YS + cot * 64 + choff;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[pl] = tr8(ya + pl * YPLANE, YS);
+            for (int pl = 0; pl < NPL; ++pl) af[pl] = tr8(ya + pl * YPLANE, YS);
 #pragma unroll
             for (int t = 0; t < TMAX; ++t) {
                 const int tap = tap_lo + t;
                 if (tap < tap_hi) {                                       // wave-uniform
                     const int ky = tap / 3, kx = tap - 3 * ky;
                     const unsigned char *xa = ximg + (ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
-                    bf16x8 bfr[3];
+                    bf16x8 bfr[NPL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
+                    for (int pl = 0; pl < NPL; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
                     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
+                    for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia[e]], bfr[ib[e]], acc[t], 0, 0, 0);
                 }
             }
@@ -491,12 +502,17 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc) {
 
 #define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_)                                                                                  \
     do {                                                                                                                    \
-        hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_>), dim3((unsigned)grid), dim3(NT), 0, s, a);            \
-        note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                       \
+        if (single) {                                                                                                       \
+            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1>), dim3((unsigned)grid), dim3(NT), 0, s, a);     \
+            note_kernel("bf16_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                  \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3>), dim3((unsigned)grid), dim3(NT), 0, s, a);     \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                   \
+        }                                                                                                                   \
     } while (0)
 
 // `a`: x, wf, bias, mask, y, geometry and epilogue flags; splits the reduction into `ws` when the plan says so
-int launch_rows(RowsArgs a, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
+int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
     const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc);
     const long long grid = r.tiles * r.splits;
     if (grid > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
@@ -589,7 +605,7 @@ T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bia
     a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
-    return launch_rows(a, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
+    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
 }
 
 T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, const float *mask, int B, int H, int W, int Cin,
@@ -601,7 +617,7 @@ T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, 
     a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
     a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
-    return launch_rows(a, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
+    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
 }
 
 T2H_API size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -628,9 +644,15 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
     dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
-    if (p.cot == 4) { hipLaunchKernelGGL(bx3_wgrad_kernel<4>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4>"); }
-    else if (p.cot == 2) { hipLaunchKernelGGL(bx3_wgrad_kernel<2>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2>"); }
-    else { hipLaunchKernelGGL(bx3_wgrad_kernel<1>, grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1>"); }
+    if (flags & T2H_BF16) {
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bf16_wgrad_kernel<4>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bf16_wgrad_kernel<2>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bf16_wgrad_kernel<1>"); }
+    } else {
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1>"); }
+    }
     if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s);
 }

@@ -101,15 +101,32 @@ def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
 # T2H_CONV_PRECISION=fp32 keeps every 3x3 convolution on conv.hip's fp32 MFMA kernels (A/B; same tolerance either way: the
 # split is exact and the accumulation fp32 -- tests/test_hip_conv.py measures both against float64).  Planes of at least
 # T2H_BX3_MIN_PIXELS pixels (default: 256 x 256, where the kernels were measured 1.4-1.8x faster; profiles/conv_bf16x3_lab.hip).
+# 'bf16' (set by TomoSAR2Height.set_mlp_precision('bf16'), BASELINE configs[2]): the same kernels with the leading bf16 part of
+# both operands only -- one MFMA per product, tolerance of that MODE 2e-2 of the height scale (tests/test_full_size_vs_oracle.py).
 CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "bf16x3")
 BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(32 * 32)))
-if CONV_PRECISION not in ("fp32", "bf16x3"):
-    raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected 'fp32' or 'bf16x3'")
+if CONV_PRECISION not in ("fp32", "bf16x3", "bf16"):
+    raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected 'fp32', 'bf16x3' or 'bf16'")
+_DEFAULT_CONV_PRECISION = CONV_PRECISION
+
+
+def set_conv_precision(name: str = None):
+    """'bf16x3' (exact split: fp32-grade), 'fp32' (conv.hip's fp32 MFMA) or 'bf16' (operands rounded to bf16: configs[2]);
+    None restores the process default (T2H_CONV_PRECISION)."""
+    global CONV_PRECISION
+    name = _DEFAULT_CONV_PRECISION if name is None else name
+    if name not in ("fp32", "bf16x3", "bf16"):
+        raise ValueError("conv precision must be 'fp32', 'bf16x3' or 'bf16'")
+    CONV_PRECISION = name
 
 
 def bx3_applicable(b: int, h: int, wd: int, cin: int, cout: int) -> bool:
-    return (CONV_PRECISION == "bf16x3" and h * wd >= BX3_MIN_PIXELS
+    return (CONV_PRECISION in ("bf16x3", "bf16") and h * wd >= BX3_MIN_PIXELS
             and bool(_lib.load().t2h_conv3x3_bx3_supported(b, h, wd, cin, cout)))
+
+
+def _bx3_flag() -> int:
+    return _lib.BF16 if CONV_PRECISION == "bf16" else 0
 
 
 class SplitWeightCache:
@@ -160,7 +177,7 @@ def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
     cout = w.shape[0]
     lib = _lib.load()
     if bx3_applicable(b, h, wd, cin, cout):
-        flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0)
+        flags = (_lib.RELU_OUT if relu else 0) | (_lib.ACCUM if accumulate else 0) | _bx3_flag()
         nws = _lib.ws_bytes("t2h_conv3x3_bx3_fwd_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, x.device)
         _lib.call("t2h_conv3x3_bx3_fwd", _lib.ptr(x), _lib.ptr(split_weights.get(w, False)),
@@ -186,7 +203,7 @@ def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
         nws = _lib.ws_bytes("t2h_conv3x3_bx3_dgrad_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, gy.device)
         _lib.call("t2h_conv3x3_bx3_dgrad", _lib.ptr(gy), _lib.ptr(split_weights.get(w, True)), _lib.ptr(dx),
-                  _lib.ptr(mask) if mask is not None else None, b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0,
+                  _lib.ptr(mask) if mask is not None else None, b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag(),
                   _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel()),
                   flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
@@ -209,7 +226,7 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
         nws = _lib.ws_bytes("t2h_conv3x3_bx3_wgrad_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, gy.device)
         _lib.call(entry, _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                  b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
+                  b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag(), _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
                   tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
         return

@@ -62,9 +62,12 @@ class TomoSAR2Height(nn.Module):
 
     @staticmethod
     def set_mlp_precision(name: str):
-        """'fp32' (default) or 'bf16' for the per-point MLP GEMMs (process-wide; see ``mlp.set_precision``)."""
-        from . import mlp
+        """'fp32' (default) or 'bf16' (BASELINE configs[2]) for the per-point MLP GEMMs (process-wide; see ``mlp.set_precision``)
+        AND the 3x3 grid convolutions: in 'bf16' mode they run on the same bf16 matrix-core kernels with the operands rounded to
+        bf16 once instead of split exactly (``grid.set_conv_precision``) -- one MFMA per product, fp32 accumulate, fp32 tensors."""
+        from . import grid, mlp
         mlp.set_precision(name)
+        grid.set_conv_precision("bf16" if name == "bf16" else None)
 
     def forward(self, input_cloud=None, input_image=None):
         assert self.use_image or self.use_cloud, "At least one input modality must be used."
