@@ -72,11 +72,16 @@ def test_benchmarked_configuration_matches_the_oracle_at_full_size(use_image):
     # weight gradient, i.e. moves that row by ~1/sqrt(1024) = 3 % (measured: image_encoder.up_convs.0.conv2.weight 1.1e-2 with
     # L2 2.3e-3, everything else < 6.1e-3).  The image U-Net's three deepest levels therefore get 3e-2 in the max norm; the L2
     # criterion (3e-3) holds everywhere, and the mask-pinned checks of test_hip_masks.py / test_hip_conv.py pin the arithmetic.
+    # r04: the image U-Net's L2 bound is 5e-3 (measured 3.8e-3 on image_encoder.down_convs.2.conv1.weight once every 3x3
+    # convolution ran on the split-bf16 matrix-core kernels -- another summation order, so another set of units within 1e-7 of zero
+    # flips); that this is mask-flip noise and not arithmetic is pinned by test_hip_masks.py::test_image_unet_*_with_the_same_masks:
+    # the same levels, same kernels, against float64 with the forward's own masks: every output and gradient <= 2e-6.
     small_planes = ("image_encoder.down_convs.4.", "image_encoder.down_convs.5.", "image_encoder.up_convs.0.")
     for mx, l2, k in rows:
         lim_mx = 3e-2 if k.startswith(small_planes) else 1e-2
+        lim_l2 = 5e-3 if k.startswith("image_encoder.") else 3e-3
         assert mx <= lim_mx, f"{k}: max-normalised gradient error {mx:.2e} > {lim_mx:g}"
-        assert l2 <= 3e-3, f"{k}: L2 relative gradient error {l2:.2e}"
+        assert l2 <= lim_l2, f"{k}: L2 relative gradient error {l2:.2e} > {lim_l2:g}"
 
 
 # ------------------------------------------------------------------------------------------------ r04: every reported line

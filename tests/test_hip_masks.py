@@ -425,3 +425,86 @@ def test_deferred_point_features_equal_the_point_wise_chain():
     print(f"[deferred vs point-wise] plane {err:.2e}; worst gradients:", [(f"{m:.1e}", f"{l:.1e}", k) for m, l, k in worst[:4]])
     for mx, l2, k in worst:
         assert mx <= 1e-2 and l2 <= 3e-3, f"{k}: max {mx:.2e}, L2 {l2:.2e}"
+
+
+# ------------------------------------------------------------------------------------------------ image U-Net levels
+# (the plain image U-Net -- unet.py:112-187 -- had no mask-pinned level check, and it is where the module-level
+# gradient bound is loosest.)  Same method: the float64 restatement takes the HIP forward's own ReLU masks / pool winners.
+@pytest.mark.parametrize("cin,cout,hw,pooling", [(64, 128, 128, True), (32, 64, 256, True), (512, 1024, 16, False)],
+                         ids=["down2_64_128_at_128", "down1_32_64_at_256", "down5_512_1024_at_16"])
+def test_image_unet_down_level_vs_float64_with_the_same_masks(cin, cout, hw, pooling):
+    """DownConv of the image encoder (unet.py: conv3x3 -> ReLU -> conv3x3 -> ReLU -> 2x2 max-pool): both outputs and every
+    gradient, on the convolution kernels the model takes at that size (matrix cores with the exact bf16 split from 32-wide
+    planes, conv.hip's fp32 MFMA below)."""
+    from tomosar2height_amd import grid
+    from tomosar2height_amd.encoder.unet import DownConv
+    dev = _dev()
+    level = det_init_(DownConv(cin, cout, pooling=pooling), seed=61).to(dev)
+    level.channels_last = True
+    for m in (level.conv1, level.conv2):
+        m.weight.data = _cl(m.weight.data)
+    x = _cl(_rand((1, cin, hw, hw), 1)).requires_grad_(True)
+    pooled, before = level(x)
+    g_pool, g_before = _rand(tuple(pooled.shape), 2), _rand(tuple(before.shape), 3)
+    ((pooled * g_pool).sum() + ((before * g_before).sum() if pooling else 0.0)).backward()
+    with torch.no_grad():                                       # the same launches -> the same bits -> the forward's masks
+        y1 = grid._empty_cl(1, cout, hw, hw, dev)
+        grid.conv3x3_fwd_(x.detach(), grid._w_cl(level.conv1.weight), level.conv1.bias, y1, relu=True)
+    m1, m2 = (y1 > 0).to(D), (before.detach() > 0).to(D)
+
+    def restate(d):
+        p = {k: v.detach().to(d).requires_grad_(True) for k, v in _p64(level).items()}
+        x64 = x.detach().to(d, D).requires_grad_(True)
+        a1 = _conv64(x64, p, "conv1", 1) * m1.to(d)
+        a2 = _conv64(a1, p, "conv2", 1) * m2.to(d)
+        out = _pool64(a2, before.detach().to(d)) if pooling else a2
+        ((out * g_pool.to(d, D)).sum() + ((a2 * g_before.to(d, D)).sum() if pooling else 0.0)).backward()
+        return out, a2, x64, p
+    out64, a264, x64, p = _run64(restate)
+    ck = _Checks()
+    ck.add("out pooled", pooled.cpu(), out64.cpu())
+    ck.add("out before_pool", before.cpu(), a264.cpu())
+    ck.add("d x", x.grad.cpu(), x64.grad.cpu())
+    for k, v in level.named_parameters():
+        ck.add("d " + k, v.grad.cpu(), p[k].grad.cpu())
+    ck.finish(f"image U-Net DownConv {cin}->{cout} @{hw}^2")
+
+
+def test_image_unet_up_level_vs_float64_with_the_same_masks():
+    """UpConv 0 of the image encoder (1024 -> 512: transposed 2x2 conv of the 16 x 16 bottom plane, concat with the 32 x 32 skip,
+    conv3x3 -> ReLU -> conv3x3 -> ReLU): output and every gradient."""
+    from tomosar2height_amd import grid
+    from tomosar2height_amd.encoder.unet import UpConv
+    dev = _dev()
+    level = det_init_(UpConv(1024, 512), seed=62).to(dev)
+    level.channels_last = True
+    for m in (level.conv1, level.conv2, level.upconv):
+        m.weight.data = _cl(m.weight.data)
+    from_up = _cl(_rand((1, 1024, 16, 16), 4)).requires_grad_(True)
+    from_down = _cl(_rand((1, 512, 32, 32), 5)).requires_grad_(True)
+    out = level(from_down, from_up)
+    g = _rand(tuple(out.shape), 6)
+    (out * g).sum().backward()
+    with torch.no_grad():
+        up = grid.upconv2x2(from_up.detach(), level.upconv)
+        y1 = grid._empty_cl(1, 512, 32, 32, dev)
+        grid.conv3x3_fwd_(_cl(torch.cat((up, from_down.detach()), 1)), grid._w_cl(level.conv1.weight), level.conv1.bias, y1, relu=True)
+    m1, m2 = (y1 > 0).to(D), (out.detach() > 0).to(D)
+
+    def restate(d):
+        p = {k: v.detach().to(d).requires_grad_(True) for k, v in _p64(level).items()}
+        fu = from_up.detach().to(d, D).requires_grad_(True)
+        fd = from_down.detach().to(d, D).requires_grad_(True)
+        u = F.conv_transpose2d(fu, p["upconv.weight"], p["upconv.bias"], stride=2)
+        a1 = _conv64(torch.cat((u, fd), 1), p, "conv1", 1) * m1.to(d)
+        a2 = _conv64(a1, p, "conv2", 1) * m2.to(d)
+        (a2 * g.to(d, D)).sum().backward()
+        return a2, fu, fd, p
+    a264, fu, fd, p = _run64(restate)
+    ck = _Checks()
+    ck.add("out", out.cpu(), a264.cpu())
+    ck.add("d from_up", from_up.grad.cpu(), fu.grad.cpu())
+    ck.add("d from_down", from_down.grad.cpu(), fd.grad.cpu())
+    for k, v in level.named_parameters():
+        ck.add("d " + k, v.grad.cpu(), p[k].grad.cpu())
+    ck.finish("image U-Net UpConv 1024->512 @16^2->32^2")
