@@ -378,6 +378,19 @@ size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int C
 int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
                           int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
+/* The 1-tap form of the same kernels: a GEMM on rows, y[M, N] = [y +] act( x[M, K] W^T + bias ) * (mask > 0), fp32 in / out, products
+ * by the exact 3-way bf16 split (T2H_BF16: leading part only).  For nn.Linear on pixel rows and the grid-side products of the
+ * deferred ALTO point update (alto.py:123-130 re-associated, tomosar2height_amd/deferred.py), whose long reductions (K up to 2752
+ * stacked columns) ran at 0.4-0.6 of the fp32 matrix peak.  W: [N][K] with row stride ldw (w_is_kn = 0, nn.Linear layout) or
+ * [K][N] (w_is_kn = 1), split once by t2h_gemm_bx3_prepare.  M % 128 == 0, K % 64 == 0, N % 32 == 0 (t2h_gemm_bx3_supported);
+ * ldx / ldy / ldm: row strides in floats (column slices of wider matrices are fine).  Few-row products split K into slabs. */
+int t2h_gemm_bx3_supported(int64_t M, int K, int N);
+size_t t2h_gemm_bx3_weights_bytes(int K, int N);
+int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, void *wf, t2h_stream_t stream);
+size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N);
+int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
+                 int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
 /* nn.ConvTranspose2d(kernel_size=2, stride=2) of the ALTO up path (upconv2x2 in alto.py, used at alto.py:175,215-218,236):
  * output pixel (2y+dy, 2x+dx) = bias + sum_ci x[y, x, ci] w[ci, dy, dx, co].  H, W = INPUT plane dims (powers of two),
  * x [B,H,W,Cin], y / dy [B,2H,2W,Cout] NHWC; w [Cin][2][2][Cout] = channels_last memory of torch's [Cin,Cout,2,2]

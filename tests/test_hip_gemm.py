@@ -197,3 +197,43 @@ def test_full_size_linear_kernels_satisfy_the_bilinear_identities(k, n):
     a, b, c = dot(y, g), dot(x, dx), dot(w, dw)
     scale = max(abs(a), 1.0)
     assert abs(a - b) <= 2e-5 * scale + 1e-2 and abs(a - c) <= 2e-5 * scale + 1e-2, (a, b, c)
+
+
+# ---- the 1-tap form of the split-bf16 matrix-core kernels as a GEMM on rows (csrc/conv_bx3.hip, t2h_gemm_bx3) -------------------
+@pytest.mark.parametrize("m,k,n", [(65536, 320, 64), (16384, 832, 128), (1024, 1856, 512), (4096, 64, 832), (128, 64, 32),
+                                   (16384, 128, 2624)])
+def test_gemm_bx3_rows_vs_float64(m, k, n):
+    """The grid-side products of the deferred point update (deferred.py): y = x W^T and y = x W (k-major weight) on column SLICES
+    of wider matrices, with mask / accumulate, and a few-row case whose reduction is split into slabs -- against float64 at the
+    tolerance of the fp32 MFMA GEMMs (2e-5 of the max-norm)."""
+    from tomosar2height_amd import mlp
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(m + k + n)
+    wide = torch.randn(m, k + 64, generator=g).to(dev)
+    x = wide[:, 32:32 + k]                                                   # row stride k + 64, 128-byte offset
+    w_nk = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    w_kn = w_nk.t().contiguous()
+    want = x.double().cpu() @ w_nk.double().cpu().t()
+    scale = want.abs().max().item()
+    assert mlp._bx3_gemm_ok(m, k, n, x)
+
+    out_wide = torch.zeros(m, n + 32, device=dev)
+    y = out_wide[:, 16:16 + n]
+    from tomosar2height_amd import _lib
+    with _lib.KernelTimeline() as tl:
+        mlp.linear_fwd_(x, w_nk, None, y, bx3=True)
+    torch.cuda.synchronize()
+    assert any(r[5].startswith("bx3_rows_kernel") for r in tl.records), [r[5] for r in tl.records]
+    assert (y.double().cpu() - want).abs().max().item() <= 2e-5 * scale
+    assert float(out_wide[:, :16].abs().max()) == 0.0 and float(out_wide[:, 16 + n:].abs().max()) == 0.0
+    # k-major weight ("dx = dy w"), ReLU mask of the consumer, accumulate
+    mask = torch.randn(m, n, generator=g).to(dev)
+    base = torch.randn(m, n, generator=g).to(dev)
+    dx = base.clone()
+    mlp.linear_dgrad_(x, w_kn, dx, mask=mask, accumulate=True, bx3=True)
+    want2 = base.double().cpu() + want * (mask.cpu() > 0)
+    assert (dx.double().cpu() - want2).abs().max().item() <= 2e-5 * max(scale, want2.abs().max().item())
+    # determinism (slabs are summed in a fixed order)
+    y2 = torch.empty(m, n, device=dev)
+    mlp.linear_fwd_(x, w_nk, None, y2, bx3=True)
+    assert torch.equal(y2, y.contiguous())

@@ -90,6 +90,11 @@ SIGNATURES = {
     "t2h_conv3x3_bx3_dgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_conv3x3_bx3_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "t2h_conv3x3_bx3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_gemm_bx3_supported": (_i, [_i64, _i, _i]),
+    "t2h_gemm_bx3_weights_bytes": (_sz, [_i, _i]),
+    "t2h_gemm_bx3_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_gemm_bx3_workspace_bytes": (_sz, [_i64, _i, _i]),
+    "t2h_gemm_bx3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_fwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_dgrad_workspace_bytes": (_sz, [_i] * 5),

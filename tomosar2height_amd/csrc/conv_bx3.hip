@@ -100,6 +100,32 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
     dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
 }
 
+// the same for a plain weight matrix (1-tap form): W given as [N][K] (nn.Linear: k contiguous) or, KN, as [K][N]
+template <bool KN>
+__global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__restrict__ w, int K, int N, int ldw,
+                                                              unsigned *__restrict__ wf) {
+    const int ntile = N / 32;
+    const long long total = (long long)(K / 16) * ntile * 64;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int tile = (int)((t >> 6) % ntile);
+    const long long c16 = (t >> 6) / ntile;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = tile * 32 + r, k0 = (int)c16 * 16 + 8 * h;
+    unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = KN ? w[(size_t)(k0 + 2 * j) * ldw + n] : w[(size_t)n * ldw + k0 + 2 * j];
+        const float b = KN ? w[(size_t)(k0 + 2 * j + 1) * ldw + n] : w[(size_t)n * ldw + k0 + 2 * j + 1];
+        split3(a, b, p1[j], p2[j], p3[j]);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((c16 * ntile + tile) * 3) * 64 + lane;
+    dst[0] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+    dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+    dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
 // ---- fwd / dgrad --------------------------------------------------------------------------------------------------------------
 struct RowsArgs {
     const float *x;          // [B,H,W,Kc] fp32: the input (fwd) or dY (dgrad)
@@ -109,6 +135,7 @@ struct RowsArgs {
     float *y;                // [B,H,W,Nc], or the slab base when the reduction is split
     int B, H, W, Kc, Nc, flags;
     int splits, chunks_per_split;   // splits > 1: grid = tiles x splits, partial sums to y + split * B H W Nc (no epilogue)
+    int ldx, ldy, ldm;       // row strides (floats) of x, y and mask: Kc / Nc / Nc for the convolutions, free for the 1-tap (GEMM) form
 };
 
 // TH image rows x 32 columns x BN output channels per workgroup, CCH reduction channels per staged halo chunk.  Two shapes are
@@ -117,12 +144,17 @@ struct RowsArgs {
 // images + two weight slabs under 80 KB: two workgroups per CU, one staging while the other computes.
 // NPL = 3: the exact split (six MFMAs per product).  NPL = 1: operands rounded to bf16 once (T2H_BF16, BASELINE configs[2]:
 // one MFMA per product, a third of the LDS images and weight traffic) -- the same kernel without the residual planes.
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL>
+// NTAP = 9: the 3x3 convolution.  NTAP = 1: the same kernel as a plain GEMM on rows, Y[M, Nc] = X[M, Kc] W^T -- 1x1 convolutions,
+// nn.Linear on pixel rows and the grid-side products of the deferred ALTO point update (deferred.py): the "image" is M / 32
+// rows of 32 "pixels" with no halo, the staged chunk is the tile itself (chunks of 64 / 32 channels), row strides are free.
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL, int NTAP>
 __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     constexpr int PXB = CCH * 2 + 16;     // bytes per pixel and plane of the halo image: CCH bf16 + 16 B (an odd multiple of 16 B)
-    constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = 9 * NQ;
+    constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = NTAP * NQ;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
-    constexpr int HP = (TH + 2) * (TW + 2);                              // halo pixels
+    constexpr int HB = NTAP == 9 ? 1 : 0;                                // halo border
+    constexpr int HW = TW + 2 * HB;                                      // pixels per staged image row
+    constexpr int HP = (TH + 2 * HB) * HW;                               // staged pixels
     constexpr int PLANE = HP * PXB;                                      // bytes per bf16 plane
     constexpr int BSLAB = (BN / 32) * NPL * 1024;                        // bytes per weight slab
     constexpr int HALO_BYTES = NPL * PLANE;
@@ -156,11 +188,11 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         for (int f = 0; f < PER; ++f) {
             const int idx = tid + f * NT;
             const int px = idx / F4, c4 = idx % F4;
-            const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const int hy = px / HW, hx = px - hy * HW;
+            const int gy = y0 + hy - HB, gx = x0 + hx - HB;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.Kc + c * CCH + c4 * 4);
+                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.ldx + c * CCH + c4 * 4);
             hreg[f] = v;
         }
     };
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * 3 * 1024;
     const size_t slab_stride = (size_t)(p.Nc / 32) * 3 * 1024;
     auto issue_b = [&](int c, int st, unsigned char *dst) {
-        const int s = (c * NQ + st % NQ) * 9 + st / NQ;
+        const int s = (c * NQ + st % NQ) * NTAP + st / NQ;
         const unsigned char *src = wbase + (size_t)s * slab_stride;
         constexpr int PIECES = BSLAB / 1024;                             // 1 KB per wave instruction, dealt round-robin to the waves
 #pragma unroll
@@ -216,8 +248,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         if (c + 1 < c_end) halo_load(c + 1);                             // in flight under this chunk's MFMAs
         __syncthreads();
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - 3 * ky;
+        for (int tap = 0; tap < NTAP; ++tap) {
+            const int ky = NTAP == 9 ? tap / 3 : 0, kx = NTAP == 9 ? tap - 3 * ky : 0;
 #pragma unroll
             for (int q = 0; q < NQ; ++q, ++s) {
                 const unsigned char *cur = bbuf + (s & 1) * BSLAB;
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 uint4 af[TM][NPL], bfr[TN][NPL];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
+                    const int px = (wm * TM + i + ky) * HW + r + kx;
                     const unsigned char *a = halo + px * PXB + q * 32 + h * 16;
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
@@ -257,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
-    float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.Nc);      // (split == 0 unless the reduction is split)
+    float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.ldy);     // (split == 0 unless the reduction is split)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -271,10 +303,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
-                const size_t o = (pix0 + pass * 8 + er) * p.Nc + col;
+                const size_t o = (pix0 + pass * 8 + er) * p.ldy + col;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (p.mask) {
-                    const float4 mk = *reinterpret_cast<const float4 *>(p.mask + o);
+                    const float4 mk = *reinterpret_cast<const float4 *>(p.mask + (pix0 + pass * 8 + er) * p.ldm + col);
                     v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
                     v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                 }
@@ -475,19 +507,19 @@ int check_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
 }
 
 struct RowsPlan { bool tall; int bn, splits, chunks_per_split; long long tiles; };
-RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc) {
+RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9) {
     RowsPlan r{};
     r.bn = Nc % 128 == 0 ? 128 : (Nc % 64 == 0 ? 64 : 32);
     // 8-row tiles where they still give every CU its two workgroups twice over (512 x 512 planes: 1024 tiles); measured on
     // 64->128 / 128->64 / 64->32 at 512^2: 203 -> 185, 239 -> 194, 76 -> 72 us, and slower at 256^2 (256 tiles: one per CU)
     static const long long min_tiles8 = getenv("T2H_BX3_TILES8") ? atoll(getenv("T2H_BX3_TILES8")) : 1024;
     const long long tiles8 = H % 8 == 0 ? (long long)B * (H / 8) * (W / TW) * (Nc / r.bn) : 0;
-    r.tall = tiles8 >= min_tiles8;
+    r.tall = tiles8 >= min_tiles8 && !(ntap == 1 && r.bn == 128);        // (1-tap, 128 columns: the 8-row images would not fit twice per CU)
     r.tiles = r.tall ? tiles8 : (long long)B * (H / 4) * (W / TW) * (Nc / r.bn);
     // small planes with many channels: fewer tiles than the chip holds workgroups -> split the reduction over whole 32-channel
     // chunks into slabs (summed in a fixed order by reduce_rows_epilogue, which also applies the epilogue): deterministic
     r.splits = 1;
-    const int nchunk = Kc / (r.tall ? 16 : 32);
+    const int nchunk = ntap == 9 ? Kc / (r.tall ? 16 : 32) : Kc / (r.tall ? 32 : 64);      // (the 1-tap form stages 64 / 32 channels)
     static const long long target = getenv("T2H_BX3_ROWS_WGS") ? atoll(getenv("T2H_BX3_ROWS_WGS")) : 512;
     if (!r.tall && r.tiles < target / 2) {
         long long want = (target + r.tiles - 1) / r.tiles;
@@ -500,20 +532,20 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc) {
     return r;
 }
 
-#define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_)                                                                                  \
+#define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_, NTAP_)                                                                           \
     do {                                                                                                                    \
         if (single) {                                                                                                       \
-            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1>), dim3((unsigned)grid), dim3(NT), 0, s, a);     \
-            note_kernel("bf16_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                  \
+            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
+            note_kernel("bf16_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ "," #NTAP_ ">");                       \
         } else {                                                                                                            \
-            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3>), dim3((unsigned)grid), dim3(NT), 0, s, a);     \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ">");                                   \
+            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ "," #NTAP_ ">");                        \
         }                                                                                                                   \
     } while (0)
 
 // `a`: x, wf, bias, mask, y, geometry and epilogue flags; splits the reduction into `ws` when the plan says so
-int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what) {
-    const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc);
+int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9) {
+    const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc, ntap);
     const long long grid = r.tiles * r.splits;
     if (grid > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
     const long long M = (long long)a.B * a.H * a.W;
@@ -521,19 +553,31 @@ int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t 
     if (r.splits > 1) {
         const size_t need = (size_t)r.splits * M * a.Nc * sizeof(float);
         if (!ws || ws_bytes < need || !al16(ws)) return fail(T2H_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
-        e.C = a.y; e.bias = a.bias; e.mask = a.mask; e.M = (int)M; e.N = a.Nc; e.ldc = a.Nc; e.ldm = a.Nc;
+        e.C = a.y; e.bias = a.bias; e.mask = a.mask; e.M = (int)M; e.N = a.Nc; e.ldc = a.ldy; e.ldm = a.ldm;
         e.accum = a.flags & F_ACCUM; e.relu_out = a.flags & F_RELU_OUT;
-        a.y = static_cast<float *>(ws); a.bias = nullptr; a.mask = nullptr; a.flags = 0;
+        a.y = static_cast<float *>(ws); a.bias = nullptr; a.mask = nullptr; a.flags = 0; a.ldy = a.Nc;
     }
     a.splits = r.splits; a.chunks_per_split = r.chunks_per_split;
-    if (r.tall) {
-        if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16);
-        else if (r.bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16);
-        else BX3_LAUNCH(8, 32, 4, 1, 16);
+    if (ntap == 9) {
+        if (r.tall) {
+            if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16, 9);
+            else if (r.bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16, 9);
+            else BX3_LAUNCH(8, 32, 4, 1, 16, 9);
+        } else {
+            if (r.bn == 128) BX3_LAUNCH(4, 128, 2, 2, 32, 9);
+            else if (r.bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32, 9);
+            else BX3_LAUNCH(4, 32, 4, 1, 32, 9);
+        }
     } else {
-        if (r.bn == 128) BX3_LAUNCH(4, 128, 2, 2, 32);
-        else if (r.bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32);
-        else BX3_LAUNCH(4, 32, 4, 1, 32);
+        if (r.tall) {
+            if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 32, 1);
+            else if (r.bn == 64) BX3_LAUNCH(8, 64, 4, 1, 32, 1);
+            else BX3_LAUNCH(8, 32, 4, 1, 32, 1);
+        } else {
+            if (r.bn == 128) BX3_LAUNCH(4, 128, 2, 2, 64, 1);
+            else if (r.bn == 64) BX3_LAUNCH(4, 64, 4, 1, 64, 1);
+            else BX3_LAUNCH(4, 32, 4, 1, 64, 1);
+        }
     }
     if (int rc = check_launch(what)) return rc;
     if (r.splits > 1) return launch_reduce_rows_epilogue(static_cast<const float *>(ws), r.splits, M * a.Nc, M, a.Nc, e, s);
@@ -603,7 +647,7 @@ T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bia
     if (!al16(x) || !al16(wf) || !al16(y) || (bias && !al16(bias))) return fail(T2H_ERR_ARG, "conv3x3_bx3_fwd: pointers must be 16-byte aligned");
     RowsArgs a{};
     a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = nullptr; a.y = y;
-    a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout;
+    a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout; a.ldx = Cin; a.ldy = Cout; a.ldm = Cout;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
     return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
 }
@@ -615,7 +659,7 @@ T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, 
     if (!al16(dy) || !al16(wf_t) || !al16(dx) || (mask && !al16(mask))) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad: pointers must be 16-byte aligned");
     RowsArgs a{};
     a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
-    a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin;
+    a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = Cin;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
     return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
 }
@@ -655,4 +699,46 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     }
     if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s);
+}
+
+// ---- the 1-tap form as a GEMM on rows ---------------------------------------------------------------------------------------------
+T2H_API int t2h_gemm_bx3_supported(int64_t M, int K, int N) {
+    return M >= 128 && M % 128 == 0 && M <= (1LL << 30) && K >= 64 && K % 64 == 0 && N >= 32 && N % 32 == 0;
+}
+
+T2H_API size_t t2h_gemm_bx3_weights_bytes(int K, int N) {
+    if (K < 16 || N < 32 || K % 16 || N % 32) return 0;
+    return (size_t)K * N * 6;
+}
+
+T2H_API int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, void *wf, t2h_stream_t stream) {
+    if (!w || !wf) return fail(T2H_ERR_ARG, "gemm_bx3_prepare: null pointer");
+    if (K < 16 || N < 32 || K % 16 || N % 32 || !al16(wf) || ldw < (w_is_kn ? N : K))
+        return fail(T2H_ERR_ARG, "gemm_bx3_prepare: K=%d must be a multiple of 16, N=%d of 32, ldw=%d at least the row length", K, N, ldw);
+    const long long total = (long long)(K / 16) * (N / 32) * 64;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (w_is_kn) hipLaunchKernelGGL(bx3_prepare_gemm_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), w, K, N, ldw, static_cast<unsigned *>(wf));
+    else hipLaunchKernelGGL(bx3_prepare_gemm_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), w, K, N, ldw, static_cast<unsigned *>(wf));
+    return check_launch("gemm_bx3_prepare");
+}
+
+T2H_API size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N) {
+    if (!t2h_gemm_bx3_supported(M, K, N)) return 0;
+    const RowsPlan r = bx3_rows_plan(1, (int)(M / 32), 32, K, N, 1);
+    return r.splits > 1 ? (size_t)r.splits * M * N * sizeof(float) : 0;
+}
+
+T2H_API int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
+                         int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!x || !wf || !y) return fail(T2H_ERR_ARG, "gemm_bx3: null pointer");
+    if (!t2h_gemm_bx3_supported(M, K, N))
+        return fail(T2H_ERR_ARG, "gemm_bx3: needs M %% 128 == 0, K %% 64 == 0, N %% 32 == 0 (M=%lld K=%d N=%d)", (long long)M, K, N);
+    if (ldx < K || ldy < N || ldx % 4 || ldy % 4 || (mask && (ldm < N || ldm % 4)) || !al16(x) || !al16(wf) || !al16(y) || (bias && !al16(bias)) ||
+        (mask && !al16(mask)))
+        return fail(T2H_ERR_ARG, "gemm_bx3: rows must be 16-byte aligned and at least K / N floats long");
+    RowsArgs a{};
+    a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = mask; a.y = y;
+    a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = K; a.Nc = N; a.ldx = ldx; a.ldy = ldy; a.ldm = ldm;
+    a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
+    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "gemm_bx3", 1);
 }

@@ -207,7 +207,7 @@ class _DeferredLevel(torch.autograd.Function):
             raise RuntimeError(f"deferred level {idx}: {a_all.shape[0]} composed rows for {k} source columns")
         x = state.S[lv][:, :k]
         acc = torch.empty(x.shape[0], a_all.shape[1], dtype=torch.float32, device=x.device)
-        mlp.linear_dgrad_(x, a_all, acc)                                   # "dx = dy w" is exactly x @ A
+        mlp.linear_dgrad_(x, a_all, acc, bx3=True)                         # "dx = dy w" is exactly x @ A
         cnt = counts(tile, lv)
         out = torch.empty_like(acc)
         _lib.call("t2h_mean_bias_fwd", _lib.ptr(acc), _lib.ptr(cnt), _lib.ptr(const), acc.shape[0], acc.shape[1], _lib.ptr(out),
@@ -260,7 +260,7 @@ class _DeferredLevel(torch.autograd.Function):
         dS, seen = state.grad_matrix(lv)
         if seen and seen < k:
             raise RuntimeError("deferred backward out of order")
-        mlp.linear_fwd_(dacc, a_all, None, dS[:, :k], accumulate=bool(seen))   # dacc @ A^T
+        mlp.linear_fwd_(dacc, a_all, None, dS[:, :k], accumulate=bool(seen), bx3=True)   # dacc @ A^T
         state.dS_cols[lv] = max(seen, k)
         # this level's own source: every level that used its sums has contributed by now
         lo, hi = state.off[idx + 1], state.off[idx + 2]

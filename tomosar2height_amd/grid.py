@@ -158,13 +158,37 @@ class SplitWeightCache:
         _lib.call("t2h_conv3x3_bx3_prepare", _lib.ptr(w), cin, cout, 1 if transposed else 0, _lib.ptr(buf), _lib.stream(),
                   nbytes=10 * w.numel())
 
+    def get_gemm(self, w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
+        """The same for a plain weight matrix of the 1-tap (GEMM) form: ``w`` [N, K] (nn.Linear) or, ``w_is_kn``, [K, N]."""
+        import weakref
+        key = (id(w), "kn" if w_is_kn else "nk")
+        e = self.entries.get(key)
+        k, n = (w.shape[0], w.shape[1]) if w_is_kn else (w.shape[1], w.shape[0])
+        if e is None or e[0]() is not w:
+            buf = torch.empty(int(_lib.load().t2h_gemm_bx3_weights_bytes(k, n)), dtype=torch.uint8, device=w.device)
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
+        if e[1] != w._version or e[2] != w.data_ptr():
+            self._prepare_gemm(w, w_is_kn, e[3])
+            e[1], e[2] = w._version, w.data_ptr()
+        return e[3]
+
+    @staticmethod
+    def _prepare_gemm(w, w_is_kn, buf):
+        k, n = (w.shape[0], w.shape[1]) if w_is_kn else (w.shape[1], w.shape[0])
+        _lib.call("t2h_gemm_bx3_prepare", _lib.ptr(w), w.stride(0), k, n, 1 if w_is_kn else 0, _lib.ptr(buf), _lib.stream(),
+                  nbytes=10 * w.numel())
+
     def refresh(self):
         """Re-split every live weight into its existing buffer."""
-        for (_, transposed), e in list(self.entries.items()):
+        for (_, kind), e in list(self.entries.items()):
             w = e[0]()
-            if w is not None:
-                self._prepare(w, transposed, e[3])
-                e[1], e[2] = w._version, w.data_ptr()
+            if w is None:
+                continue
+            if kind in ("kn", "nk"):
+                self._prepare_gemm(w, kind == "kn", e[3])
+            else:
+                self._prepare(w, kind, e[3])
+            e[1], e[2] = w._version, w.data_ptr()
 
 
 split_weights = SplitWeightCache()

@@ -59,11 +59,39 @@ def _rows(t: torch.Tensor, what: str):
     return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
 
-def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
-    """y = [y +] act_out(act_in(x) w^T + bias), written in place into ``y`` (may be a column slice)."""
+# Grid-side products of the deferred point update (deferred.py) on the bf16 matrix cores with the exact 3-way split
+# (csrc/conv_bx3.hip, 1-tap form; fp32-grade like the convolutions): T2H_GEMM_BX3=0 keeps them on the fp32 MFMA kernels (A/B)
+GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
+
+
+def _bx3_gemm_ok(m, k, n, *rows) -> bool:
+    return (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
+            and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows))
+
+
+def _gemm_bx3(x, w, w_is_kn, bias, mask, y, relu_out, accumulate, tag):
+    from . import grid
+    (xp, ldx), (yp, ldy) = _rows(x, "gemm_bx3 x"), _rows(y, "gemm_bx3 y")
+    m, k = x.shape
+    n = y.shape[1]
+    mp, ldm = (None, 0) if mask is None else _rows(mask, "gemm_bx3 mask")
+    nws = _lib.ws_bytes("t2h_gemm_bx3_workspace_bytes", m, k, n)
+    ws = _lib.workspace(nws, x.device)
+    flags = (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0)
+    _lib.call("t2h_gemm_bx3", xp, ldx, _lib.ptr(grid.split_weights.get_gemm(w, w_is_kn)), bias.data_ptr() if bias is not None else None,
+              mp, ldm, yp, ldy, m, k, n, flags, _lib.ptr(ws), nws, _lib.stream(),
+              nbytes=4 * (m * k + m * n + n * k + (m * n if mask is not None else 0)), flops=2 * m * k * n, tag=_lib.timing() and tag)
+    return y
+
+
+def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False, bx3=False):
+    """y = [y +] act_out(act_in(x) w^T + bias), written in place into ``y`` (may be a column slice).  ``bx3``: the caller's
+    product is a grid-side one with a weight that lives across calls (split once): take the split-bf16 matrix-core kernel."""
     (xp, ldx), (yp, ldy) = _rows(x, "linear_fwd x"), _rows(y, "linear_fwd y")
     m, k = x.shape
     n = w.shape[0]
+    if bx3 and not relu_in and w.is_contiguous() and _bx3_gemm_ok(m, k, n, x, y):
+        return _gemm_bx3(x, w, False, bias, None, y, relu_out, accumulate, f"t2h_linear_fwd[K={k},N={n}]")
     w = w.contiguous()
     flags = (_lib.RELU_IN if relu_in else 0) | (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
     _lib.call("t2h_linear_fwd", xp, ldx, w.data_ptr(), bias.data_ptr() if bias is not None else None, yp, ldy, m, k, n,
@@ -72,11 +100,13 @@ def linear_fwd_(x, w, bias, y, relu_in=False, relu_out=False, accumulate=False):
     return y
 
 
-def linear_dgrad_(dy, w, dx, mask=None, accumulate=False):
-    """dx = [dx +] (dy w) * (mask > 0), in place into ``dx``."""
+def linear_dgrad_(dy, w, dx, mask=None, accumulate=False, bx3=False):
+    """dx = [dx +] (dy w) * (mask > 0), in place into ``dx``.  ``bx3``: see ``linear_fwd_``."""
     (gp, ldg), (dp, ldd) = _rows(dy, "linear_dgrad dy"), _rows(dx, "linear_dgrad dx")
     m, n = dy.shape
     k = w.shape[1]
+    if bx3 and w.is_contiguous() and _bx3_gemm_ok(m, n, k, dy, dx, mask):
+        return _gemm_bx3(dy, w, True, None, mask, dx, False, accumulate, f"t2h_linear_dgrad[N={n},K={k}]")
     w = w.contiguous()
     mp, ldm = (None, 0) if mask is None else _rows(mask, "linear_dgrad mask")
     _lib.call("t2h_linear_dgrad", gp, ldg, w.data_ptr(), dp, ldd, m, k, n, mp, ldm,

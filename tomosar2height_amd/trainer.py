@@ -317,6 +317,11 @@ class Trainer:
             # included, bumps the parameters' version counters, which ComposeCache.get compares -- but a replayed hipGraph
             # runs no Python per tile.)
             self.compose_cache.refresh()
+        if self._graph is not None:
+            # a replayed hipGraph runs no Python per tile: the split (bf16 x 3) copies of the convolution weights and of the
+            # composed maps are refreshed here, in place (eagerly they follow the tensors' version counters by themselves)
+            from . import grid
+            grid.split_weights.refresh()
         if self.scheduler is not None:
             self.scheduler.step()                                         # train.py:188-190: once per iteration
         with torch.no_grad():
