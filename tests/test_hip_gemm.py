@@ -202,7 +202,7 @@ def test_full_size_linear_kernels_satisfy_the_bilinear_identities(k, n):
 # ---- the 1-tap form of the split-bf16 matrix-core kernels as a GEMM on rows (csrc/conv_bx3.hip, t2h_gemm_bx3) -------------------
 @pytest.mark.parametrize("m,k,n", [(65536, 320, 64), (16384, 832, 128), (1024, 1856, 512), (4096, 64, 832), (128, 64, 32),
                                    (16384, 128, 2624)])
-def test_gemm_bx3_rows_vs_float64(m, k, n):
+def test_gemm_bx3_rows_vs_float64(m, k, n, monkeypatch):
     """The grid-side products of the deferred point update (deferred.py): y = x W^T and y = x W (k-major weight) on column SLICES
     of wider matrices, with mask / accumulate, and a few-row case whose reduction is split into slabs -- against float64 at the
     tolerance of the fp32 MFMA GEMMs (2e-5 of the max-norm)."""
@@ -215,7 +215,8 @@ def test_gemm_bx3_rows_vs_float64(m, k, n):
     w_kn = w_nk.t().contiguous()
     want = x.double().cpu() @ w_nk.double().cpu().t()
     scale = want.abs().max().item()
-    assert mlp._bx3_gemm_ok(m, k, n, x)
+    assert mlp._bx3_gemm_ok(m, k, n, x, force=True)
+    monkeypatch.setattr(mlp, "_bx3_gemm_ok", lambda *a, **kw: True)      # every shape through the split form here
 
     out_wide = torch.zeros(m, n + 32, device=dev)
     y = out_wide[:, 16:16 + n]

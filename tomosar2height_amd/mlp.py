@@ -64,9 +64,15 @@ def _rows(t: torch.Tensor, what: str):
 GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
 
 
-def _bx3_gemm_ok(m, k, n, *rows) -> bool:
-    return (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
-            and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows))
+def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
+    """Where the split-bf16 form wins (measured, profiles/r04g_*): every staged A element has to be split (~6 VALU lane-operations)
+    and is then used for n outputs, so narrow outputs (the r = 256 level product: 2752 -> 64, 250 us on fp32 MFMA, 278 us split) and
+    one-chunk reductions (64 -> 2752) stay on the fp32 kernels; from 128 outputs / 128-deep reductions / 4096 rows up the split form
+    is 7-22 % faster (2368 -> 256 at 64^2: 72 -> 56 us)."""
+    if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
+            and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
+        return False
+    return force or (n >= 128 and k >= 128 and m >= 4096)
 
 
 def _gemm_bx3(x, w, w_is_kn, bias, mask, y, relu_out, accumulate, tag):
