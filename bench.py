@@ -132,6 +132,28 @@ def pmc_traffic():
         return {}, None
 
 
+def rocprof_durations():
+    """Per-kernel-symbol durations of a `rocprofv3 --kernel-trace` run of THIS command (steady state, last 6 tile-steps), committed
+    by profiles/run_profiles.sh as profiles/rocprof_kernels.json.  NOT measured in this run: HIP-event pairs around single launches
+    over-read short and MFMA-dense kernels by 2-18 % (non-uniformly), so the line carries the profiler's figure beside its own."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "rocprof_kernels.json")) as f:
+            d = json.load(f)
+        return {k: v["avg_us"] for k, v in d.get("kernels", {}).items()}, f"profiles/rocprof_kernels.json (tag {d.get('tag', '?')})"
+    except (OSError, ValueError, KeyError):
+        return {}, None
+
+
+def bx3_peak(symbol: str):
+    """Matrix-core ceiling of a csrc/conv_bx3.hip kernel in ALGORITHMIC flops: dense bf16 peak / 6 with the exact split (NPL = 3),
+    the bf16 peak itself in the bf16 mode (NPL = 1); None for any other symbol."""
+    if not symbol.startswith("bx3_"):
+        return None
+    args = symbol[symbol.find("<") + 1:symbol.rfind(">")].split(",")
+    npl = args[5] if symbol.startswith("bx3_rows") and len(args) > 5 else (args[1] if len(args) > 1 else "3")
+    return MFMA_BF16_PEAK_TFLOPS if npl.strip() == "1" else MFMA_BX3_PEAK_TFLOPS
+
+
 def point_update_note():
     """Which association of the ALTO point update runs (same function as alto.py:121-130, see mlp.py / deferred.py)."""
     from tomosar2height_amd import deferred, mlp
@@ -270,7 +292,7 @@ def infer_bench(args, world, rank, dev, group):
 def kernel_tables(timeline, n_steps):
     """(per-tag rows, per-symbol rows) from a KernelTimeline over ``n_steps`` tile-steps, both sorted by time."""
     def row(name, d):
-        peak_tf = MFMA_BX3_PEAK_TFLOPS if str(d.get("symbol", name)).startswith("bx3_") else MFMA_F32_PEAK_TFLOPS
+        peak_tf = bx3_peak(str(d.get("symbol", name))) or MFMA_F32_PEAK_TFLOPS
         avg_us = 1e3 * d["ms"] / d["calls"]
         per_b, per_f = d["bytes"] / d["calls"], d["flops"] / d["calls"]
         gbs = per_b / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
@@ -653,6 +675,15 @@ def main():
             named = {k["kernel"]: k for k in tags}
             if syms:
                 out["roofline"] = roof(syms[0], traffic.get(syms[0]["kernel"]))       # the kernel symbol with the largest time share
+                prof_us, prof_src = rocprof_durations()
+                if syms[0]["kernel"] in prof_us and args.points == 131072 and args.train_batch == 1 and not args.use_image:
+                    # the profiler's duration of the same symbol (committed trace of the same command): `frac` stays on the
+                    # conservative HIP-event figure, `frac_rocprof` is what rocprofv3 --stats readers will recompute
+                    us = prof_us[syms[0]["kernel"]]
+                    per = syms[0]["flops_per_launch"] / 1e12 if syms[0]["bound"] == "mfma" else syms[0]["bytes_per_launch"] / 1e9
+                    out["roofline"]["avg_us_rocprof"] = us
+                    out["roofline"]["frac_rocprof"] = round(per / (us * 1e-6) / out["roofline"]["peak"], 4)
+                    out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
                 out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps; "

@@ -22,43 +22,30 @@ import glob
 import json
 import os
 import re
+import sys
 
-REPS = 3        # profiles/pmc_probe.py launches every group this many times in a row
-# the probe's launches in order: groups of (bench.py tag, kernel-name substrings of one launch of the op); ops that share a
-# kernel symbol (the pixel gather of both sample adjoints) are told apart by their position in the dispatch sequence
-PROBE_GROUPS = [
-    [("t2h_segmean_fwd[C=512,r=32]", ["segmean_cells_kernel", "segmean_finalize_kernel"])],
-    [("t2h_sample_fwd[C=512,r=32]", ["sample_fwd_kernel"]),
-     ("t2h_sample_bwd[C=512,r=32]", ["sample_bwd_cells_", "sample_bwd_gather9_kernel"])],
-    # r03, deferred point update: per-cell sums of the widest hidden activations at the finest resolution
-    [("t2h_segsum_fwd[C=1024,r=256]", ["segmean_fwd_kernel<4, false>"])],
-    [("t2h_segsum_bwd_multi[C=1024,n=4]", ["segsum_bwd_multi_kernel"])],
-    # r03, hidden activations on chip: sample + ReLU + per-cell sums + sign bits; the backward walk + its pixel gather
-    [("t2h_sample_relu_cellsums[C=1024,r=32]", ["sample_relu_cellsums_kernel"])],
-    [("t2h_sample_bwd_from_sums[C=1024,r=32]", ["sample_bwd_walk_kernel", "sample_bwd_gather9_kernel"])],
-]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from probe_manifest import PROBE_GROUPS, REPS            # noqa: E402  (shared with profiles/pmc_probe.py: one definition)
 
 
 def probe_sequence(rows):
-    """Walk the probe's dispatches in order -> {tag: [mean counter value per part]} (None where the sequence does not match)."""
-    out, i = {}, 0
-    for group in PROBE_GROUPS:
-        acc = {tag: [0.0] * len(parts) for tag, parts in group}
-        ok = True
-        for _ in range(REPS):
-            for tag, parts in group:
-                for j, sub in enumerate(parts):
-                    while i < len(rows) and sub not in rows[i]["Kernel_Name"]:
-                        i += 1
-                    if i >= len(rows):
-                        ok = False
-                        break
-                    acc[tag][j] += float(rows[i]["Counter_Value"]) / REPS
-                    i += 1
-        for tag, _ in group:
-            out[tag] = acc[tag] if ok else None
-        if not ok:
-            break
+    """The probe's dispatches in order -> {tag: [mean counter value per part]}.  STRICT: the dispatches that belong to the probe's
+    ops (any kernel-name substring of the manifest) must be exactly the manifest's sequence, REPS times per group -- a reordered
+    or added launch in pmc_probe.py, or a kernel-selection change in the library, fails here instead of attributing counters to
+    the wrong tag."""
+    subs = sorted({sub for group in PROBE_GROUPS for _, parts in group for sub in parts}, key=len, reverse=True)
+    mine = [r for r in rows if any(sub in r["Kernel_Name"] for sub in subs)]
+    expected = [(tag, j, sub) for group in PROBE_GROUPS for _ in range(REPS) for tag, parts in group for j, sub in enumerate(parts)]
+    if len(mine) != len(expected):
+        raise SystemExit(f"collect_pmc: the probe issued {len(mine)} dispatches of the manifest's kernels, the manifest "
+                         f"(profiles/probe_manifest.py) expects {len(expected)}: update the manifest with the probe")
+    out = {tag: [0.0] * len(parts) for group in PROBE_GROUPS for tag, parts in group}
+    for r, (tag, j, sub) in zip(mine, expected):
+        if sub not in r["Kernel_Name"]:
+            raise SystemExit(f"collect_pmc: dispatch {r['Dispatch_Id']} is {r['Kernel_Name'][:80]!r}, the manifest expects "
+                             f"{sub!r} for {tag}: launch order and manifest disagree")
+        out[tag][j] += float(r["Counter_Value"]) / REPS
     return out
 
 

@@ -96,7 +96,10 @@ struct ConvArgs {
 
 constexpr int TW = 32;
 
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CC>
+// ORD: 0 = fragments loaded tile-major, smallest terms first, all reads before the first MFMA (the first shipped form);
+//      1 = fragments loaded PLANE-major and the products largest first (a1b1 needs only the first TM + TN reads), reads still fenced;
+//      2 = as 1 without the fence (the compiler may sink reads between the MFMAs)
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CC, int ORD = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(ConvArgs p) {
     constexpr int PXB = CC * 2 + 16;              // bytes per pixel and plane in the halo image: CC bf16 + 16 B pad (odd multiple of 16 B)
     constexpr int NQ = CC / 16, F4 = CC / 4;
@@ -194,35 +197,197 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(ConvArgs p) {
                 const unsigned char *cur = bbuf + (s & 1) * BSLAB;
                 if (!(c == nchunk - 1 && tap == 8 && q == NQ - 1)) issue_b(s + 1, bbuf + ((s + 1) & 1) * BSLAB);
                 uint4 af[TM][3], bf[TN][3];
+                if (ORD == 0) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
-                    const unsigned char *a = halo + px * PXB + q * 32 + h * 16;
+                    for (int i = 0; i < TM; ++i) {
+                        const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
+                        const unsigned char *a = halo + px * PXB + q * 32 + h * 16;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
+                        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            bf[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * 3 + pl) * 1024 + lane * 16);
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
+                            af[i][pl] = *reinterpret_cast<const uint4 *>(halo + px * PXB + q * 32 + h * 16 + pl * PLANE);
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            bf[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * 3 + pl) * 1024 + lane * 16);
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        bf[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * 3 + pl) * 1024 + lane * 16);
-                __builtin_amdgcn_sched_barrier(0);
-                // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
-                constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+                if (ORD != 2) __builtin_amdgcn_sched_barrier(0);
+                // ORD 0: smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1; else largest first: a1b1, a1b2, a2b1, a2b2, a1b3, a3b1
+                constexpr int ia0[6] = {2, 0, 1, 1, 0, 0}, ib0[6] = {0, 2, 1, 0, 1, 0};
+                constexpr int ia1[6] = {0, 0, 1, 1, 0, 2}, ib1[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
                 for (int e = 0; e < 6; ++e)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ia[e]]),
-                                                                                 *reinterpret_cast<bf16x8 *>(&bf[j][ib[e]]), acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ORD ? ia1[e] : ia0[e]]),
+                                                                                 *reinterpret_cast<bf16x8 *>(&bf[j][ORD ? ib1[e] : ib0[e]]), acc[i][j], 0, 0, 0);
                 __syncthreads();                                         // (drains the next slab's DMA: vmcnt(0))
             }
         }
     }
 
     // epilogue: per 32 x 32 tile through a private LDS patch -> float4 rows along the output channels
+    float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + ec;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + col);
+            const size_t pix0 = ((size_t)b * p.H + y0 + wm * TM + i) * p.W + x0;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4 *>(p.y + (pix0 + pass * 8 + er) * p.Cout + col) = v;
+            }
+        }
+}
+
+
+// ---- "wide" variant: ONE 512-thread workgroup per CU (8 waves as 4 x 2, 8 image rows x 32 columns x 128 channels), 32 reduction
+// channels per staged chunk AND per barrier (both 16-channel halves of a tap in one step: 48 MFMAs per wave between barriers instead
+// of 24, weight slabs of 24 KB).  LDS: halo 81.6 KB + 2 x 24 KB.  The two waves of a SIMD belong to the same barrier domain.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16x3_wide_kernel(ConvArgs p) {
+    constexpr int TH = 8, WAVES_M = 4, WAVES_N = 2, CC = 32, NTH = 512, NWV = 8;
+    constexpr int PXB = CC * 2 + 16, F4 = CC / 4;
+    constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
+    constexpr int HP = (TH + 2) * (TW + 2);
+    constexpr int PLANE = HP * PXB;
+    constexpr int BSLAB = 2 * (BN / 32) * 3 * 1024;                      // both halves of a tap
+    constexpr int HALO_BYTES = 3 * PLANE;
+    constexpr int LDS_BYTES = HALO_BYTES + 2 * BSLAB;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char *halo = lds, *bbuf = lds + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned qq = nb / 8, rr = nb % 8, xx = bid % 8, i8 = bid / 8;
+    unsigned t = (xx < rr ? xx * (qq + 1) : rr * (qq + 1) + (xx - rr) * qq) + i8;
+    const int ntn = p.Cout / BN;
+    const int tn = t % ntn; t /= ntn;
+    const int tiles_x = p.W / TW;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int tiles_y = p.H / TH;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH, n0 = tn * BN;
+    const int nchunk = p.Cin / CC;
+    constexpr int NF4 = HP * F4, PER = (NF4 + NTH - 1) / NTH;
+    float4 hreg[PER];
+    auto halo_load = [&](int c) {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            const int idx = tid + f * NTH;
+            const int px = idx / F4, c4 = idx % F4;
+            const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.Cin + c * CC + c4 * 4);
+            hreg[f] = v;
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int f = 0; f < PER; ++f) {
+            const int idx = tid + f * NTH;
+            if (idx < NF4) {
+                const int px = idx / F4, c4 = idx % F4;
+                unsigned a1, a2, a3, b1, b2, b3;
+                split3(hreg[f].x, hreg[f].y, a1, a2, a3);
+                split3(hreg[f].z, hreg[f].w, b1, b2, b3);
+                unsigned char *d = halo + px * PXB + c4 * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a3, b3);
+            }
+        }
+    };
+    // weights in the lab's CC = 32 order: slab s = (c * 9 + tap) * 2 + q; a step = the two consecutive slabs of a tap
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf);
+    const size_t slab_stride = (size_t)(p.Cout / 32) * 3 * 1024;
+    auto issue_b = [&](int step, unsigned char *dst) {
+        constexpr int HALF = (BN / 32) * 3;                              // 1 KB pieces per half
+#pragma unroll
+        for (int j = 0; j < (2 * HALF + NWV - 1) / NWV; ++j) {
+            const int piece = j * NWV + wave;
+            if (piece < 2 * HALF) {
+                const int q = piece / HALF, pp = piece - q * HALF;
+                const unsigned char *src = wbase + (size_t)(2 * step + q) * slab_stride + (size_t)(n0 / 32) * 3 * 1024 + pp * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(dst + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
+    const int r = lane & 31, h = lane >> 5;
+    halo_load(0);
+    int s = 0;
+    const int nstep = nchunk * 9;
+    for (int c = 0; c < nchunk; ++c) {
+        halo_store();
+        if (c == 0) issue_b(0, bbuf);
+        if (c + 1 < nchunk) halo_load(c + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const unsigned char *cur = bbuf + (s & 1) * BSLAB;
+            if (s + 1 < nstep) issue_b(s + 1, bbuf + ((s + 1) & 1) * BSLAB);
+            uint4 af[2][TM][3], bf[2][TN][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int px = (wm * TM + i + ky) * (TW + 2) + r + kx;
+                        af[q][i][pl] = *reinterpret_cast<const uint4 *>(halo + px * PXB + q * 32 + h * 16 + pl * PLANE);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[q][j][pl] = *reinterpret_cast<const uint4 *>(cur + ((q * (BN / 32) + wn * TN + j) * 3 + pl) * 1024 + lane * 16);
+                }
+            }
+            constexpr int ia1[6] = {0, 0, 1, 1, 0, 2}, ib1[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[q][i][ia1[e]]),
+                                                                                 *reinterpret_cast<bf16x8 *>(&bf[q][j][ib1[e]]), acc[i][j], 0, 0, 0);
+            __syncthreads();
+        }
+    }
     float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
@@ -280,12 +445,17 @@ int main(int argc, char **argv) {
     ConvArgs a{dx, dwf, db, dy16, H, W, Cin, Cout, 1};
     const int BN = Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
     struct Variant { const char *name; int th, cc; void (*launch)(ConvArgs, int, hipStream_t); };
-#define V(TH_, BN_, WM_, WN_, CC_) Variant{"TH=" #TH_ " BN=" #BN_ " waves " #WM_ "x" #WN_ " CC=" #CC_, TH_, CC_, \
-    [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_kernel<TH_, BN_, WM_, WN_, CC_>), dim3(grid), dim3(256), 0, s_, q); }}
+#define V(TH_, BN_, WM_, WN_, CC_) VO(TH_, BN_, WM_, WN_, CC_, 0)
+#define VO(TH_, BN_, WM_, WN_, CC_, ORD_) Variant{"TH=" #TH_ " BN=" #BN_ " waves " #WM_ "x" #WN_ " CC=" #CC_ " ORD=" #ORD_, TH_, CC_, \
+    [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_kernel<TH_, BN_, WM_, WN_, CC_, ORD_>), dim3(grid), dim3(256), 0, s_, q); }}
     std::vector<Variant> vars;
-    if (BN == 128) vars = {V(4, 128, 2, 2, 32), V(8, 128, 2, 2, 16), V(4, 128, 2, 2, 16)};
-    else if (BN == 64) vars = {V(4, 64, 2, 2, 32), V(8, 64, 4, 1, 16), V(4, 64, 4, 1, 32), V(8, 64, 2, 2, 16)};
-    else vars = {V(4, 32, 4, 1, 32), V(8, 32, 4, 1, 16), V(8, 32, 4, 1, 32)};
+    Variant wide128{"WIDE 512 threads TH=8 BN=128 CC=32 (48 MFMAs / barrier)", 8, 32,
+        [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_wide_kernel<128>), dim3(grid), dim3(512), 0, s_, q); }};
+    Variant wide64{"WIDE 512 threads TH=8 BN=64 CC=32", 8, 32,
+        [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_wide_kernel<64>), dim3(grid), dim3(512), 0, s_, q); }};
+    if (BN == 128) vars = {wide128, V(4, 128, 2, 2, 32), VO(4, 128, 2, 2, 32, 1), VO(4, 128, 2, 2, 32, 2), V(8, 128, 2, 2, 16), VO(8, 128, 2, 2, 16, 1), VO(8, 128, 2, 2, 16, 2)};
+    else if (BN == 64) vars = {wide64, V(4, 64, 4, 1, 32), VO(4, 64, 4, 1, 32, 1), VO(4, 64, 4, 1, 32, 2), V(8, 64, 4, 1, 16), VO(8, 64, 4, 1, 16, 1), VO(8, 64, 4, 1, 16, 2)};
+    else vars = {V(4, 32, 4, 1, 32), VO(4, 32, 4, 1, 32, 1), VO(4, 32, 4, 1, 32, 2), V(8, 32, 4, 1, 16), VO(8, 32, 4, 1, 16, 1)};
     int cur_cc = 0;
     auto prep = [&]() {
         const long long total = (long long)(Cin / 16) * 9 * (Cout / 32) * 64;

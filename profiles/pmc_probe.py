@@ -16,7 +16,8 @@ from tomosar2height_amd import ops                           # noqa: E402
 from tomosar2height_amd.synthetic import berlin_tile          # noqa: E402
 from tomosar2height_amd.tile import TileIndex                 # noqa: E402
 
-REPS = 3
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from probe_manifest import REPS                          # noqa: E402
 dev = torch.device("cuda:0")
 tile = TileIndex(berlin_tile(0)["inputs"].to(dev), 256)
 M = tile.n_points

@@ -10,6 +10,26 @@ the last `--steps` tiles are summarised.
 import argparse
 import collections
 import csv
+import json
+import re
+
+
+def short_symbol(k: str) -> str:
+    """A rocprofv3 kernel name as bench.py's kernel tables spell the symbol (t2h_last_kernel_name): no return type, namespaces,
+    argument list or blanks -- 'void t2h::(anonymous namespace)::bx3_rows_kernel<4, 128, 2, 2, 32, 3, 9>(t2h::...)' ->
+    'bx3_rows_kernel<4,128,2,2,32,3,9>'."""
+    k = re.sub(r"^void ", "", k)
+    depth, out = 0, []
+    for ch in k:                      # cut at the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and out and "".join(out).rstrip().endswith(("kernel", ">")):
+            break
+        out.append(ch)
+    k = "".join(out).replace("(anonymous namespace)::", "").replace("t2h::", "").replace(" ", "")
+    return k
 
 
 def category(k):
@@ -29,6 +49,8 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--json", default="", help="also write {tag, steps, kernels: {symbol: {avg_us, launches_per_step}}} here")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
     rows = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "tile_keys_kernel" in r["Kernel_Name"]]
@@ -51,6 +73,18 @@ def main():
     print(f"{'kernel':<100s} {'launches/step':>13s} {'avg us':>10s} {'ms/step':>9s}")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.top]:
         print(f"{k[:100]:<100s} {c / a.steps:13.1f} {t / c:10.1f} {t / 1e3 / a.steps:9.3f}")
+    if a.json:
+        kernels = {}
+        for k, (c, t) in agg.items():
+            e = kernels.setdefault(short_symbol(k), {"us": 0.0, "launches": 0})
+            e["us"] += t
+            e["launches"] += c
+        out = {"tag": a.tag, "steps": a.steps, "wall_ms_per_step": round(wall, 3), "busy_ms_per_step": round(busy, 3),
+               "launches_per_step": round(len(sel) / a.steps, 1),
+               "kernels": {k: {"avg_us": round(v["us"] / v["launches"], 2), "launches_per_step": round(v["launches"] / a.steps, 2)}
+                           for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["us"])}}
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":
