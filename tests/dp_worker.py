@@ -48,10 +48,15 @@ def _step(model, dev, tiles, group, every):
     grabbed = {}
     tr = Trainer(model, torch.optim.AdamW(model.parameters(), lr=1e-3), device=dev, optimize_every=every, use_cloud=True,
                  process_group=group)
-    tr.on_reduced = lambda flat: grabbed.__setitem__("g", flat.clone())
+    def grab(flat):
+        grabbed["g"] = flat.clone()
+        # the same gradient in PARAMETER order (zeros for the parameters that never receive one): lines up with `params` below
+        grabbed["gp"] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in model.parameters()])
+    tr.on_reduced = grab
     stepped = [tr.train_step(t) for t in tiles]
     assert stepped[-1] is True and not any(stepped[:-1]), stepped
     params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    tr.grad_in_param_order = grabbed["gp"]
     return grabbed["g"], params, float(tr.last_avg_loss), tr
 
 
@@ -83,6 +88,13 @@ def run_dp(out_path):
     res = {"rank": rank, "world": world, "identical_replicas": identical,
            "grad_max_rel": float(((g_dp - g_1).abs().max() / g_1.abs().max()).item()),
            "param_max_abs": float((p_dp - p_1).abs().max().item()),
+           # AdamW's first step moves a weight by lr * g / (|g| + eps): where |g| is within the re-association noise of the two
+           # summation orders the step is noise too (up to 2 lr apart).  Where the gradient stands clear of that noise (1000 x)
+           # the two runs must agree tightly:
+           "param_max_abs_significant": float(((p_dp - p_1).abs() * (tr1.grad_in_param_order.abs() >
+                                                1e3 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max())).max().item()),
+           "significant_fraction": float((tr1.grad_in_param_order.abs() >
+                                          1e3 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max()).float().mean().item()),
            "loss_dp": loss_dp, "loss_single": loss_1, "none_grad": none_grad, "live": live,
            "bucket": int(tr.bucket.flat.numel()), "bucket_single": int(tr1.bucket.flat.numel()),
            "bucket_views_aligned": all(p.grad.data_ptr() % 16 == 0 for p in model.parameters() if p.grad is not None)}

@@ -38,10 +38,13 @@ def test_two_ranks_hip_model_equals_single_process(tmp_path):
     assert res["world"] == 2 and res["identical_replicas"]
     # 2 + 2 tiles summed per rank then across ranks vs 4 tiles summed in order: fp32 re-association only
     assert res["grad_max_rel"] <= 2e-5, res
-    # AdamW, lr 1e-3: its first step moves every weight by lr * g / (|g| + eps), so where a gradient element is ~1e-7 of the
-    # largest the re-association noise above (the composed maps' gradients are back-propagated on per-rank sums, then reduced)
-    # is amplified to a fraction of lr; a lost rank contribution would move weights by ~1e-3 everywhere
-    assert res["param_max_abs"] <= 2e-4, res
+    # AdamW, lr 1e-3: its first step moves every weight by lr * g / (|g| + eps), so where a gradient element lies within the
+    # re-association noise above (the composed maps' gradients are back-propagated on per-rank sums, then reduced; the
+    # convolutions sum in another order per rank count) the step itself is noise, up to 2 lr apart.  Where the gradient stands
+    # 1000 x clear of that noise the post-step weights agree to 1e-5; everywhere they stay within the 2 lr bound; a lost rank
+    # contribution would move the significant weights by ~1e-3
+    assert res["param_max_abs"] <= 2.1e-3, res
+    assert res["significant_fraction"] > 0.3 and res["param_max_abs_significant"] <= 1e-5, res
     assert abs(res["loss_dp"] - res["loss_single"]) <= 1e-5 * abs(res["loss_single"])
     assert len(res["none_grad"]) == 8 and all("up_convs.3." in k for k in res["none_grad"])     # alto.py:241-242
     assert res["bucket"] == res["bucket_single"] >= res["live"] and res["bucket_views_aligned"]
