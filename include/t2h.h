@@ -265,6 +265,7 @@ int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, i
 #define T2H_RELU_OUT 2
 #define T2H_ACCUM 4
 #define T2H_BF16 8   /* operands rounded to bf16 (RNE) while staging, fp32 accumulate: BASELINE.json configs[2] */
+#define T2H_DEFER_REDUCE 32 /* weight-gradient entry points: see t2h_reduce_capture_begin */
 #define T2H_BF16X3 16 /* fp32-grade products from bf16 MFMAs: exact 3-way bf16 split of both operands, 6 piece products
                          (error <= ~2^-23 relative per product, fp32 accumulate); opt-in, never the default */
 int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
@@ -390,6 +391,19 @@ int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, voi
 size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N);
 int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
                  int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* Batched slab reductions.  Every weight-gradient entry point (t2h_linear_wgrad, t2h_conv3x3_wgrad, t2h_conv3x3_bx3_wgrad,
+ * t2h_upconv2x2_wgrad[_bias]) ends with a launch that sums its split slabs (fixed order: deterministic) into dw / db.  Within one
+ * backward pass (trainer.py:70 `loss.backward()`) nothing reads those gradients before the pass ends, so a caller may bracket the
+ * pass with t2h_reduce_capture_begin() / t2h_reduce_capture_end(stream): while the capture is active, calls that carry
+ * T2H_DEFER_REDUCE record their reduction instead of launching it, and _end runs all recorded ones in one launch per 24 (same
+ * summation tree per output: bit-identical results; ~50 launches per tile-step become 2-3).  The caller must keep the workspaces of
+ * the recorded calls alive until _end and must not read dw / db before it.  The capture is process-wide state (the backward may run
+ * on another thread than the caller's); two reductions into the same output are never batched together (the earlier ones are
+ * flushed first).  t2h_reduce_capture_pending: recorded reductions, -1 when no capture is active. */
+int t2h_reduce_capture_begin(void);
+int t2h_reduce_capture_pending(void);
+int t2h_reduce_capture_end(t2h_stream_t stream);
 
 /* nn.ConvTranspose2d(kernel_size=2, stride=2) of the ALTO up path (upconv2x2 in alto.py, used at alto.py:175,215-218,236):
  * output pixel (2y+dy, 2x+dx) = bias + sum_ci x[y, x, ci] w[ci, dy, dx, co].  H, W = INPUT plane dims (powers of two),

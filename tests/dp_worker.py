@@ -89,12 +89,12 @@ def run_dp(out_path):
            "grad_max_rel": float(((g_dp - g_1).abs().max() / g_1.abs().max()).item()),
            "param_max_abs": float((p_dp - p_1).abs().max().item()),
            # AdamW's first step moves a weight by lr * g / (|g| + eps): where |g| is within the re-association noise of the two
-           # summation orders the step is noise too (up to 2 lr apart).  Where the gradient stands clear of that noise (1000 x)
+           # summation orders the step is noise too (up to 2 lr apart).  Where the gradient stands clear of that noise (100 x)
            # the two runs must agree tightly:
            "param_max_abs_significant": float(((p_dp - p_1).abs() * (tr1.grad_in_param_order.abs() >
-                                                1e3 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max())).max().item()),
+                                                1e2 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max())).max().item()),
            "significant_fraction": float((tr1.grad_in_param_order.abs() >
-                                          1e3 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max()).float().mean().item()),
+                                          1e2 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max()).float().mean().item()),
            "loss_dp": loss_dp, "loss_single": loss_1, "none_grad": none_grad, "live": live,
            "bucket": int(tr.bucket.flat.numel()), "bucket_single": int(tr1.bucket.flat.numel()),
            "bucket_views_aligned": all(p.grad.data_ptr() % 16 == 0 for p in model.parameters() if p.grad is not None)}

@@ -238,3 +238,34 @@ def test_gemm_bx3_rows_vs_float64(m, k, n, monkeypatch):
     y2 = torch.empty(m, n, device=dev)
     mlp.linear_fwd_(x, w_nk, None, y2, bx3=True)
     assert torch.equal(y2, y.contiguous())
+
+
+def test_batched_slab_reductions_are_bit_identical():
+    """_lib.reduce_capture: weight-gradient calls that opt in record their slab reduction and the block's exit runs them in one
+    launch -- the same summation tree per output, so dw / db equal the immediately reduced ones bit for bit; two calls into the
+    SAME output inside one capture are never batched together (the first is flushed)."""
+    from tomosar2height_amd import _lib, grid, mlp
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(131072, 64, 128), (65536, 320, 64), (4096, 256, 512)]
+    data = [(torch.randn(m, n, generator=g).to(dev), torch.randn(m, k, generator=g).to(dev)) for m, k, n in shapes]
+    x = torch.randn(1, 64, 128, 128, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(1, 128, 128, 128, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run(capture):
+        outs = [(torch.full((n, k), 0.5, device=dev), torch.full((n,), 0.25, device=dev)) for m, k, n in shapes]
+        cw = torch.ones(128, 64, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+        cb = torch.ones(128, device=dev)
+        with _lib.reduce_capture(capture):
+            for (dy, xx), (dw, db) in zip(data, outs):
+                mlp.linear_wgrad_(dy, xx, dw, db, accumulate=True, defer=True)
+            grid.conv3x3_wgrad_(gy, x, cw, cb, accumulate=True, defer=True)
+            if capture:
+                assert _lib.load().t2h_reduce_capture_pending() >= 3
+            mlp.linear_wgrad_(data[0][0], data[0][1], outs[0][0], outs[0][1], accumulate=True, defer=True)   # same output again
+        assert _lib.load().t2h_reduce_capture_pending() == -1
+        torch.cuda.synchronize()
+        return [t for pair in outs for t in pair] + [cw, cb]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)

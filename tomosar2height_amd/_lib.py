@@ -95,6 +95,9 @@ SIGNATURES = {
     "t2h_gemm_bx3_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "t2h_gemm_bx3_workspace_bytes": (_sz, [_i64, _i, _i]),
     "t2h_gemm_bx3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_reduce_capture_begin": (_i, []),
+    "t2h_reduce_capture_pending": (_i, []),
+    "t2h_reduce_capture_end": (_i, [_vp]),
     "t2h_upconv2x2_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_fwd_add": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_dgrad_workspace_bytes": (_sz, [_i] * 5),
@@ -127,7 +130,43 @@ SIGNATURES = {
     "t2h_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
-RELU_IN, RELU_OUT, ACCUM, BF16, BF16X3 = 1, 2, 4, 8, 16
+RELU_IN, RELU_OUT, ACCUM, BF16, BF16X3, DEFER_REDUCE = 1, 2, 4, 8, 16, 32
+
+
+class reduce_capture:
+    """``with _lib.reduce_capture():`` around a backward pass: weight-gradient calls that opt in (``defer_reduce()`` -> flag
+    T2H_DEFER_REDUCE) record their slab reduction instead of launching it; leaving the block runs them all in one launch per 24
+    (include/t2h.h, t2h_reduce_capture_begin).  The workspaces of recorded calls are kept alive here until then."""
+    active = None
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled and reduce_capture.active is None
+        self.keep = []
+
+    def __enter__(self):
+        if self.enabled:
+            check(load().t2h_reduce_capture_begin(), "t2h_reduce_capture_begin")
+            reduce_capture.active = self
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            reduce_capture.active = None
+            rc = load().t2h_reduce_capture_end(stream())
+            self.keep.clear()
+            if exc[0] is None:
+                check(rc, "t2h_reduce_capture_end")
+
+
+def defer_reduce(ws=None) -> int:
+    """Flag for a weight-gradient call whose outputs nobody reads before the current backward pass ends (0 when no capture is
+    active); ``ws``: the call's workspace, kept alive until the batched reduction has run."""
+    cap = reduce_capture.active
+    if cap is None:
+        return 0
+    if ws is not None:
+        cap.keep.append(ws)
+    return DEFER_REDUCE
 
 _lib = None
 

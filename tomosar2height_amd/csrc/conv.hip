@@ -612,7 +612,8 @@ T2H_API int t2h_conv3x3_wgrad(const float *dy, const float *x, float *dw, float 
     note_kernel(p.bm == 128 ? "conv_wgrad_kernel<128,128,2,2,4,false>" : (p.bm == 64 ? "conv_wgrad_kernel<64,128,2,2,4,false>" : "conv_wgrad_kernel<32,128,1,4,4,false>"));
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
     const int accumulate = (flags & T2H_ACCUM) ? 1 : 0;
-    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, colslab, db, s);
+    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, accumulate, dw, colslab, db, s, 0, 0,
+                               (flags & T2H_DEFER_REDUCE) != 0);
 }
 
 // ---- ConvTranspose2d(kernel_size=2, stride=2): H, W are the INPUT plane's dims, the output is 2H x 2W ----------------
@@ -693,5 +694,5 @@ T2H_API int t2h_upconv2x2_wgrad_bias(const float *dy, const float *x, float *dw,
     if (int rc = check_launch("upconv2x2_wgrad")) return rc;
     // the bias gradient sums the column slabs over the splits AND the four taps: [splits * 4][Cout] rows of length Cout
     return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw,
-                               db ? colslab : nullptr, db, s, db ? 4 * p.splits : 0, Cout);
+                               db ? colslab : nullptr, db, s, db ? 4 * p.splits : 0, Cout, (flags & T2H_DEFER_REDUCE) != 0);
 }

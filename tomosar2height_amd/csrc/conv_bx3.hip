@@ -698,7 +698,8 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
         else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,3>"); }
     }
     if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
-    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s);
+    return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
+                               0, 0, (flags & T2H_DEFER_REDUCE) != 0);
 }
 
 // ---- the 1-tap form as a GEMM on rows ---------------------------------------------------------------------------------------------

@@ -157,7 +157,8 @@ int check_small(const char *what, int B, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0);
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0,
+                        bool deferrable = false);
 
 }  // namespace t2h
 

@@ -19,7 +19,9 @@
 // slab in the caller's workspace, and reduce_slabs_kernel sums the slabs in split order (no atomics =>
 // deterministic).
 #include <stdlib.h>
+#include <mutex>
 #include <string>
+#include <vector>
 #include "t2h_common.h"
 #include "gemm_args.h"
 #include "gemm_tile.h"
@@ -241,15 +243,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_kernel(Gemm
 // that are not multiples of 4.  Workgroups past the matrix part reduce the bias-gradient slabs
 // (col_slabs [splits][rows] -> col_out[rows]) in the same launch, one element per lane.
 template <int VEC>
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
-                                                          int rows, int cols, int ld_out, int accumulate,
-                                                          float *__restrict__ out, const float *__restrict__ col_slabs,
-                                                          float *__restrict__ col_out, unsigned matrix_blocks, int col_splits,
-                                                          int col_rows) {
-    __shared__ float red[256 * VEC];
+__device__ inline void reduce_slabs_body(float *red, unsigned block, const float *__restrict__ slabs, int splits, long long stride,
+                                         int rows, int cols, int ld_out, int accumulate, float *__restrict__ out,
+                                         const float *__restrict__ col_slabs, float *__restrict__ col_out,
+                                         unsigned matrix_blocks, int col_splits, int col_rows) {
     const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
-    if (blockIdx.x >= matrix_blocks) {
-        const long long e = (long long)(blockIdx.x - matrix_blocks) * 16 + el;
+    if (block >= matrix_blocks) {
+        const long long e = (long long)(block - matrix_blocks) * 16 + el;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (e < col_rows) {
             int z = q;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restri
     }
     using V = Vec<VEC>;
     const long long total = (long long)rows * cols;
-    const long long e = ((long long)blockIdx.x * 16 + el) * VEC;
+    const long long e = ((long long)block * 16 + el) * VEC;
     V s0, s1, s2, s3;
 #pragma unroll
     for (int c = 0; c < VEC; ++c) s0.v[c] = s1.v[c] = s2.v[c] = s3.v[c] = 0.f;
@@ -309,6 +309,43 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restri
         }
         t.store(dst);
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int splits, long long stride,
+                                                          int rows, int cols, int ld_out, int accumulate,
+                                                          float *__restrict__ out, const float *__restrict__ col_slabs,
+                                                          float *__restrict__ col_out, unsigned matrix_blocks, int col_splits,
+                                                          int col_rows) {
+    __shared__ float red[256 * VEC];
+    reduce_slabs_body<VEC>(red, blockIdx.x, slabs, splits, stride, rows, cols, ld_out, accumulate, out, col_slabs, col_out,
+                           matrix_blocks, col_splits, col_rows);
+}
+
+// Many slab reductions in ONE launch (t2h_reduce_capture_*): the weight / bias gradients of a tile's backward are not read before
+// the end of the backward, so their reductions (one per layer: ~50 launches of 4-20 us per tile-step) are recorded while the
+// capture is active and run together.  Same body, same summation tree per output: bit-identical to the separate launches.
+constexpr int kBatchSegs = 24;
+struct ReduceSeg {
+    const float *slabs; float *out; const float *col_slabs; float *col_out;
+    long long stride;
+    int splits, rows, cols, ld_out, accumulate, col_splits, col_rows, vec;
+    unsigned matrix_blocks, blocks;
+};
+struct ReduceBatch { int n; unsigned first[kBatchSegs + 1]; ReduceSeg seg[kBatchSegs]; };
+
+__global__ __launch_bounds__(256) void reduce_slabs_batch_kernel(ReduceBatch b) {
+    __shared__ float red[256 * 4];
+    int s = 0;
+    while (s + 1 < b.n && blockIdx.x >= b.first[s + 1]) ++s;
+    const ReduceSeg &g = b.seg[s];
+    const unsigned block = blockIdx.x - b.first[s];
+    if (g.vec == 4)
+        reduce_slabs_body<4>(red, block, g.slabs, g.splits, g.stride, g.rows, g.cols, g.ld_out, g.accumulate, g.out, g.col_slabs,
+                             g.col_out, g.matrix_blocks, g.col_splits, g.col_rows);
+    else
+        reduce_slabs_body<1>(red, block, g.slabs, g.splits, g.stride, g.rows, g.cols, g.ld_out, g.accumulate, g.out, g.col_slabs,
+                             g.col_out, g.matrix_blocks, g.col_splits, g.col_rows);
 }
 
 // ---- small-K fallback (fc_pos: K = 3): plain VALU, memory bound --------------------------------------------
@@ -541,8 +578,32 @@ static int launch_rows(const GemmArgs &a, int mode, hipStream_t s, const char *w
 
 static bool aligned4(const void *p, int ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
+// ---- capture of deferrable slab reductions (process-wide, explicit: see t2h_reduce_capture_begin in include/t2h.h) ----------------
+static std::mutex g_cap_mutex;
+static bool g_cap_active = false;
+static std::vector<ReduceSeg> g_cap;
+
+static int flush_captured_locked(hipStream_t s) {
+    size_t i = 0;
+    while (i < g_cap.size()) {
+        ReduceBatch b{};
+        unsigned blocks = 0;
+        for (; i < g_cap.size() && b.n < kBatchSegs; ++i) {
+            b.first[b.n] = blocks;
+            b.seg[b.n] = g_cap[i];
+            blocks += g_cap[i].blocks;
+            ++b.n;
+        }
+        b.first[b.n] = blocks;
+        hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3(blocks), dim3(256), 0, s, b);
+    }
+    g_cap.clear();
+    return check_launch("reduce_slabs_batch");
+}
+
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits, int col_rows) {
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits, int col_rows,
+                        bool deferrable) {
     // col_slabs [col_splits][col_rows] -> col_out[col_rows]; by default the matrix's split count and row count
     if (col_splits <= 0) col_splits = splits;
     if (col_rows <= 0) col_rows = rows;
@@ -550,6 +611,23 @@ int launch_reduce_slabs(const float *slabs, int splits, long long stride, int ro
     const bool vec = cols % 4 == 0 && ld_out % 4 == 0 && stride % 4 == 0 && (uintptr_t)slabs % 16 == 0 && (uintptr_t)out % 16 == 0;
     const unsigned mb = (unsigned)((total + (vec ? 63 : 15)) / (vec ? 64 : 16));
     const unsigned cb = col_out ? (unsigned)((col_rows + 15) / 16) : 0u;
+    if (deferrable) {
+        std::lock_guard<std::mutex> lock(g_cap_mutex);
+        if (g_cap_active) {
+            // two reductions into the same output in one batch would race: run what is queued first
+            for (const ReduceSeg &q : g_cap)
+                if (q.out == out || (col_out && q.col_out == col_out)) {
+                    if (int rc = flush_captured_locked(s)) return rc;
+                    break;
+                }
+            ReduceSeg g{};
+            g.slabs = slabs; g.out = out; g.col_slabs = col_slabs; g.col_out = col_out; g.stride = stride; g.splits = splits;
+            g.rows = rows; g.cols = cols; g.ld_out = ld_out; g.accumulate = accumulate; g.col_splits = col_splits;
+            g.col_rows = col_rows; g.vec = vec ? 4 : 1; g.matrix_blocks = mb; g.blocks = mb + cb;
+            g_cap.push_back(g);
+            return T2H_OK;
+        }
+    }
     if (vec)
         hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(mb + cb), dim3(256), 0, s, slabs, splits, stride, rows, cols, ld_out,
                            accumulate, out, col_slabs, col_out, mb, col_splits, col_rows);
@@ -562,6 +640,26 @@ int launch_reduce_slabs(const float *slabs, int splits, long long stride, int ro
 }  // namespace t2h
 
 using namespace t2h;
+
+T2H_API int t2h_reduce_capture_begin(void) {
+    std::lock_guard<std::mutex> lock(g_cap_mutex);
+    if (g_cap_active) return fail(T2H_ERR_ARG, "reduce_capture_begin: a capture is already active");
+    g_cap_active = true;
+    g_cap.clear();
+    return T2H_OK;
+}
+
+T2H_API int t2h_reduce_capture_pending(void) {
+    std::lock_guard<std::mutex> lock(g_cap_mutex);
+    return g_cap_active ? (int)g_cap.size() : -1;
+}
+
+T2H_API int t2h_reduce_capture_end(t2h_stream_t stream) {
+    std::lock_guard<std::mutex> lock(g_cap_mutex);
+    if (!g_cap_active) return fail(T2H_ERR_ARG, "reduce_capture_end: no capture is active");
+    g_cap_active = false;
+    return flush_captured_locked(as_stream(stream));
+}
 
 static int map_flags(int f) {
     int o = 0;
@@ -706,5 +804,6 @@ T2H_API int t2h_linear_wgrad(const float *dy, int lddy, const float *x, int ldx,
         if (rc) return rc;
     }
     if (direct) return T2H_OK;
-    return launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, colslab, db, s);
+    return launch_reduce_slabs(slab, p.splits, (long long)N * K, N, K, K, accumulate, dw, colslab, db, s, 0, 0,
+                               (flags & T2H_DEFER_REDUCE) != 0);
 }

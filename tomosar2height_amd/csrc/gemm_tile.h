@@ -213,8 +213,11 @@ __device__ inline void store_tiles_f32(f32x16 (&acc)[TM][TN], float *patch, int 
 
 // reduce_slabs_kernel of gemm.hip: out[r, c] = [out +] sum_z slabs[z][r * cols + c] in a fixed order, and in the same
 // launch col_out[r] = [col_out +] sum_z col_slabs[z][r] (the bias gradient; col_out may be null)
+// `deferrable` (entry points: flag T2H_DEFER_REDUCE): while a t2h_reduce_capture is active the reduction is recorded instead of
+// launched and runs with all other recorded ones in ONE launch at t2h_reduce_capture_end
 int launch_reduce_slabs(const float *slabs, int splits, long long stride, int rows, int cols, int ld_out, int accumulate,
-                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0);
+                        float *out, const float *col_slabs, float *col_out, hipStream_t s, int col_splits = 0, int col_rows = 0,
+                        bool deferrable = false);
 
 // reduce_rows_epilogue_kernel of conv.hip: out[r, c] = [out +] act( sum_z slabs[z][r, c] + bias[c] ) * (mask > 0), splits in order
 int launch_reduce_rows_epilogue(const float *slabs, int splits, long long stride, long long M, int N, const EpilogueArgs &e,

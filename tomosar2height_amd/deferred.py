@@ -243,7 +243,7 @@ class _DeferredLevel(torch.autograd.Function):
         if state.cache is not None and not ctx.needs_input_grad[1]:
             # maps from the trainer's ComposeCache: this tile's share goes onto the persistent sums (zeroed by flush())
             e = state.cache.levels[idx]
-            mlp.linear_wgrad_(x, dacc, e["ga"], None, accumulate=True)        # += x^T dacc
+            mlp.linear_wgrad_(x, dacc, e["ga"], None, accumulate=True, defer=True)   # += x^T dacc (read at flush(): after the pass)
             e["gconst"].add_(dconst)
             dconst = None
             state.cache.pending = True

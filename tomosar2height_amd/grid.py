@@ -241,7 +241,9 @@ def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
     return dx
 
 
-def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
+def conv3x3_wgrad_(gy, x, dw, db, accumulate=False, defer=False):
+    """``defer``: dw / db are final gradient buffers nobody reads before the backward pass ends -- the slab reduction may join the
+    pass's batched one (``_lib.reduce_capture``)."""
     b, cout, h, wd = gy.shape
     cin = x.shape[1]
     lib = _lib.load()
@@ -250,14 +252,16 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False):
         nws = _lib.ws_bytes("t2h_conv3x3_bx3_wgrad_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, gy.device)
         _lib.call(entry, _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                  b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag(), _lib.ptr(ws), nws, _lib.stream(),
+                  b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag() | (_lib.defer_reduce(ws) if defer else 0),
+                  _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
                   tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
         return
     nws = _lib.ws_bytes("t2h_conv3x3_wgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-              b, h, wd, cin, cout, _lib.ACCUM if accumulate else 0, _lib.ptr(ws), nws, _lib.stream(),
+              b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | (_lib.defer_reduce(ws) if defer else 0), _lib.ptr(ws), nws,
+              _lib.stream(),
               nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
               tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
 
@@ -319,7 +323,7 @@ def _conv3x3_param_grads(gm, x, weight, bias):
             gm.record_stream(side)
             x.record_stream(side)
         else:
-            conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
+            conv3x3_wgrad_(gm, x, wg, bg, accumulate=True, defer=True)
         return None, None
     dw = torch.empty_like(weight, memory_format=torch.channels_last)
     db = torch.empty_like(bias) if bias is not None else None
@@ -540,7 +544,7 @@ class _UpConv2x2(torch.autograd.Function):
         ws = _lib.workspace(nws, g.device)
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
         _lib.call("t2h_upconv2x2_wgrad_bias", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
-                  b, h, wd, cin, cout, _lib.ACCUM if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
+                  b, h, wd, cin, cout, (_lib.ACCUM | _lib.defer_reduce(ws)) if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                   tag=_lib.timing() and f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
         ga = g if ctx.has_addend else None

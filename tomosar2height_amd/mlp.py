@@ -122,8 +122,9 @@ def linear_dgrad_(dy, w, dx, mask=None, accumulate=False, bx3=False):
     return dx
 
 
-def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
-    """dw = [dw +] dy^T act_in(x); db = [db +] colsum(dy) (db may be None); deterministic split reduction."""
+def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False, defer=False):
+    """dw = [dw +] dy^T act_in(x); db = [db +] colsum(dy) (db may be None); deterministic split reduction.  ``defer``: dw / db are
+    buffers nobody reads before the backward pass ends: the reduction may join the pass's batched one (``_lib.reduce_capture``)."""
     (gp, ldg), (xp, ldx) = _rows(dy, "linear_wgrad dy"), _rows(x, "linear_wgrad x")
     m, n = dy.shape
     k = x.shape[1]
@@ -137,7 +138,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False):
         return
     ws_bytes = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, k, n)
     ws = _lib.workspace(ws_bytes, dy.device)
-    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag()
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag() | (_lib.defer_reduce(ws) if defer else 0)
     _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
               ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
               tag=_lib.timing() and f"t2h_linear_wgrad[N={n},K={k}]")
@@ -182,7 +183,7 @@ def _wgrad(dy, x, w, bias, relu_in=False):
             and (bias is None or (bias.grad is not None and bias.grad.is_contiguous()))):
         side = _WGRAD_STREAM
         if side is None:
-            linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+            linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True, defer=True)
         else:
             side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
             with torch.cuda.stream(side):

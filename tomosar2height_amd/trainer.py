@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import mlp
+from . import _lib, mlp
 
 
 def _is_dense(t: torch.Tensor) -> bool:
@@ -199,7 +199,7 @@ class Trainer:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):     # capture on the stream the warm-up ran on
                 l1, ce = self._losses(static, 0.0001)
-                with mlp.direct_grad_accumulation(self.direct_accumulation):
+                with mlp.direct_grad_accumulation(self.direct_accumulation), _lib.reduce_capture(self.direct_accumulation):
                     (l1 + ce).backward()
         self.bucket.flat.copy_(saved)
         if saved_cache is not None:
@@ -261,7 +261,12 @@ class Trainer:
                 if self._conv_side is None:
                     self._conv_side = torch.cuda.Stream(device=loss.device)
                 conv_side = self._conv_side
-            with mlp.direct_grad_accumulation(self.bucket is not None and self.direct_accumulation, side, conv_side):
+            direct = self.bucket is not None and self.direct_accumulation
+            # the weight gradients accumulate straight into the bucket and nothing reads it before the pass ends: their slab
+            # reductions run as ONE batched launch at the end of the pass instead of one launch per layer (T2H_BATCH_REDUCE=0: A/B)
+            batch = (direct and loss.is_cuda and side is None and conv_side is None
+                     and os.environ.get("T2H_BATCH_REDUCE", "1") != "0")
+            with mlp.direct_grad_accumulation(direct, side, conv_side), _lib.reduce_capture(batch):
                 loss.backward()
             for st in (side, conv_side):
                 if st is not None:
