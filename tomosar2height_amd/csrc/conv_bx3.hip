@@ -516,6 +516,11 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9) {
     const long long tiles8 = H % 8 == 0 ? (long long)B * (H / 8) * (W / TW) * (Nc / r.bn) : 0;
     r.tall = tiles8 >= min_tiles8 && !(ntap == 1 && r.bn == 128);        // (1-tap, 128 columns: the 8-row images would not fit twice per CU)
     r.tiles = r.tall ? tiles8 : (long long)B * (H / 4) * (W / TW) * (Nc / r.bn);
+    // few tiles (small planes) and a short reduction (<= 128 channels: few chunks to split): 64-column tiles double the tile count
+    // instead of splitting the reduction into slabs (64->128 at 128^2: 32 -> 24 us, 128->256 at 64^2: 31 -> 29; with longer
+    // reductions the narrower tiles lose: 512->256 at 64^2 dgrad 64 -> 98 us).  T2H_BX3_NARROW=0: A/B
+    static const bool narrow = !(getenv("T2H_BX3_NARROW") && getenv("T2H_BX3_NARROW")[0] == '0');
+    if (narrow && !r.tall && r.bn == 128 && r.tiles < 256 && Kc <= 128) { r.bn = 64; r.tiles *= 2; }
     // small planes with many channels: fewer tiles than the chip holds workgroups -> split the reduction over whole 32-channel
     // chunks into slabs (summed in a fixed order by reduce_rows_epilogue, which also applies the epilogue): deterministic
     r.splits = 1;
