@@ -643,7 +643,7 @@ def main():
             "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "f32 tensors, bf16-operand MFMA in the per-point GEMMs",
+            "dtype": {"fp32": "f32", "bf16": "f32 tensors, bf16-operand MFMA in the per-point GEMMs and the 3x3 convolutions",
                       "bf16x3": "f32 tensors, per-point GEMM products via exact 3-way bf16 split (6 bf16 MFMAs)"}[args.mlp_precision],
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: Berlin cloud+image" if args.use_image
@@ -661,7 +661,12 @@ def main():
                        "rccl_ranks": world if (world > 1 and dist.get_backend(group) == "nccl") else 0,
                        "channels_last": bool(args.channels_last),
                        "point_distribution": "uniform (no-skew control)" if args.uniform_xy else "70 % in 160 buildings + 30 % uniform",
-                       "grid_convs": "t2h implicit-GEMM (csrc/conv.hip)" if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen",
+                       "grid_convs": ({"bf16x3": "t2h csrc/conv_bx3.hip: every fp32 product from six bf16 MFMAs (exact 3-way operand "
+                                                 "split, fp32 accumulate; error vs float64 = the fp32 MFMA kernels'), planes >= 32 wide; "
+                                                 "csrc/conv.hip (fp32 MFMA) for the rest",
+                                       "bf16": "t2h csrc/conv_bx3.hip, operands rounded to bf16 (one MFMA per product, fp32 accumulate)",
+                                       "fp32": "t2h implicit-GEMM on fp32 MFMA (csrc/conv.hip)"}[grid.CONV_PRECISION]
+                                      if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen"),
                        "point_update": point_update_note(),
                        "library_fallbacks": getattr(grid, "fallback_count", lambda: None)(),
                        "hip_graph": bool(args.hip_graph)},

@@ -99,8 +99,17 @@ constexpr int TW = 32;
 // ORD: 0 = fragments loaded tile-major, smallest terms first, all reads before the first MFMA (the first shipped form);
 //      1 = fragments loaded PLANE-major and the products largest first (a1b1 needs only the first TM + TN reads), reads still fenced;
 //      2 = as 1 without the fence (the compiler may sink reads between the MFMAs)
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CC, int ORD = 0>
+// PRIO: 1 = static s_setprio by the parity of the wave's slot on its SIMD (HW_ID.WAVE_ID): the two co-resident waves of a SIMD get
+//       different priorities, so their MFMA bursts do not interleave evenly (both then finish together and leave the matrix pipe idle
+//       while both read LDS / issue DMA / wait at their barriers) but run one after the other; 2 = by (blockIdx.x >> 8) & 1
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CC, int ORD = 0, int PRIO = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(ConvArgs p) {
+    if (PRIO == 1) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID, bits [3:0]: WAVE_ID
+        if (slot & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    } else if (PRIO == 2) {
+        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
     constexpr int PXB = CC * 2 + 16;              // bytes per pixel and plane in the halo image: CC bf16 + 16 B pad (odd multiple of 16 B)
     constexpr int NQ = CC / 16, F4 = CC / 4;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
@@ -446,15 +455,16 @@ int main(int argc, char **argv) {
     const int BN = Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
     struct Variant { const char *name; int th, cc; void (*launch)(ConvArgs, int, hipStream_t); };
 #define V(TH_, BN_, WM_, WN_, CC_) VO(TH_, BN_, WM_, WN_, CC_, 0)
-#define VO(TH_, BN_, WM_, WN_, CC_, ORD_) Variant{"TH=" #TH_ " BN=" #BN_ " waves " #WM_ "x" #WN_ " CC=" #CC_ " ORD=" #ORD_, TH_, CC_, \
-    [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_kernel<TH_, BN_, WM_, WN_, CC_, ORD_>), dim3(grid), dim3(256), 0, s_, q); }}
+#define VO(TH_, BN_, WM_, WN_, CC_, ORD_) VP(TH_, BN_, WM_, WN_, CC_, ORD_, 0)
+#define VP(TH_, BN_, WM_, WN_, CC_, ORD_, PRIO_) Variant{"TH=" #TH_ " BN=" #BN_ " waves " #WM_ "x" #WN_ " CC=" #CC_ " ORD=" #ORD_ " PRIO=" #PRIO_, TH_, CC_, \
+    [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_kernel<TH_, BN_, WM_, WN_, CC_, ORD_, PRIO_>), dim3(grid), dim3(256), 0, s_, q); }}
     std::vector<Variant> vars;
     Variant wide128{"WIDE 512 threads TH=8 BN=128 CC=32 (48 MFMAs / barrier)", 8, 32,
         [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_wide_kernel<128>), dim3(grid), dim3(512), 0, s_, q); }};
     Variant wide64{"WIDE 512 threads TH=8 BN=64 CC=32", 8, 32,
         [](ConvArgs q, int grid, hipStream_t s_) { hipLaunchKernelGGL((conv3x3_bf16x3_wide_kernel<64>), dim3(grid), dim3(512), 0, s_, q); }};
-    if (BN == 128) vars = {wide128, V(4, 128, 2, 2, 32), VO(4, 128, 2, 2, 32, 1), VO(4, 128, 2, 2, 32, 2), V(8, 128, 2, 2, 16), VO(8, 128, 2, 2, 16, 1), VO(8, 128, 2, 2, 16, 2)};
-    else if (BN == 64) vars = {wide64, V(4, 64, 4, 1, 32), VO(4, 64, 4, 1, 32, 1), VO(4, 64, 4, 1, 32, 2), V(8, 64, 4, 1, 16), VO(8, 64, 4, 1, 16, 1), VO(8, 64, 4, 1, 16, 2)};
+    if (BN == 128) vars = {VP(4, 128, 2, 2, 32, 0, 1), VP(4, 128, 2, 2, 32, 0, 2), VP(8, 128, 2, 2, 16, 0, 1), VP(8, 128, 2, 2, 16, 0, 2), wide128, V(4, 128, 2, 2, 32), VO(4, 128, 2, 2, 32, 1), VO(4, 128, 2, 2, 32, 2), V(8, 128, 2, 2, 16), VO(8, 128, 2, 2, 16, 1), VO(8, 128, 2, 2, 16, 2)};
+    else if (BN == 64) vars = {VP(4, 64, 4, 1, 32, 0, 1), VP(8, 64, 4, 1, 16, 0, 1), VP(8, 64, 4, 1, 16, 0, 2), wide64, V(4, 64, 4, 1, 32), VO(4, 64, 4, 1, 32, 1), VO(4, 64, 4, 1, 32, 2), V(8, 64, 4, 1, 16), VO(8, 64, 4, 1, 16, 1), VO(8, 64, 4, 1, 16, 2)};
     else vars = {V(4, 32, 4, 1, 32), VO(4, 32, 4, 1, 32, 1), VO(4, 32, 4, 1, 32, 2), V(8, 32, 4, 1, 16), VO(8, 32, 4, 1, 16, 1)};
     int cur_cc = 0;
     auto prep = [&]() {
