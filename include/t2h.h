@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 9
+#define T2H_ABI_VERSION 10
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -391,6 +391,21 @@ int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, voi
 size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N);
 int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
                  int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* ConvTranspose2d(kernel_size = 2, stride = 2) (upconv2x2, alto.py:175,215-218,236) on the same 1-tap kernels.  The forward is the
+ * GEMM [B H W, Cin] x [Cin, (tap, co)] with a scattering epilogue: column tile -> tap = 2 dy + dx -> output pixel (2y + dy, 2x + dx),
+ * bias and the residual `addend` (output-shaped, or null) added there; y[B, 2H, 2W, Cout] NHWC.  The data gradient gathers its A
+ * rows instead: K = (tap, co) reads dy at the four output pixels of each input pixel.  Weights: the module's [Cin, Cout, 2, 2]
+ * tensor in [Cin][2][2][Cout] memory order IS the matrix [Cin][4 Cout]: split it with t2h_gemm_bx3_prepare(w, 4 Cout, K = Cin,
+ * N = 4 Cout, w_is_kn = 1) for the forward and (w, 4 Cout, K = 4 Cout, N = Cin, w_is_kn = 0) for the data gradient.
+ * H, W powers of two, B H W % 128 == 0, Cin % 64 == 0, Cout % 64 == 0 (t2h_upconv2x2_bx3_supported).  Replaces
+ * t2h_upconv2x2_fwd_add / t2h_upconv2x2_dgrad where supported; the weight gradient stays on t2h_upconv2x2_wgrad_bias. */
+int t2h_upconv2x2_bx3_supported(int B, int H, int W, int Cin, int Cout);
+int t2h_upconv2x2_bx3_fwd(const float *x, const void *wf, const float *bias, const float *addend, float *y, int B, int H, int W,
+                          int Cin, int Cout, int flags, t2h_stream_t stream);
+size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+                            void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* Batched slab reductions.  Every weight-gradient entry point (t2h_linear_wgrad, t2h_conv3x3_wgrad, t2h_conv3x3_bx3_wgrad,
  * t2h_upconv2x2_wgrad[_bias]) ends with a launch that sums its split slabs (fixed order: deterministic) into dw / db.  Within one

@@ -94,7 +94,11 @@ if args.only in ("", "upconv"):
         ws_d = _lib.workspace(lib.t2h_upconv2x2_dgrad_workspace_bytes(1, h, h, cin, cout), dev)
         ws_w = _lib.workspace(lib.t2h_upconv2x2_wgrad_workspace_bytes(1, h, h, cin, cout), dev)
         fl = 2.0 * 4 * cin * cout * h * h
+        wf, wft = grid.split_weights.get_up(w, True), grid.split_weights.get_up(w, False)
+        ws_b = _lib.workspace(lib.t2h_upconv2x2_bx3_dgrad_workspace_bytes(1, h, h, cin, cout), dev)
         for name, fn in (
+                ("bx3_fwd", lambda: _lib.call("t2h_upconv2x2_bx3_fwd", _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
+                ("bx3_dgrad", lambda: _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(gy), _lib.ptr(wft), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_b), ws_b.numel(), _lib.stream())),
                 ("fwd", lambda: _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
                 ("dgrad", lambda: _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_d), ws_d.numel(), _lib.stream())),
                 ("wgrad", lambda: _lib.call("t2h_upconv2x2_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), 1, h, h, cin, cout, 0, _lib.ptr(ws_w), ws_w.numel(), _lib.stream()))):

@@ -433,6 +433,70 @@ def test_upconv2x2_matches_conv_transpose(b, h, w, cin, cout):
     assert torch.equal(wbuf, w0 + w0) and torch.equal(bbuf, b0 + b0)
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 32, 32, 512, 256), (1, 64, 64, 256, 128), (1, 128, 128, 128, 64), (2, 16, 32, 64, 64),
+                                            (4, 32, 32, 192, 64), (1, 8, 16, 1024, 512)])
+def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, monkeypatch):
+    """The transposed convolutions on csrc/conv_bx3.hip (scattering epilogue / gathering loader on the 1-tap form): forward with bias
+    and residual addend, data gradient (split-K slabs at the small planes), against float64, at the error of the fp32-MFMA kernels;
+    the kernels actually ran; the fp32 path (T2H_UPCONV_BX3=0 sibling) gives the same values to fp32 rounding."""
+    import copy
+    from tomosar2height_amd import _lib, grid
+    monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 128)
+    g = torch.Generator().manual_seed(b * 7 + h + cin + cout)
+    torch.manual_seed(b + h + cin + cout)
+    conv = torch.nn.ConvTranspose2d(cin, cout, 2, stride=2)
+    ref = copy.deepcopy(conv).double()
+    x = torch.randn(b, cin, h, w, generator=g)
+    add = torch.randn(b, cout, 2 * h, 2 * w, generator=g)
+    gout = torch.randn(b, cout, 2 * h, 2 * w, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr) + add.double()
+    yr.backward(gout.double())
+    conv = conv.to(_dev()).to(memory_format=torch.channels_last)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(grid, "UPCONV_BX3", on)
+        conv.zero_grad(set_to_none=True)
+        xg = _cl(x).requires_grad_(True)
+        ag = _cl(add).requires_grad_(True)
+        assert grid._up_bx3(xg, conv.weight, grid._w_cl(conv.weight)) == on
+        with _lib.KernelTimeline() as tl:
+            y = grid.upconv2x2(xg, conv, ag)
+            y.backward(_cl(gout))
+        torch.cuda.synchronize()
+        names = [r[5] for r in tl.records if r[5].startswith("bx3_rows_kernel")]
+        assert (len(names) == 2 and names[0].endswith(",64,3,1,1>") and names[1].endswith(",64,3,1,2>")) if on else not names, names
+        outs[on] = (y.detach().clone(), xg.grad.clone(), ag.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    for on in (True, False):
+        y, dx, da, dw, db = outs[on]
+        _close(y, yr.detach())
+        _close(dx, xr.grad)
+        assert torch.equal(da.cpu(), gout)
+        _close(dw, ref.weight.grad)
+        _close(db, ref.bias.grad)
+    # the split product is exact to fp32 rounding of the accumulation: both paths sit at the same distance from float64
+    for i in (0, 1):
+        e_on = (outs[True][i].double().cpu() - (yr.detach(), xr.grad)[i]).abs().max().item()
+        e_off = (outs[False][i].double().cpu() - (yr.detach(), xr.grad)[i]).abs().max().item()
+        assert e_on <= 2.0 * e_off + 1e-6, (i, e_on, e_off)
+
+
+def test_upconv2x2_bx3_weights_follow_the_optimizer():
+    """The split planes of a transposed-convolution weight are cached per weight version: an in-place update re-splits them."""
+    from tomosar2height_amd import grid
+    torch.manual_seed(3)
+    conv = torch.nn.ConvTranspose2d(64, 64, 2, stride=2).to(_dev()).to(memory_format=torch.channels_last)
+    x = _cl(torch.randn(1, 64, 32, 32))
+    y0 = grid.upconv2x2(x, conv).detach().clone()
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+        conv.bias.zero_()
+    y1 = grid.upconv2x2(x, conv).detach()
+    ref = torch.nn.functional.conv_transpose2d(x.double().cpu(), conv.weight.detach().double().cpu(), None, stride=2)
+    _close(y1, ref)
+    assert not torch.allclose(y0, y1)
+
+
 def test_conv3x3_argument_errors():
     from tomosar2height_amd import _lib, grid
     x = grid._empty_cl(1, 32, 12, 16, _dev())

@@ -136,7 +136,17 @@ struct RowsArgs {
     int B, H, W, Kc, Nc, flags;
     int splits, chunks_per_split;   // splits > 1: grid = tiles x splits, partial sums to y + split * B H W Nc (no epilogue)
     int ldx, ldy, ldm;       // row strides (floats) of x, y and mask: Kc / Nc / Nc for the convolutions, free for the 1-tap (GEMM) form
+    // 2x2 stride-2 transposed convolution on the 1-tap form (UPM != 0): the GEMM rows are the pixels of the INPUT plane
+    // [*, 2^up_logH, 2^up_logW], the output plane has twice its size and up_cout channels
+    const float *addend;     // UPM = 1: tensor of the output's shape added to the result, or null
+    int up_logW, up_logH, up_cout;
 };
+
+// output pixel (2y + dy, 2x + dx) of the transposed convolution for GEMM row m = ((b * H + y) * W + x), tap = 2 dy + dx
+__device__ inline size_t up_pixel(long long m, int tap, int logW, int logH) {
+    const long long x = m & ((1LL << logW) - 1), y = (m >> logW) & ((1LL << logH) - 1), b = m >> (logW + logH);
+    return (size_t)(((b << (logH + 1)) + 2 * y + (tap >> 1)) << (logW + 1)) + 2 * x + (tap & 1);
+}
 
 // TH image rows x 32 columns x BN output channels per workgroup, CCH reduction channels per staged halo chunk.  Two shapes are
 // used: 4 rows / 32 channels (80-byte pixel stride) and -- for planes with enough tiles to fill the chip -- 8 rows / 16
@@ -147,8 +157,12 @@ struct RowsArgs {
 // NTAP = 9: the 3x3 convolution.  NTAP = 1: the same kernel as a plain GEMM on rows, Y[M, Nc] = X[M, Kc] W^T -- 1x1 convolutions,
 // nn.Linear on pixel rows and the grid-side products of the deferred ALTO point update (deferred.py): the "image" is M / 32
 // rows of 32 "pixels" with no halo, the staged chunk is the tile itself (chunks of 64 / 32 channels), row strides are free.
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL, int NTAP>
+// UPM (1-tap form only): 1 = ConvTranspose2d(2, stride 2) forward -- GEMM [pixels, Cin] x [Cin, (tap, co)] with a SCATTERING epilogue
+// (column tile -> tap -> output pixel up(p, tap)), bias / residual addend there; 2 = its data gradient -- the A rows are GATHERED:
+// chunk c of K = (tap, co) reads dY[up(p, tap)][co0 ..] (alto.py:175,215-218,236).
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL, int NTAP, int UPM = 0>
 __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
+    static_assert(UPM == 0 || NTAP == 1, "the transposed convolution runs on the 1-tap form");
     constexpr int PXB = CCH * 2 + 16;     // bytes per pixel and plane of the halo image: CCH bf16 + 16 B (an odd multiple of 16 B)
     constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = NTAP * NQ;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
@@ -191,7 +205,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             const int hy = px / HW, hx = px - hy * HW;
             const int gy = y0 + hy - HB, gx = x0 + hx - HB;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+            if (UPM == 2) {
+                const int k0 = c * CCH, tap = k0 / p.up_cout, co0 = k0 - tap * p.up_cout;      // (CCH divides up_cout)
+                if (idx < NF4)
+                    v = *reinterpret_cast<const float4 *>(p.x + up_pixel(((long long)b * p.H + gy) * p.W + gx, tap, p.up_logW, p.up_logH) *
+                                                                    p.up_cout + co0 + c4 * 4);
+            } else if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
                 v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.ldx + c * CCH + c4 * 4);
             hreg[f] = v;
         }
@@ -298,11 +317,21 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 #pragma unroll
             for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + col);
+            const int up_tap = UPM == 1 ? col / p.up_cout : 0, up_co = UPM == 1 ? col - up_tap * p.up_cout : col;
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + up_co);
             const size_t pix0 = ((size_t)b * p.H + y0 + wm * TM + i) * p.W + x0;
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
+                if (UPM == 1) {      // scatter: row = input pixel, column tile = (tap, 32 channels) -> output pixel up(row, tap)
+                    const size_t o = up_pixel((long long)(pix0 + pass * 8 + er), up_tap, p.up_logW, p.up_logH) * p.up_cout + up_co;
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    float4 *dst = reinterpret_cast<float4 *>(p.y + o);
+                    if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                    if (p.addend) { const float4 ad = *reinterpret_cast<const float4 *>(p.addend + o); v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
+                    *dst = v;
+                    continue;
+                }
                 const size_t o = (pix0 + pass * 8 + er) * p.ldy + col;
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 if (p.mask) {
@@ -507,9 +536,29 @@ int check_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
 }
 
 struct RowsPlan { bool tall; int bn, splits, chunks_per_split; long long tiles; };
-RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9) {
+RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int upm = 0) {
     RowsPlan r{};
     r.bn = Nc % 128 == 0 ? 128 : (Nc % 64 == 0 ? 64 : 32);
+    if (upm) {
+        // transposed convolution: 4-row tiles only; the forward's scattering epilogue cannot take split slabs, so it narrows its
+        // column tiles until ~256 workgroups exist; the data gradient splits like any other few-tile product
+        r.tall = false;
+        const long long row_tiles = (long long)B * (H / 4) * (W / TW);
+        if (upm == 1) while (r.bn > 32 && row_tiles * (Nc / r.bn) < 192) r.bn >>= 1;
+        r.tiles = row_tiles * (Nc / r.bn);
+        r.splits = 1;
+        const int nchunk_u = Kc / 64;
+        static const long long target_u = 512;
+        if (upm == 2 && r.tiles < target_u / 2) {
+            long long want = (target_u + r.tiles - 1) / r.tiles;
+            if (want > nchunk_u) want = nchunk_u;
+            if (want > 32) want = 32;
+            r.splits = (int)(want < 1 ? 1 : want);
+        }
+        r.chunks_per_split = (nchunk_u + r.splits - 1) / r.splits;
+        r.splits = (nchunk_u + r.chunks_per_split - 1) / r.chunks_per_split;
+        return r;
+    }
     // 8-row tiles where they still give every CU its two workgroups twice over (512 x 512 planes: 1024 tiles); measured on
     // 64->128 / 128->64 / 64->32 at 512^2: 203 -> 185, 239 -> 194, 76 -> 72 us, and slower at 256^2 (256 tiles: one per CU)
     static const long long min_tiles8 = getenv("T2H_BX3_TILES8") ? atoll(getenv("T2H_BX3_TILES8")) : 1024;
@@ -549,8 +598,14 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9) {
     } while (0)
 
 // `a`: x, wf, bias, mask, y, geometry and epilogue flags; splits the reduction into `ws` when the plan says so
-int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9) {
-    const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc, ntap);
+#define BX3_LAUNCH_UP(BN_, WM_, WN_, UPM_)                                                                                    \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 3, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a);   \
+        note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,3,1," #UPM_ ">");                                      \
+    } while (0)
+
+int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9, int upm = 0) {
+    const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc, ntap, upm);
     const long long grid = r.tiles * r.splits;
     if (grid > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
     const long long M = (long long)a.B * a.H * a.W;
@@ -563,7 +618,15 @@ int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t 
         a.y = static_cast<float *>(ws); a.bias = nullptr; a.mask = nullptr; a.flags = 0; a.ldy = a.Nc;
     }
     a.splits = r.splits; a.chunks_per_split = r.chunks_per_split;
-    if (ntap == 9) {
+    if (upm == 1) {
+        if (r.bn == 128) BX3_LAUNCH_UP(128, 2, 2, 1);
+        else if (r.bn == 64) BX3_LAUNCH_UP(64, 4, 1, 1);
+        else BX3_LAUNCH_UP(32, 4, 1, 1);
+    } else if (upm == 2) {
+        if (r.bn == 128) BX3_LAUNCH_UP(128, 2, 2, 2);
+        else if (r.bn == 64) BX3_LAUNCH_UP(64, 4, 1, 2);
+        else BX3_LAUNCH_UP(32, 4, 1, 2);
+    } else if (ntap == 9) {
         if (r.tall) {
             if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 16, 9);
             else if (r.bn == 64) BX3_LAUNCH(8, 64, 4, 1, 16, 9);
@@ -747,4 +810,55 @@ T2H_API int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *b
     a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = K; a.Nc = N; a.ldx = ldx; a.ldy = ldy; a.ldm = ldm;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
     return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "gemm_bx3", 1);
+}
+
+// ---- ConvTranspose2d(kernel_size = 2, stride = 2) on the 1-tap form -------------------------------------------------------------------
+static int check_up_bx3(const char *what, int B, int H, int W, int Cin, int Cout) {
+    if (B < 1 || !pow2(H) || !pow2(W) || H > 16384 || W > 16384 || (long long)B * H * W % 128 != 0 || (long long)B * H * W > (1LL << 28) ||
+        Cin < 64 || Cout < 64 || Cin % 64 || Cout % 64)
+        return fail(T2H_ERR_ARG, "%s: needs power-of-two H, W with B H W %% 128 == 0 and Cin, Cout multiples of 64 (B=%d H=%d W=%d %d->%d)",
+                    what, B, H, W, Cin, Cout);
+    return T2H_OK;
+}
+static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+T2H_API int t2h_upconv2x2_bx3_supported(int B, int H, int W, int Cin, int Cout) {
+    return B >= 1 && pow2(H) && pow2(W) && H <= 16384 && W <= 16384 && (long long)B * H * W % 128 == 0 && (long long)B * H * W <= (1LL << 28) &&
+           Cin >= 64 && Cout >= 64 && Cin % 64 == 0 && Cout % 64 == 0;
+}
+
+T2H_API int t2h_upconv2x2_bx3_fwd(const float *x, const void *wf, const float *bias, const float *addend, float *y, int B, int H, int W,
+                                  int Cin, int Cout, int flags, t2h_stream_t stream) {
+    if (!x || !wf || !y) return fail(T2H_ERR_ARG, "upconv2x2_bx3_fwd: null pointer");
+    if (int rc = check_up_bx3("upconv2x2_bx3_fwd", B, H, W, Cin, Cout)) return rc;
+    if (!al16(x) || !al16(wf) || !al16(y) || (bias && !al16(bias)) || (addend && !al16(addend)))
+        return fail(T2H_ERR_ARG, "upconv2x2_bx3_fwd: pointers must be 16-byte aligned");
+    const long long M = (long long)B * H * W;
+    RowsArgs a{};
+    a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.addend = addend; a.y = y;
+    a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = Cin; a.Nc = 4 * Cout; a.ldx = Cin; a.ldy = 4 * Cout; a.ldm = 0;
+    a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
+    a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
+    return launch_rows(a, false, nullptr, 0, as_stream(stream), "upconv2x2_bx3_fwd", 1, 1);
+}
+
+T2H_API size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_upconv2x2_bx3_supported(B, H, W, Cin, Cout)) return 0;
+    const long long M = (long long)B * H * W;
+    const RowsPlan r = bx3_rows_plan(1, (int)(M / 32), 32, 4 * Cout, Cin, 1, 2);
+    return r.splits > 1 ? (size_t)r.splits * M * Cin * sizeof(float) : 0;
+}
+
+T2H_API int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+                                    void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !wf_t || !dx) return fail(T2H_ERR_ARG, "upconv2x2_bx3_dgrad: null pointer");
+    if (int rc = check_up_bx3("upconv2x2_bx3_dgrad", B, H, W, Cin, Cout)) return rc;
+    if (!al16(dy) || !al16(wf_t) || !al16(dx)) return fail(T2H_ERR_ARG, "upconv2x2_bx3_dgrad: pointers must be 16-byte aligned");
+    const long long M = (long long)B * H * W;
+    RowsArgs a{};
+    a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.y = dx;
+    a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = 4 * Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = 0;
+    a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
+    a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
+    return launch_rows(a, false, workspace, workspace_bytes, as_stream(stream), "upconv2x2_bx3_dgrad", 1, 2);
 }

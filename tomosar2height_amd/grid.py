@@ -178,13 +178,38 @@ class SplitWeightCache:
         _lib.call("t2h_gemm_bx3_prepare", _lib.ptr(w), w.stride(0), k, n, 1 if w_is_kn else 0, _lib.ptr(buf), _lib.stream(),
                   nbytes=10 * w.numel())
 
+    def get_up(self, w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
+        """The same for a ConvTranspose2d(2, stride 2) weight [Cin, Cout, 2, 2] whose memory is [Cin][2][2][Cout]: the matrix
+        [Cin, (tap, co)] as the forward's [K, N] operand (``w_is_kn``) or as the data gradient's [N, K] operand."""
+        import weakref
+        key = (id(w), "up_kn" if w_is_kn else "up_nk")
+        e = self.entries.get(key)
+        cin, n4 = w.shape[0], 4 * w.shape[1]
+        if e is None or e[0]() is not w:
+            k, n = (cin, n4) if w_is_kn else (n4, cin)
+            buf = torch.empty(int(_lib.load().t2h_gemm_bx3_weights_bytes(k, n)), dtype=torch.uint8, device=w.device)
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
+        if e[1] != w._version or e[2] != w.data_ptr():
+            self._prepare_up(w, w_is_kn, e[3])
+            e[1], e[2] = w._version, w.data_ptr()
+        return e[3]
+
+    @staticmethod
+    def _prepare_up(w, w_is_kn, buf):
+        cin, n4 = w.shape[0], 4 * w.shape[1]
+        k, n = (cin, n4) if w_is_kn else (n4, cin)
+        _lib.call("t2h_gemm_bx3_prepare", _lib.ptr(w), n4, k, n, 1 if w_is_kn else 0, _lib.ptr(buf), _lib.stream(),
+                  nbytes=10 * w.numel())
+
     def refresh(self):
         """Re-split every live weight into its existing buffer."""
         for (_, kind), e in list(self.entries.items()):
             w = e[0]()
             if w is None:
                 continue
-            if kind in ("kn", "nk"):
+            if kind in ("up_kn", "up_nk"):
+                self._prepare_up(w, kind == "up_kn", e[3])
+            elif kind in ("kn", "nk"):
                 self._prepare_gemm(w, kind == "kn", e[3])
             else:
                 self._prepare(w, kind, e[3])
@@ -495,6 +520,17 @@ def upconv2x2_supported(x: torch.Tensor, conv) -> bool:
             and x.dtype == torch.float32 and _pow2(x.shape[2]) and _pow2(x.shape[3]))
 
 
+UPCONV_BX3 = os.environ.get("T2H_UPCONV_BX3", "1") != "0"      # A/B: 0 = transposed convolutions stay on conv.hip (fp32 MFMA)
+
+
+def _up_bx3(x, weight, w) -> bool:
+    """The transposed convolution runs on the split-bf16 kernels (csrc/conv_bx3.hip, 1-tap form with a scattering epilogue /
+    gathering loader) when the precision mode asks for them, the shape fits and the weight already lies [Cin][2][2][Cout]."""
+    b, cin, h, wd = x.shape
+    return bool(UPCONV_BX3 and CONV_PRECISION in ("bf16x3", "bf16") and w is weight and b * h * wd >= BX3_MIN_PIXELS
+                and _lib.load().t2h_upconv2x2_bx3_supported(b, h, wd, cin, weight.shape[1]))
+
+
 class _UpConv2x2(torch.autograd.Function):
     """nn.ConvTranspose2d(kernel_size=2, stride=2) (upconv2x2, alto.py:175,215-218,236) on csrc/conv.hip."""
 
@@ -510,6 +546,15 @@ class _UpConv2x2(torch.autograd.Function):
             if addend.shape != y.shape:
                 raise ValueError("upconv2x2: addend must have the output's shape")
         ctx.has_addend = addend is not None
+        ctx.bx3 = _up_bx3(x, weight, w)
+        if ctx.bx3:
+            _lib.call("t2h_upconv2x2_bx3_fwd", _lib.ptr(x), _lib.ptr(split_weights.get_up(w, True)),
+                      _lib.ptr(bias) if bias is not None else None, _lib.ptr(addend) if addend is not None else None, _lib.ptr(y),
+                      b, h, wd, cin, cout, 0, _lib.stream(),
+                      nbytes=4 * (x.numel() + y.numel() * (2 if addend is not None else 1)) + 6 * w.numel(),
+                      flops=2 * 4 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_upconv2x2_bx3_fwd[{cin}->{cout},{h}x{wd}]")
+            ctx.save_for_backward(x, weight, bias)
+            return y
         _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias) if bias is not None else None,
                   _lib.ptr(addend) if addend is not None else None, _lib.ptr(y),
                   b, h, wd, cin, cout, 0, _lib.stream(),
@@ -530,6 +575,14 @@ class _UpConv2x2(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=torch.channels_last)
+        if dx is not None and ctx.bx3:
+            nws = _lib.ws_bytes("t2h_upconv2x2_bx3_dgrad_workspace_bytes", b, h, wd, cin, cout)
+            ws = _lib.workspace(nws, g.device)
+            _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(g), _lib.ptr(split_weights.get_up(w, False)), _lib.ptr(dx),
+                      b, h, wd, cin, cout, 0, _lib.ptr(ws), nws, _lib.stream(),
+                      nbytes=4 * (g.numel() + dx.numel()) + 6 * w.numel(), flops=flops,
+                      tag=_lib.timing() and f"t2h_upconv2x2_bx3_dgrad[{cout}->{cin},{h}x{wd}]")
+        elif dx is not None:
             nws = _lib.ws_bytes("t2h_upconv2x2_dgrad_workspace_bytes", b, h, wd, cin, cout)
             ws = _lib.workspace(nws, g.device)
             _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(g), _lib.ptr(w), _lib.ptr(dx), b, h, wd, cin, cout, 0, _lib.ptr(ws), nws,
