@@ -399,12 +399,17 @@ int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, con
  * tensor in [Cin][2][2][Cout] memory order IS the matrix [Cin][4 Cout]: split it with t2h_gemm_bx3_prepare(w, 4 Cout, K = Cin,
  * N = 4 Cout, w_is_kn = 1) for the forward and (w, 4 Cout, K = 4 Cout, N = Cin, w_is_kn = 0) for the data gradient.
  * H, W powers of two, B H W % 128 == 0, Cin % 64 == 0, Cout % 64 == 0 (t2h_upconv2x2_bx3_supported).  Replaces
- * t2h_upconv2x2_fwd_add / t2h_upconv2x2_dgrad where supported; the weight gradient stays on t2h_upconv2x2_wgrad_bias. */
+ * t2h_upconv2x2_fwd_add / t2h_upconv2x2_dgrad where supported.  The weight gradient dW[ci][tap][co] = sum_p x[p][ci] dy[up(p, tap)][co]
+ * (and db = column sums of dy) is bx3_wgrad_kernel with the roles swapped and 4 taps (W >= 32 in addition; same flags, workspace and
+ * slab reduction as t2h_conv3x3_bx3_wgrad); replaces t2h_upconv2x2_wgrad_bias. */
 int t2h_upconv2x2_bx3_supported(int B, int H, int W, int Cin, int Cout);
 int t2h_upconv2x2_bx3_fwd(const float *x, const void *wf, const float *bias, const float *addend, float *y, int B, int H, int W,
                           int Cin, int Cout, int flags, t2h_stream_t stream);
 size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+                            void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+size_t t2h_upconv2x2_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout, int flags,
                             void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* Batched slab reductions.  Every weight-gradient entry point (t2h_linear_wgrad, t2h_conv3x3_wgrad, t2h_conv3x3_bx3_wgrad,

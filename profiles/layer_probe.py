@@ -96,7 +96,10 @@ if args.only in ("", "upconv"):
         fl = 2.0 * 4 * cin * cout * h * h
         wf, wft = grid.split_weights.get_up(w, True), grid.split_weights.get_up(w, False)
         ws_b = _lib.workspace(lib.t2h_upconv2x2_bx3_dgrad_workspace_bytes(1, h, h, cin, cout), dev)
+        ws_bw = _lib.workspace(lib.t2h_upconv2x2_bx3_wgrad_workspace_bytes(1, h, h, cin, cout), dev)
+        db = torch.empty(cout, device=dev)
         for name, fn in (
+                ("bx3_wgrad", lambda: _lib.call("t2h_upconv2x2_bx3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), 1, h, h, cin, cout, 0, _lib.ptr(ws_bw), ws_bw.numel(), _lib.stream())),
                 ("bx3_fwd", lambda: _lib.call("t2h_upconv2x2_bx3_fwd", _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
                 ("bx3_dgrad", lambda: _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(gy), _lib.ptr(wft), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_b), ws_b.numel(), _lib.stream())),
                 ("fwd", lambda: _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),

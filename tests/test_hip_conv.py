@@ -464,8 +464,12 @@ def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, monkeypatch):
             y = grid.upconv2x2(xg, conv, ag)
             y.backward(_cl(gout))
         torch.cuda.synchronize()
-        names = [r[5] for r in tl.records if r[5].startswith("bx3_rows_kernel")]
-        assert (len(names) == 2 and names[0].endswith(",64,3,1,1>") and names[1].endswith(",64,3,1,2>")) if on else not names, names
+        names = [r[5] for r in tl.records if r[5].startswith("bx3_")]
+        if on:
+            assert names[0].endswith(",64,3,1,1>") and names[1].endswith(",64,3,1,2>"), names
+            assert names[2:] == ([f"bx3_wgrad_kernel<{4 if cin % 128 == 0 else 2},3,true>"] if w >= 32 else []), names
+        else:
+            assert not names, names
         outs[on] = (y.detach().clone(), xg.grad.clone(), ag.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
     for on in (True, False):
         y, dx, da, dw, db = outs[on]
@@ -474,6 +478,14 @@ def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, monkeypatch):
         assert torch.equal(da.cpu(), gout)
         _close(dw, ref.weight.grad)
         _close(db, ref.bias.grad)
+    # direct accumulation into .grad: same slabs, same order -> exact doubling
+    from tomosar2height_amd import mlp
+    monkeypatch.setattr(grid, "UPCONV_BX3", True)
+    wbuf, bbuf = conv.weight.grad, conv.bias.grad
+    conv.weight.grad.copy_(outs[True][3]); conv.bias.grad.copy_(outs[True][4])
+    with mlp.direct_grad_accumulation(True):
+        grid.upconv2x2(_cl(x).requires_grad_(True), conv, None).backward(_cl(gout))
+    assert conv.weight.grad is wbuf and torch.equal(wbuf, outs[True][3] * 2) and torch.equal(bbuf, outs[True][4] * 2)
     # the split product is exact to fp32 rounding of the accumulation: both paths sit at the same distance from float64
     for i in (0, 1):
         e_on = (outs[True][i].double().cpu() - (yr.detach(), xr.grad)[i]).abs().max().item()

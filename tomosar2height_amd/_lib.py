@@ -98,6 +98,8 @@ SIGNATURES = {
     "t2h_upconv2x2_bx3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_bx3_dgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "t2h_upconv2x2_bx3_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_upconv2x2_bx3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "t2h_upconv2x2_bx3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_gemm_bx3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_reduce_capture_begin": (_i, []),
     "t2h_reduce_capture_pending": (_i, []),

@@ -359,13 +359,19 @@ struct WgradArgs {
 
 // COT = 32-channel tiles of Cout per workgroup (4, 2 or 1): the workgroup's (COT x 9) output tiles are dealt to the four waves
 // as (co tile, contiguous tap range)
-template <int COT, int NPL>
+// UP: the weight gradient of ConvTranspose2d(2, stride 2), dW[ci][tap][co] = sum_p x[p][ci] dy[up(p, tap)][co] -- the same kernel with
+// the roles swapped: p.dy = the layer's INPUT x (the 32 x 32 COT "row" side, no halo), p.x = the layer's output gradient, whose two
+// rows x 64 pixels above a unit's 32 input pixels are staged de-interleaved as [tap][32 pixels] (so a tap reads exactly like a 3 x 3
+// tap does), 4 taps instead of 9; p.Cout / p.Cin are the channel counts of those roles (the layer's Cin / Cout), p.H / p.W the INPUT
+// plane.  The column sums (bias gradient) are then those of the tap side.
+template <int COT, int NPL, bool UP = false>
 __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
+    constexpr int NTAPS = UP ? 4 : 9;
     constexpr int WPC = 4 / COT;                                         // waves per co tile
-    constexpr int TMAX = (9 + WPC - 1) / WPC;                            // taps per wave, at most
+    constexpr int TMAX = (NTAPS + WPC - 1) / WPC;                        // taps per wave, at most
     constexpr int YS = COT == 1 ? 64 : 64 * COT + 64;                    // dY image: bytes per pixel row (4 rows tile the bank row)
     constexpr int XS = 64;                                               // X image: 32 bf16 per pixel, no padding
-    constexpr int YPLANE = 32 * YS, XHP = 3 * (TW + 2), XPLANE = XHP * XS;
+    constexpr int YPLANE = 32 * YS, XHP = UP ? 4 * TW : 3 * (TW + 2), XPLANE = XHP * XS;
     constexpr int LDS_WORK = NPL * YPLANE + NPL * XPLANE;
     constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (epilogue patches, column-sum scratch)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     const int segs = p.W / TW;
 
     const int cot = wave / WPC, sub = wave % WPC;                         // this wave's co tile and tap range
-    const int tap_lo = (9 * sub + WPC - 1) / WPC, tap_hi = (9 * (sub + 1) + WPC - 1) / WPC;
+    const int tap_lo = (NTAPS * sub + WPC - 1) / WPC, tap_hi = (NTAPS * (sub + 1) + WPC - 1) / WPC;
 
     // staging registers: X halo 3 x 34 pixels x 8 float4; dY 32 pixels x (8 COT) float4
     constexpr int XF4 = XHP * 8, XPER = (XF4 + NT - 1) / NT;
@@ -393,7 +399,9 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
             const int gy = y + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < XF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+            if (UP) {      // px = (output row parity, 64 output pixels): rows 2 row, 2 row + 1 of the [*, 2 W] plane, columns 2 x0 ..
+                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(2 * row + (px >> 6)) * (2 * p.W) + 2 * x0 + (px & 63)) * p.Cin + ci0 + c4 * 4);
+            } else if (idx < XF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
                 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(row + hy - 1) * p.W + gx) * p.Cin + ci0 + c4 * 4);
             xr[f] = v;
         }
@@ -405,13 +413,18 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
         }
     };
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool do_colsum = p.colslab != nullptr && blockIdx.y == 0;
+    const bool do_colsum = p.colslab != nullptr && (UP ? blockIdx.z == 0 : blockIdx.y == 0);
     auto store_unit = [&]() {
 #pragma unroll
         for (int f = 0; f < XPER; ++f) {
             const int idx = tid + f * NT;
             if (idx < XF4) {
-                const int px = idx >> 3, c4 = idx & 7;
+                const int c4 = idx & 7;
+                int px = idx >> 3;
+                if (UP) {                                                // (row parity, column 2 i + dx) -> slot [tap = 2 dy + dx][i]
+                    px = ((px >> 6) * 2 + (px & 1)) * TW + ((px & 63) >> 1);
+                    if (do_colsum) { csum.x += xr[f].x; csum.y += xr[f].y; csum.z += xr[f].z; csum.w += xr[f].w; }
+                }
                 unsigned a1, a2, a3, b1, b2, b3;
                 split3(xr[f].x, xr[f].y, a1, a2, a3);
                 split3(xr[f].z, xr[f].w, b1, b2, b3);
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
                 *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
                 *reinterpret_cast<uint2 *>(d + 2 * YPLANE) = make_uint2(a3, b3);
             }
-            if (do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
+            if (!UP && do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
         }
     };
 
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
                 const int tap = tap_lo + t;
                 if (tap < tap_hi) {                                       // wave-uniform
                     const int ky = tap / 3, kx = tap - 3 * ky;
-                    const unsigned char *xa = ximg + (ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
+                    const unsigned char *xa = ximg + (UP ? tap * TW + 16 * s + kpix : ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
                     bf16x8 bfr[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
@@ -494,11 +507,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
         float4 *red = reinterpret_cast<float4 *>(lds);
         red[tid] = csum;
         __syncthreads();
-        constexpr int CG = 8 * COT;
+        constexpr int CG = UP ? 8 : 8 * COT;
         if (tid < CG) {
             float4 tsum = red[tid];
             for (int j = tid + CG; j < NT; j += CG) { tsum.x += red[j].x; tsum.y += red[j].y; tsum.z += red[j].z; tsum.w += red[j].w; }
-            *reinterpret_cast<float4 *>(p.colslab + (size_t)split * p.Cout + co0 + tid * 4) = tsum;
+            if (UP) *reinterpret_cast<float4 *>(p.colslab + (size_t)split * p.Cin + ci0 + tid * 4) = tsum;
+            else *reinterpret_cast<float4 *>(p.colslab + (size_t)split * p.Cout + co0 + tid * 4) = tsum;
         }
         __syncthreads();
     }
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     // slab tile (co tile, tap): rows co, columns tap * Cin + ci0 .. + 31
     float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4, r = lane & 31, h = lane >> 5;
-    float *sbase = p.slab + (size_t)split * p.Cout * 9 * p.Cin;
+    float *sbase = p.slab + (size_t)split * p.Cout * NTAPS * p.Cin;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
         const int tap = tap_lo + t;
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             for (int pass = 0; pass < 4; ++pass) {
                 const float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
                 const int co = co0 + cot * 32 + pass * 8 + er;
-                *reinterpret_cast<float4 *>(sbase + ((size_t)co * 9 + tap) * p.Cin + ci0 + ec) = v;
+                *reinterpret_cast<float4 *>(sbase + ((size_t)co * NTAPS + tap) * p.Cin + ci0 + ec) = v;
             }
         }
     }
@@ -861,4 +875,51 @@ T2H_API int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx
     a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
     return launch_rows(a, false, workspace, workspace_bytes, as_stream(stream), "upconv2x2_bx3_dgrad", 1, 2);
+}
+
+static WgradPlan up_wgrad_plan(int B, int H, int W, int Cin, int Cout) {
+    // roles swapped: the 32 COT-wide side is the layer's Cin, the 32-channel chunks (CC) its Cout; ~256 workgroups
+    WgradPlan p{};
+    p.cot = Cin % 128 == 0 ? 4 : 2;
+    p.n_units = (int)((long long)B * H * W / TW);
+    const long long groups = (long long)(Cout / CC) * (Cin / (32 * p.cot));
+    static const long long forced = getenv("T2H_BX3_UPWGRAD_WGS") ? atoll(getenv("T2H_BX3_UPWGRAD_WGS")) : 0;
+    long long splits = (forced > 0 ? forced : 256) / groups;
+    if (splits < 1) splits = 1;
+    if (splits > p.n_units) splits = p.n_units;
+    p.units_per_split = (int)((p.n_units + splits - 1) / splits);
+    p.splits = (p.n_units + p.units_per_split - 1) / p.units_per_split;
+    return p;
+}
+
+T2H_API size_t t2h_upconv2x2_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_upconv2x2_bx3_supported(B, H, W, Cin, Cout) || W < TW) return 0;
+    const WgradPlan p = up_wgrad_plan(B, H, W, Cin, Cout);
+    return (size_t)p.splits * ((size_t)Cin * 4 * Cout + Cout) * sizeof(float);
+}
+
+T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
+                                    int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: null pointer");
+    if (int rc = check_up_bx3("upconv2x2_bx3_wgrad", B, H, W, Cin, Cout)) return rc;
+    if (W < TW) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: W=%d below the %d-pixel unit", W, TW);
+    if (!al16(dy) || !al16(x)) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: pointers must be 16-byte aligned");
+    const size_t need = t2h_upconv2x2_bx3_wgrad_workspace_bytes(B, H, W, Cin, Cout);
+    if (!workspace || workspace_bytes < need || !al16(workspace))
+        return fail(T2H_ERR_WORKSPACE, "upconv2x2_bx3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    const WgradPlan p = up_wgrad_plan(B, H, W, Cin, Cout);
+    const int Ncols = 4 * Cout;
+    float *slab = static_cast<float *>(workspace);
+    float *colslab = slab + (size_t)p.splits * Cin * Ncols;
+    WgradArgs a{};
+    a.dy = x; a.x = dy; a.slab = slab; a.colslab = db ? colslab : nullptr;           // (roles swapped, see the kernel)
+    a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
+    dim3 grid(p.splits, Cout / CC, Cin / (32 * p.cot));
+    if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: too many channel chunks");
+    if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,true>"); }
+    else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,true>"); }
+    if (int rc = check_launch("upconv2x2_bx3_wgrad")) return rc;
+    return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
+                               p.splits, Cout, (flags & T2H_DEFER_REDUCE) != 0);
 }

@@ -593,13 +593,14 @@ class _UpConv2x2(torch.autograd.Function):
                   and (bias is None or (bg is not None and bg.is_contiguous())))
         dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
         db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
-        nws = _lib.ws_bytes("t2h_upconv2x2_wgrad_workspace_bytes", b, h, wd, cin, cout)
+        up = "t2h_upconv2x2_bx3_wgrad" if (ctx.bx3 and BX3_WGRAD and wd >= 32) else "t2h_upconv2x2_wgrad_bias"
+        nws = _lib.ws_bytes(up.replace("_bias", "") + "_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, g.device)
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
-        _lib.call("t2h_upconv2x2_wgrad_bias", _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
+        _lib.call(up, _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
                   b, h, wd, cin, cout, (_lib.ACCUM | _lib.defer_reduce(ws)) if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
-                  tag=_lib.timing() and f"t2h_upconv2x2_wgrad[{cin}->{cout},{h}x{wd}]")
+                  tag=_lib.timing() and f"{up}[{cin}->{cout},{h}x{wd}]")
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
