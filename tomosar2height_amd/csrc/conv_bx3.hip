@@ -309,42 +309,75 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
     float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.ldy);     // (split == 0 unless the reduction is split)
+    // What the epilogue READS from global memory (ReLU mask, the old values under T2H_ACCUM, the residual addend of the transposed
+    // convolution) is fetched one 32 x 32 tile ahead of the tile being written: issued inside the pass loop each load's latency was
+    // exposed once per pass -- 4 TM TN dependent round trips per workgroup, 60 us of the 260 us 512^2 data gradients.
+    constexpr int T = TM * TN;
+    float4 pre_m[2][4], pre_o[2][4];
+    auto tile_off = [&](int t, int pass, int &col_out, int &up_co) -> size_t {
+        const int i = t / TN, j = t % TN;
+        const int col = n0 + (wn * TN + j) * 32 + ec;
+        const size_t pix = ((size_t)b * p.H + y0 + wm * TM + i) * p.W + x0 + pass * 8 + er;
+        col_out = col;
+        if (UPM == 1) {      // scatter: row = input pixel, column tile = (tap, 32 channels) -> output pixel up(row, tap)
+            const int up_tap = col / p.up_cout;
+            up_co = col - up_tap * p.up_cout;
+            return up_pixel((long long)pix, up_tap, p.up_logW, p.up_logH) * p.up_cout + up_co;
+        }
+        up_co = col;
+        return pix;
+    };
+    auto prefetch = [&](int t, float4 (&m)[4], float4 (&o)[4]) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + ec;
-#pragma unroll
-            for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int up_tap = UPM == 1 ? col / p.up_cout : 0, up_co = UPM == 1 ? col - up_tap * p.up_cout : col;
-            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + up_co);
-            const size_t pix0 = ((size_t)b * p.H + y0 + wm * TM + i) * p.W + x0;
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
-                if (UPM == 1) {      // scatter: row = input pixel, column tile = (tap, 32 channels) -> output pixel up(row, tap)
-                    const size_t o = up_pixel((long long)(pix0 + pass * 8 + er), up_tap, p.up_logW, p.up_logH) * p.up_cout + up_co;
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    float4 *dst = reinterpret_cast<float4 *>(p.y + o);
-                    if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
-                    if (p.addend) { const float4 ad = *reinterpret_cast<const float4 *>(p.addend + o); v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
-                    *dst = v;
-                    continue;
-                }
-                const size_t o = (pix0 + pass * 8 + er) * p.ldy + col;
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                if (p.mask) {
-                    const float4 mk = *reinterpret_cast<const float4 *>(p.mask + (pix0 + pass * 8 + er) * p.ldm + col);
-                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-                }
-                if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
-                float4 *dst = reinterpret_cast<float4 *>(ybase + o);
-                if (accum) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
-                *dst = v;
+        for (int pass = 0; pass < 4; ++pass) {
+            int col, co;
+            const size_t q = tile_off(t, pass, col, co);
+            if (UPM == 1) {
+                if (p.addend) m[pass] = *reinterpret_cast<const float4 *>(p.addend + q);
+                if (accum) o[pass] = *reinterpret_cast<const float4 *>(p.y + q);
+            } else {
+                if (p.mask) m[pass] = *reinterpret_cast<const float4 *>(p.mask + q * p.ldm + col);
+                if (accum) o[pass] = *reinterpret_cast<const float4 *>(ybase + q * p.ldy + col);
             }
         }
+    };
+    prefetch(0, pre_m[0], pre_o[0]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int i = t / TN, j = t % TN;
+        if (t + 1 < T) prefetch(t + 1, pre_m[(t + 1) & 1], pre_o[(t + 1) & 1]);
+#pragma unroll
+        for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            int col, co;
+            tile_off(t, 0, col, co);
+            if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + co);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
+            int col, co;
+            const size_t q = tile_off(t, pass, col, co);
+            const float4 mk = pre_m[t & 1][pass], old = pre_o[t & 1][pass];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (UPM == 1) {
+                float4 *dst = reinterpret_cast<float4 *>(p.y + q);
+                if (accum) { v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                if (p.addend) { v.x += mk.x; v.y += mk.y; v.z += mk.z; v.w += mk.w; }
+                *dst = v;
+                continue;
+            }
+            if (p.mask) {
+                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            }
+            if (relu) { v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w); }
+            float4 *dst = reinterpret_cast<float4 *>(ybase + q * p.ldy + col);
+            if (accum) { v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+            *dst = v;
+        }
+    }
 }
 
 // ---- wgrad ----------------------------------------------------------------------------------------------------------------------
