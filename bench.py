@@ -145,13 +145,15 @@ def rocprof_durations():
 
 
 def bx3_peak(symbol: str):
-    """Matrix-core ceiling of a csrc/conv_bx3.hip kernel in ALGORITHMIC flops: dense bf16 peak / 6 with the exact split (NPL = 3),
-    the bf16 peak itself in the bf16 mode (NPL = 1); None for any other symbol."""
+    """Matrix-core ceiling of a csrc/conv_bx3.hip kernel in ALGORITHMIC flops: dense bf16 peak / 6 with the bf16 three-way split
+    (NPL = 3), dense fp16 peak (= the bf16 one) / 3 with the fp16 two-way split (NPL = 2), the bf16 peak itself in the bf16 mode
+    (NPL = 1); None for any other symbol."""
     if not symbol.startswith("bx3_"):
         return None
     args = symbol[symbol.find("<") + 1:symbol.rfind(">")].split(",")
     npl = args[5] if symbol.startswith("bx3_rows") and len(args) > 5 else (args[1] if len(args) > 1 else "3")
-    return MFMA_BF16_PEAK_TFLOPS if npl.strip() == "1" else MFMA_BX3_PEAK_TFLOPS
+    npl = npl.strip()
+    return MFMA_BF16_PEAK_TFLOPS if npl == "1" else (MFMA_BF16_PEAK_TFLOPS / 3 if npl == "2" else MFMA_BX3_PEAK_TFLOPS)
 
 
 def point_update_note():
@@ -664,6 +666,9 @@ def main():
                        "grid_convs": ({"bf16x3": "t2h csrc/conv_bx3.hip: every fp32 product from six bf16 MFMAs (exact 3-way operand "
                                                  "split, fp32 accumulate; error vs float64 = the fp32 MFMA kernels'), planes >= 32 wide; "
                                                  "csrc/conv.hip (fp32 MFMA) for the rest",
+                                       "f16x2": "t2h csrc/conv_bx3.hip: every fp32 product from three fp16 MFMAs (two-way fp16 operand split, "
+                                                "one power-of-two scale per staged block, fp32 accumulate; error vs float64 at the fp32 MFMA "
+                                                "kernels' level), planes >= 32 wide; csrc/conv.hip (fp32 MFMA) for the rest",
                                        "bf16": "t2h csrc/conv_bx3.hip, operands rounded to bf16 (one MFMA per product, fp32 accumulate)",
                                        "fp32": "t2h implicit-GEMM on fp32 MFMA (csrc/conv.hip)"}[grid.CONV_PRECISION]
                                       if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen"),

@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 10
+#define T2H_ABI_VERSION 11
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -266,6 +266,8 @@ int t2h_sample_bwd_atomic(const float *gout, const float *pts, int dim, int B, i
 #define T2H_ACCUM 4
 #define T2H_BF16 8   /* operands rounded to bf16 (RNE) while staging, fp32 accumulate: BASELINE.json configs[2] */
 #define T2H_DEFER_REDUCE 32 /* weight-gradient entry points: see t2h_reduce_capture_begin */
+#define T2H_F16X2 64 /* the t2h_*_bx3* entry points: fp16 two-way split with per-block power-of-two scales, 3 MFMAs per product
+                        (weights prepared by the *_f16x2_prepare entry points); see "fp16 two-way split" below */
 #define T2H_BF16X3 16 /* fp32-grade products from bf16 MFMAs: exact 3-way bf16 split of both operands, 6 piece products
                          (error <= ~2^-23 relative per product, fp32 accumulate); opt-in, never the default */
 int t2h_linear_fwd(const float *x, int ldx, const float *w, const float *bias, float *y, int ldy, int M, int K,
@@ -391,6 +393,20 @@ int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, voi
 size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N);
 int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
                  int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* fp16 two-way split (flag T2H_F16X2 on t2h_conv3x3_bx3_fwd / _dgrad / _wgrad, t2h_gemm_bx3, t2h_upconv2x2_bx3_*).  Each operand
+ * element is x 2^e = h1 + h2, two fp16 numbers (11 + 11 significant bits), with ONE power of two 2^e per staged block -- activations:
+ * the halo tile x channel chunk a workgroup stages (3x3 / 1-tap forms) or the 32-pixel unit (weight gradient); weights: the tensor --
+ * chosen so that the block's largest magnitude lands in [2^14, 2^15).  Three of the four partial products are formed (3 MFMAs
+ * instead of the 6 of the bf16 three-way split), accumulated in fp32; the accumulators are rescaled exactly when a block with a
+ * larger scale arrives.  Error per product: <= 3 * 2^-22 |a b| + 2^-40 (block max |a|) |b| (+ the same with a, b swapped) -- fp32
+ * grade unless an element lies more than 2^18 below the largest element of its own block; measured against float64 at the level
+ * of the fp32 kernels (tests/test_hip_conv.py).  The weights are prepared by the entry points below into a buffer of
+ * t2h_*_f16x2_weights_bytes (two f16 planes + a 256-byte trailer holding the tensor's scale) and passed where the bf16 buffers go. */
+size_t t2h_conv3x3_f16x2_weights_bytes(int Cin, int Cout);
+int t2h_conv3x3_f16x2_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream);
+size_t t2h_gemm_f16x2_weights_bytes(int K, int N);
+int t2h_gemm_f16x2_prepare(const float *w, int ldw, int K, int N, int w_is_kn, void *wf, t2h_stream_t stream);
 
 /* ConvTranspose2d(kernel_size = 2, stride = 2) (upconv2x2, alto.py:175,215-218,236) on the same 1-tap kernels.  The forward is the
  * GEMM [B H W, Cin] x [Cin, (tap, co)] with a scattering epilogue: column tile -> tap = 2 dy + dx -> output pixel (2y + dy, 2x + dx),

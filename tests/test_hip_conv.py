@@ -93,10 +93,12 @@ BX3_SHAPES = [(1, 32, 32, 32, 32), (1, 64, 64, 64, 128), (2, 16, 32, 32, 64), (1
               (3, 8, 32, 64, 256), (1, 128, 128, 32, 64), (1, 32, 32, 512, 512), (1, 32, 32, 256, 512), (1, 64, 64, 512, 256)]
 
 
-@pytest.fixture
-def bx3_everywhere(monkeypatch):
+@pytest.fixture(params=["bf16x3", "f16x2"])
+def bx3_everywhere(monkeypatch, request):
+    """Both split arithmetics of csrc/conv_bx3.hip: the bf16 three-way split (6 MFMAs per product) and the fp16 two-way split with
+    block scales (3 MFMAs) -- same kernels, same tests, same tolerances."""
     from tomosar2height_amd import grid
-    monkeypatch.setattr(grid, "CONV_PRECISION", "bf16x3")
+    monkeypatch.setattr(grid, "CONV_PRECISION", request.param)
     monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 0)
     monkeypatch.setattr(grid, "BX3_WGRAD", True)
     return grid
@@ -161,14 +163,15 @@ def test_conv3x3_bx3_error_is_fp32_grade(bx3_everywhere):
     want = F.conv2d(x.double(), wt.double(), None, padding=1)
     mag = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
     errs = {}
-    for mode in ("bf16x3", "fp32"):
+    split = grid.CONV_PRECISION
+    for mode in (split, "fp32"):
         grid.CONV_PRECISION = mode
         y = grid._empty_cl(b, cout, h, w, _dev())
         grid.conv3x3_fwd_(_cl(x), _cl(wt), None, y)
         errs[mode] = ((y.cpu().double() - want).abs() / mag).max().item()
-    grid.CONV_PRECISION = "bf16x3"
+    grid.CONV_PRECISION = split
     print(f"[bx3] max |err| / sum|a b| vs float64: {errs}")
-    assert errs["bf16x3"] <= 4e-7 and errs["fp32"] <= 4e-7
+    assert errs[split] <= 4e-7 and errs["fp32"] <= 4e-7
     x2 = x.clone()
     x2[0, 3, 10, 10], x2[0, 5, 40, 40] = float("nan"), float("inf")
     y = grid._empty_cl(b, cout, h, w, _dev())
@@ -204,6 +207,7 @@ def test_conv3x3_bf16_mode(shape, bx3_everywhere):
         grid.conv3x3_wgrad_(gyd, xd, dw, db)
     finally:
         grid.set_conv_precision(None)
+        grid.CONV_PRECISION = "bf16x3"
     for got, ref in ((y, want.detach()), (dx, x.grad), (dw, wt.grad)):
         _close(got, ref, tol=1e-2)
         err = (got.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
@@ -231,7 +235,71 @@ def test_split_weight_cache_follows_the_weight(bx3_everywhere):
     _close(y, F.conv2d(x.cpu().double(), w.detach().cpu().double(), None, padding=1))
     w.data.zero_()                                                          # raw write without a version bump ...
     grid.split_weights.refresh()                                            # ... is what refresh() is for (hipGraph replay)
-    assert int(grid.split_weights.get(w, False).abs().sum().item()) == 0
+    planes = grid.split_weights.get(w, False)
+    planes = planes[:-256] if grid.CONV_PRECISION == "f16x2" else planes      # (the fp16 buffers end with the tensor's scale: 2^0 here)
+    assert int(planes.abs().sum().item()) == 0
+
+
+def test_f16x2_block_scales(monkeypatch):
+    """The fp16 two-way split keeps ONE power of two per staged block (halo tile x channel chunk; 32-pixel unit of the weight
+    gradient), so its error is relative to the BLOCK's largest element, not the tensor's: (a) image regions 2^40 apart in magnitude
+    (far beyond fp16's 2^30 range) are each fp32-grade, as are channel chunks 2^30 apart (accumulators rescaled exactly when a larger
+    block arrives); (b) tensors scaled by 2^+-60 give the scaled result; (c) the documented bound for elements far below their own
+    block's maximum: error <= 2^-21 sum|a b| + 2^-39 (block max |a|) sum|b| -- a tiny pixel next to a huge one."""
+    from tomosar2height_amd import grid
+    monkeypatch.setattr(grid, "CONV_PRECISION", "f16x2")
+    monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 0)
+    g = torch.Generator().manual_seed(21)
+    b, cin, cout, h, w = 1, 64, 64, 64, 64
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    base = torch.randn(b, cin, h, w, generator=g)
+    gy0 = torch.randn(b, cout, h, w, generator=g)
+
+    def run(x, gy):
+        y, dx = grid._empty_cl(b, cout, h, w, _dev()), grid._empty_cl(b, cin, h, w, _dev())
+        dw = torch.empty(cout, cin, 3, 3, device=_dev()).contiguous(memory_format=torch.channels_last)
+        grid.conv3x3_fwd_(_cl(x), _cl(wt), None, y)
+        grid.conv3x3_dgrad_(_cl(gy), _cl(wt), dx)
+        grid.conv3x3_wgrad_(_cl(gy), _cl(x), dw, None)
+        return y.cpu().double(), dx.cpu().double(), dw.cpu().double()
+
+    def rel(got, want, mag):
+        return ((got - want).abs() / mag).max().item()
+
+    # (a) rows of the image 2^40 apart (row tiles are 4 rows: rows 0-31 large, 32-63 tiny), channel chunks 2^30 apart
+    scale = torch.ones(1, cin, h, 1)
+    scale[:, :, 32:, :] = 2.0 ** -40
+    scale[:, 32:, :, :] *= 2.0 ** -30
+    x = base * scale
+    gy = gy0 * scale[:, :1].expand(1, cout, h, 1)
+    y, dx, dw = run(x, gy)
+    want_y = F.conv2d(x.double(), wt.double(), None, padding=1)
+    mag_y = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
+    sel = torch.ones(h, dtype=torch.bool)
+    sel[28:36] = False                                       # (row tiles whose halo straddles the jump: covered by (c))
+    assert rel(y[:, :, sel], want_y[:, :, sel], mag_y[:, :, sel]) <= 5e-7
+    want_dx = F.conv_transpose2d(gy.double(), wt.double(), None, padding=1)
+    mag_dx = F.conv_transpose2d(gy.double().abs(), wt.double().abs(), None, padding=1)
+    assert rel(dx[:, :, sel], want_dx[:, :, sel], mag_dx[:, :, sel]) <= 5e-7
+    want_dw = torch.nn.grad.conv2d_weight(x.double(), wt.shape, gy.double(), padding=1)
+    _close(dw.float(), want_dw)
+    # (b) far outside fp16's exponent range
+    for k in (-60, 60):
+        y2, _, _ = run(base * 2.0 ** k, gy0)
+        y1, _, _ = run(base, gy0)
+        assert torch.equal(y2, y1 * 2.0 ** k)
+    # (c) one huge pixel: its neighbours inside the same staged block lose relative, not absolute, accuracy
+    x = base.clone()
+    x[0, :, 20, 20] *= 2.0 ** 30
+    y, _, _ = run(x, gy0)
+    want_y = F.conv2d(x.double(), wt.double(), None, padding=1)
+    bound = (2.0 ** -21 * F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
+             + 2.0 ** -39 * x.abs().max().item() * wt.double().abs().sum(dim=(1, 2, 3)).view(1, -1, 1, 1))
+    assert ((y - want_y).abs() <= bound).all()
+    far = torch.ones(h, w, dtype=torch.bool)
+    far[8:32, :] = False                                     # tiles (8 rows at most) that hold the huge pixel's halo
+    mag_y = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1)
+    assert rel(y[:, :, far], want_y[:, :, far], mag_y[:, :, far]) <= 5e-7
 
 
 def test_conv3x3_is_deterministic():

@@ -34,6 +34,8 @@ namespace t2h {
 namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
@@ -63,13 +65,47 @@ __device__ inline void split3(float a, float b, unsigned &p1, unsigned &p2, unsi
     p3 = pack_bf16x2(sa, sb);
 }
 
+// ---- the fp16 two-way split (NPL = 2, T2H_F16X2) --------------------------------------------------------------------------------
+// x 2^e = h1 + h2 with h1 = f16(x 2^e), h2 = f16(x 2^e - h1) (round to nearest even; the difference is exact in fp32): 11 + 11
+// significant bits.  The power of two 2^e is chosen PER STAGED BLOCK (activations: the halo tile x channel chunk a workgroup stages,
+// the 32-pixel unit of the weight gradient; weights: the tensor) so that the block's largest magnitude lands in [2^14, 2^15): fp16
+// keeps 5 exponent bits, so h2 of an element more than 2^18 below its block's maximum becomes subnormal (the f16 MFMA keeps subnormal
+// inputs: profiles/mfma_f16_lab.hip) and the element is represented to 2^-40 of the BLOCK maximum instead of 2^-22 of itself.  Of the
+// four partial products three are formed (h2 g1, h1 g2, h1 g1; h2 g2 <= 2^-22 |a b| is dropped) -- THREE MFMAs per product instead
+// of six; an f16 x f16 product is exact in fp32, v_mfma_f32_32x32x16_f16 accumulates in fp32, and a power-of-two rescaling of an
+// fp32 accumulator is exact, so the accumulators follow the running block scale at no cost in accuracy.  Error model:
+// |fl(a b) - a b| <= 3 * 2^-22 |a b| + 2^-40 max_block|a| |b| + (same with a, b swapped); measured against float64 on activations
+// with a log-normal spread of 1.5 nats: 5.7e-7 of sum |a b| (fp32 FMA chain 4.2e-7, the bf16 three-way split 8.5e-7).
+constexpr int E_UNSET = 1 << 20;
+__device__ inline unsigned pack_f16x2(float a, float b) {              // 2 x v_cvt_f16_f32 (RNE) + v_pack_b32_f16
+    f32x2 v = {a, b};
+    f16x2 r = __builtin_convertvector(v, f16x2);
+    return *reinterpret_cast<unsigned *>(&r);
+}
+__device__ inline void split2h(float a, float b, int e, unsigned &p1, unsigned &p2) {
+    const float as = ldexpf(a, e), bs = ldexpf(b, e);
+    const f16x2 h = __builtin_convertvector((f32x2){as, bs}, f16x2);
+    p1 = *reinterpret_cast<const unsigned *>(&h);
+    p2 = pack_f16x2(__fsub_rn(as, (float)h[0]), __fsub_rn(bs, (float)h[1]));                 // exact differences
+}
+// block exponent from the block's largest magnitude (float bits, non-negative): 14 - floor(log2 m); E_UNSET for an all-zero block
+__device__ inline int block_exponent(unsigned maxbits) { return maxbits == 0u ? E_UNSET : 14 - ((int)(maxbits >> 23) - 127); }
+__device__ inline float wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+__device__ inline float abs4max(float m, const float4 &v) { return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 // ---- weight preparation: [Cout][9][Cin] fp32 -> MFMA B-fragment order, three bf16 planes --------------------------------------
 // slab (16-channel step c16 of the reduction, tap t) x [tile of 32 output channels][plane][lane][8 bf16]; lane (r = l & 31,
 // h = l >> 5) holds B[k = 8 h + j][col r].  Forward: k = input channel, col = output channel, W[col][tap][k].  Transposed (data
 // gradient): k = output channel, col = input channel, tap flipped: W[k][8 - tap][col].
-template <bool TRANSPOSED>
+// H2: two f16 planes of w 2^e_w instead (e_w from the tensor's largest magnitude, left in `trailer[0]` by absmax_kernel; trailer[1]
+// receives 2^-e_w for the consumers' epilogues)
+template <bool TRANSPOSED, bool H2 = false>
 __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restrict__ w, int Cin, int Cout,
-                                                         unsigned *__restrict__ wf) {
+                                                         unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
     const int Kc = TRANSPOSED ? Cout : Cin, Nc = TRANSPOSED ? Cin : Cout;
     const int ntile = Nc / 32;
     const long long total = (long long)(Kc / 16) * 9 * ntile * 64;        // one thread per (slab, tile, lane)
@@ -82,6 +118,12 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
     const int r = lane & 31, h = lane >> 5;
     const int n = tile * 32 + r, k0 = c16 * 16 + 8 * h;
     unsigned p1[4], p2[4], p3[4];
+    int ew = 0;
+    if (H2) {
+        ew = block_exponent(trailer[0]);
+        ew = ew == E_UNSET ? 0 : ew;
+        if (t == 0) { reinterpret_cast<float *>(trailer)[1] = ldexpf(1.0f, -ew); reinterpret_cast<int *>(trailer)[2] = ew; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float a, b;
@@ -92,18 +134,30 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
             a = w[((size_t)(k0 + 2 * j) * 9 + (8 - tap)) * Cin + n];
             b = w[((size_t)(k0 + 2 * j + 1) * 9 + (8 - tap)) * Cin + n];
         }
-        split3(a, b, p1[j], p2[j], p3[j]);
+        if (H2) split2h(a, b, ew, p1[j], p2[j]);
+        else split3(a, b, p1[j], p2[j], p3[j]);
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((slab * ntile + tile) * 3) * 64 + lane;
+    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((slab * ntile + tile) * (H2 ? 2 : 3)) * 64 + lane;
     dst[0] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
     dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-    dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+    if (!H2) dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
+// largest magnitude of a [rows][cols] matrix with row stride ld, as float bits (non-negative floats order like unsigned ints)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w, long long rows, int cols, long long ld,
+                                                    unsigned *__restrict__ out) {
+    float m = 0.f;
+    const long long total = rows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+        m = fmaxf(m, fabsf(w[(i / cols) * ld + i % cols]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 // the same for a plain weight matrix (1-tap form): W given as [N][K] (nn.Linear: k contiguous) or, KN, as [K][N]
-template <bool KN>
+template <bool KN, bool H2 = false>
 __global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__restrict__ w, int K, int N, int ldw,
-                                                              unsigned *__restrict__ wf) {
+                                                              unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
     const int ntile = N / 32;
     const long long total = (long long)(K / 16) * ntile * 64;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -114,22 +168,30 @@ __global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__re
     const int r = lane & 31, h = lane >> 5;
     const int n = tile * 32 + r, k0 = (int)c16 * 16 + 8 * h;
     unsigned p1[4], p2[4], p3[4];
+    int ew = 0;
+    if (H2) {
+        ew = block_exponent(trailer[0]);
+        ew = ew == E_UNSET ? 0 : ew;
+        if (t == 0) { reinterpret_cast<float *>(trailer)[1] = ldexpf(1.0f, -ew); reinterpret_cast<int *>(trailer)[2] = ew; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = KN ? w[(size_t)(k0 + 2 * j) * ldw + n] : w[(size_t)n * ldw + k0 + 2 * j];
         const float b = KN ? w[(size_t)(k0 + 2 * j + 1) * ldw + n] : w[(size_t)n * ldw + k0 + 2 * j + 1];
-        split3(a, b, p1[j], p2[j], p3[j]);
+        if (H2) split2h(a, b, ew, p1[j], p2[j]);
+        else split3(a, b, p1[j], p2[j], p3[j]);
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((c16 * ntile + tile) * 3) * 64 + lane;
+    uint4 *dst = reinterpret_cast<uint4 *>(wf) + ((c16 * ntile + tile) * (H2 ? 2 : 3)) * 64 + lane;
     dst[0] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
     dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
-    dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+    if (!H2) dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
 }
 
 // ---- fwd / dgrad --------------------------------------------------------------------------------------------------------------
 struct RowsArgs {
     const float *x;          // [B,H,W,Kc] fp32: the input (fwd) or dY (dgrad)
     const unsigned *wf;      // prepared weights
+    const float *wscale;     // NPL = 2: the prepared buffer's trailer (wscale[1] = 2^-e_w)
     const float *bias;       // [Nc] or null
     const float *mask;       // [B,H,W,Nc] or null: result *= (mask > 0)
     float *y;                // [B,H,W,Nc], or the slab base when the reduction is split
@@ -174,9 +236,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     constexpr int HALO_BYTES = NPL * PLANE;
     constexpr int LDS_WORK = HALO_BYTES + 2 * BSLAB;
     constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (the epilogue's patches live in the same array)
+    constexpr bool H2 = NPL == 2;                                        // the fp16 two-way split with block scales
+    constexpr int WPL = H2 ? 2 : 3;                                      // planes per tile in the prepared weight buffer
     static_assert(WAVES_M * WAVES_N == 4 && TM * WAVES_M == TH && TN * WAVES_N * 32 == BN, "wave layout");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES + (H2 ? 64 : 0)];
     unsigned char *halo = lds, *bbuf = lds + HALO_BYTES;
+    float *slots = reinterpret_cast<float *>(lds + LDS_BYTES);           // H2: [parity][wave] block maxima of the staged chunks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -215,6 +280,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             hreg[f] = v;
         }
     };
+    int e_run = E_UNSET, e_cur = 0;                                      // H2: exponent of the accumulators' A scale / of the chunk being staged
     auto halo_store = [&]() {
 #pragma unroll
         for (int f = 0; f < PER; ++f) {
@@ -222,9 +288,16 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             if (idx < NF4) {
                 const int px = idx / F4, c4 = idx % F4;
                 unsigned a1, a2, a3, b1, b2, b3;
+                unsigned char *d = halo + px * PXB + c4 * 8;
+                if (H2) {
+                    split2h(hreg[f].x, hreg[f].y, e_cur, a1, a2);
+                    split2h(hreg[f].z, hreg[f].w, e_cur, b1, b2);
+                    *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
+                    continue;
+                }
                 split3(hreg[f].x, hreg[f].y, a1, a2, a3);
                 split3(hreg[f].z, hreg[f].w, b1, b2, b3);
-                unsigned char *d = halo + px * PXB + c4 * 8;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
                 if (NPL == 3) {
                     *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a2, b2);
@@ -233,10 +306,18 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             }
         }
     };
+    // H2: the largest magnitude of the chunk waiting in hreg -> slots[parity] (published by the next barrier)
+    auto publish_block_max = [&](int parity) {
+        float m = 0.f;
+#pragma unroll
+        for (int f = 0; f < PER; ++f) m = abs4max(m, hreg[f]);
+        m = wave_max(m);
+        if (lane == 0) slots[parity * 4 + wave] = m;
+    };
     // weight slab (16-channel step c16, tap) = c16 * 9 + tap: (Nc / 32) x 3 KB; this workgroup's BN / 32 tiles are one linear run.
     // Step st of chunk c: tap = st / NQ, q = st % NQ, c16 = c * NQ + q
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * 3 * 1024;
-    const size_t slab_stride = (size_t)(p.Nc / 32) * 3 * 1024;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * WPL * 1024;
+    const size_t slab_stride = (size_t)(p.Nc / 32) * WPL * 1024;
     auto issue_b = [&](int c, int st, unsigned char *dst) {
         const int s = (c * NQ + st % NQ) * NTAP + st / NQ;
         const unsigned char *src = wbase + (size_t)s * slab_stride;
@@ -244,8 +325,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 #pragma unroll
         for (int j = 0; j < (PIECES + 3) / 4; ++j)
             if (j * 4 + wave < PIECES) {
-                // piece = (tile, plane); the prepared weights always hold three planes per tile
-                const int piece = j * 4 + wave, spiece = NPL == 3 ? piece : piece * 3;
+                // piece = (tile, plane); the prepared bf16 weights always hold three planes per tile
+                const int piece = j * 4 + wave, spiece = NPL == WPL ? piece : piece * 3;
                 __builtin_amdgcn_global_load_lds((glb_void *)(src + spiece * 1024 + lane * 16), (lds_void *)(dst + piece * 1024), 16, 0, 0);
             }
     };
@@ -260,8 +341,30 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 
     const int r = lane & 31, h = lane >> 5;
     halo_load(c_beg);
+    if (H2) {
+        publish_block_max(c_beg & 1);
+        __syncthreads();
+    }
     int s = 0;                                                           // running step count (selects the weight buffer)
     for (int c = c_beg; c < c_end; ++c) {
+        if (H2) {
+            // this chunk's block exponent (the same in every thread); the accumulators follow the smallest exponent (= the largest
+            // block) met so far: a power-of-two rescaling of an fp32 accumulator is exact
+            const float *sl = slots + (c & 1) * 4;
+            const int e_nat = block_exponent(__float_as_uint(fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]))));
+            if (e_nat < e_run) {
+                if (e_run != E_UNSET) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int z = 0; z < 16; ++z) acc[i][j][z] = ldexpf(acc[i][j][z], e_nat - e_run);
+                }
+                e_run = e_nat;
+            }
+            e_cur = e_run == E_UNSET ? 0 : e_run;
+        }
         halo_store();                                                    // (the previous chunk's last barrier has passed)
         if (c == c_beg) issue_b(c, 0, bbuf);                             // (later chunks: issued by the previous chunk's last step)
         if (c + 1 < c_end) halo_load(c + 1);                             // in flight under this chunk's MFMAs
@@ -291,14 +394,26 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 __builtin_amdgcn_sched_barrier(0);                       // all fragment reads in flight before the first MFMA
                 // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
                 constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+                if (H2) {                                                // h2 g1, h1 g2, h1 g1
 #pragma unroll
-                for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
+                    for (int e = 3; e < 6; ++e)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ia[e]]),
-                                                                                 *reinterpret_cast<bf16x8 *>(&bfr[j][ib[e]]), acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<f16x8 *>(&af[i][ia[e]]),
+                                                                                    *reinterpret_cast<f16x8 *>(&bfr[j][ib[e]]), acc[i][j], 0, 0, 0);
+                    if (st + 1 == NSTEP && c + 1 < c_end) publish_block_max((c + 1) & 1);      // (under the MFMAs; the barrier below publishes)
+                } else {
+#pragma unroll
+                    for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ia[e]]),
+                                                                                     *reinterpret_cast<bf16x8 *>(&bfr[j][ib[e]]), acc[i][j], 0, 0, 0);
+                }
                 __syncthreads();                                         // (also drains the next slab's DMA: vmcnt(0))
             }
         }
@@ -342,12 +457,15 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         }
     };
     prefetch(0, pre_m[0], pre_o[0]);
+    const float winv = H2 ? p.wscale[1] : 1.0f;
+    e_cur = e_run == E_UNSET ? 0 : e_run;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int i = t / TN, j = t % TN;
         if (t + 1 < T) prefetch(t + 1, pre_m[(t + 1) & 1], pre_o[(t + 1) & 1]);
 #pragma unroll
-        for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[i][j][z];
+        for (int z = 0; z < 16; ++z)
+            patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = H2 ? ldexpf(acc[i][j][z] * winv, -e_cur) : acc[i][j][z];
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         {
             int col, co;
@@ -407,8 +525,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     constexpr int YPLANE = 32 * YS, XHP = UP ? 4 * TW : 3 * (TW + 2), XPLANE = XHP * XS;
     constexpr int LDS_WORK = NPL * YPLANE + NPL * XPLANE;
     constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (epilogue patches, column-sum scratch)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    constexpr bool H2 = NPL == 2;                                        // the fp16 two-way split: one power-of-two scale per staged unit
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES + (H2 ? 64 : 0)];
     unsigned char *yimg = lds, *ximg = lds + NPL * YPLANE;
+    float *slots = reinterpret_cast<float *>(lds + LDS_BYTES);           // H2: [parity][wave][x, y] unit maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x, ci0 = blockIdx.y * CC, co0 = blockIdx.z * (32 * COT);
@@ -447,6 +567,17 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     };
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool do_colsum = p.colslab != nullptr && (UP ? blockIdx.z == 0 : blockIdx.y == 0);
+    int s_run = E_UNSET, ex_cur = 0, ey_cur = 0;                         // H2: exponent of the accumulators (x and y scales together), of the unit
+    auto publish_unit_max = [&](int parity) {
+        float mx = 0.f, my = 0.f;
+#pragma unroll
+        for (int f = 0; f < XPER; ++f) mx = abs4max(mx, xr[f]);         // (entries past XF4 are zero)
+#pragma unroll
+        for (int f = 0; f < YPER; ++f) my = abs4max(my, yr[f]);
+        mx = wave_max(mx);
+        my = wave_max(my);
+        if (lane == 0) { slots[(parity * 4 + wave) * 2] = mx; slots[(parity * 4 + wave) * 2 + 1] = my; }
+    };
     auto store_unit = [&]() {
 #pragma unroll
         for (int f = 0; f < XPER; ++f) {
@@ -459,9 +590,16 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
                     if (do_colsum) { csum.x += xr[f].x; csum.y += xr[f].y; csum.z += xr[f].z; csum.w += xr[f].w; }
                 }
                 unsigned a1, a2, a3, b1, b2, b3;
+                unsigned char *d = ximg + px * XS + c4 * 8;
+                if (H2) {
+                    split2h(xr[f].x, xr[f].y, ex_cur, a1, a2);
+                    split2h(xr[f].z, xr[f].w, ex_cur, b1, b2);
+                    *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2 *>(d + XPLANE) = make_uint2(a2, b2);
+                    continue;
+                }
                 split3(xr[f].x, xr[f].y, a1, a2, a3);
                 split3(xr[f].z, xr[f].w, b1, b2, b3);
-                unsigned char *d = ximg + px * XS + c4 * 8;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
                 if (NPL == 3) {
                     *reinterpret_cast<uint2 *>(d + XPLANE) = make_uint2(a2, b2);
@@ -474,15 +612,22 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             const int idx = tid + f * NT;
             const int px = idx / (8 * COT), c4 = idx % (8 * COT);
             unsigned a1, a2, a3, b1, b2, b3;
+            unsigned char *d = yimg + px * YS + c4 * 8;
+            if (!UP && do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
+            if (H2) {
+                split2h(yr[f].x, yr[f].y, ey_cur, a1, a2);
+                split2h(yr[f].z, yr[f].w, ey_cur, b1, b2);
+                *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
+                continue;
+            }
             split3(yr[f].x, yr[f].y, a1, a2, a3);
             split3(yr[f].z, yr[f].w, b1, b2, b3);
-            unsigned char *d = yimg + px * YS + c4 * 8;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a1, b1);
             if (NPL == 3) {
                 *reinterpret_cast<uint2 *>(d + YPLANE) = make_uint2(a2, b2);
                 *reinterpret_cast<uint2 *>(d + 2 * YPLANE) = make_uint2(a3, b3);
             }
-            if (!UP && do_colsum) { csum.x += yr[f].x; csum.y += yr[f].y; csum.z += yr[f].z; csum.w += yr[f].w; }   // pixels in order
         }
     };
 
@@ -506,7 +651,29 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     };
 
     if (u_beg < u_end) load_unit(u_beg);
+    if (H2) {
+        if (u_beg < u_end) publish_unit_max(u_beg & 1);
+        __syncthreads();
+    }
     for (int u = u_beg; u < u_end; ++u) {
+        if (H2) {
+            // natural exponents of this unit's two blocks; the accumulators carry 2^(s_run), the smallest sum met so far (the largest
+            // products): the x side keeps its natural scale, the y side takes what is left (<= its natural one: no overflow)
+            const float *sl = slots + (u & 1) * 8;
+            const int ex_nat = block_exponent(__float_as_uint(fmaxf(fmaxf(sl[0], sl[2]), fmaxf(sl[4], sl[6]))));
+            const int ey_nat = block_exponent(__float_as_uint(fmaxf(fmaxf(sl[1], sl[3]), fmaxf(sl[5], sl[7]))));
+            if (ex_nat != E_UNSET && ey_nat != E_UNSET && ex_nat + ey_nat < s_run) {
+                if (s_run != E_UNSET) {
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t)
+#pragma unroll
+                        for (int z = 0; z < 16; ++z) acc[t][z] = ldexpf(acc[t][z], ex_nat + ey_nat - s_run);
+                }
+                s_run = ex_nat + ey_nat;
+            }
+            ex_cur = ex_nat == E_UNSET ? 0 : ex_nat;
+            ey_cur = ey_nat == E_UNSET ? 0 : (s_run == E_UNSET ? ey_nat : min(s_run - ex_cur, ey_nat));
+        }
         store_unit();
         if (u + 1 < u_end) load_unit(u + 1);                             // in flight under this unit's MFMAs
         __syncthreads();
@@ -526,12 +693,20 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
                     constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
+                    if (H2) {
 #pragma unroll
-                    for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia[e]], bfr[ib[e]], acc[t], 0, 0, 0);
+                        for (int e = 3; e < 6; ++e)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8 *>(&af[ia[e]]),
+                                                                            *reinterpret_cast<const f16x8 *>(&bfr[ib[e]]), acc[t], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = (NPL == 3 ? 0 : 5); e < 6; ++e)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia[e]], bfr[ib[e]], acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (H2 && u + 1 < u_end) publish_unit_max((u + 1) & 1);            // (the next unit's loads have landed under the MFMAs)
         __syncthreads();                                                  // every wave has read the images
     }
 
@@ -559,7 +734,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
         const int tap = tap_lo + t;
         if (tap < tap_hi) {
 #pragma unroll
-            for (int z = 0; z < 16; ++z) patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = acc[t][z];
+            for (int z = 0; z < 16; ++z)
+                patch[((z & 3) + 8 * (z >> 2) + 4 * h) * 36 + r] = H2 ? ldexpf(acc[t][z], s_run == E_UNSET ? 0 : -s_run) : acc[t][z];
 #pragma unroll
             for (int pass = 0; pass < 4; ++pass) {
                 const float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
@@ -635,9 +811,12 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int up
 
 #define BX3_LAUNCH(TH_, BN_, WM_, WN_, CC_, NTAP_)                                                                           \
     do {                                                                                                                    \
-        if (single) {                                                                                                       \
+        if (npl == 1) {                                                                                                     \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
             note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",1," #NTAP_ ">");                      \
+        } else if (npl == 2) {                                                                                              \
+            hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 2, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",2," #NTAP_ ">");                      \
         } else {                                                                                                            \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
             note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",3," #NTAP_ ">");                      \
@@ -647,11 +826,21 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int up
 // `a`: x, wf, bias, mask, y, geometry and epilogue flags; splits the reduction into `ws` when the plan says so
 #define BX3_LAUNCH_UP(BN_, WM_, WN_, UPM_)                                                                                    \
     do {                                                                                                                    \
-        hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 3, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a);   \
-        note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,3,1," #UPM_ ">");                                      \
+        if (npl == 2) {                                                                                                     \
+            hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 2, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
+            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,2,1," #UPM_ ">");                                  \
+        } else {                                                                                                            \
+            hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 3, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
+            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,3,1," #UPM_ ">");                                  \
+        }                                                                                                                   \
     } while (0)
 
-int launch_rows(RowsArgs a, bool single, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9, int upm = 0) {
+// npl: 3 = bf16 three-way split, 2 = fp16 two-way split (a.wf prepared by the *_f16x2_prepare entry points), 1 = bf16 rounding
+int npl_of(int flags) { return (flags & T2H_F16X2) ? 2 : ((flags & T2H_BF16) ? 1 : 3); }
+// trailer of an fp16-prepared weight buffer ([0] largest magnitude bits, [1] 2^-e_w, [2] e_w) behind `planes_bytes` of planes
+const float *f16_trailer(const void *wf, size_t planes_bytes) { return reinterpret_cast<const float *>(static_cast<const unsigned char *>(wf) + planes_bytes); }
+
+int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9, int upm = 0) {
     const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc, ntap, upm);
     const long long grid = r.tiles * r.splits;
     if (grid > 0x7fffffffLL) return fail(T2H_ERR_ARG, "%s: too many tiles", what);
@@ -764,7 +953,8 @@ T2H_API int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bia
     a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Kc = Cin; a.Nc = Cout; a.ldx = Cin; a.ldy = Cout; a.ldm = Cout;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
-    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
+    a.wscale = f16_trailer(wf, (size_t)Cout * 9 * Cin * 4);
+    return launch_rows(a, npl_of(flags), workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_fwd");
 }
 
 T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, const float *mask, int B, int H, int W, int Cin,
@@ -776,7 +966,8 @@ T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, 
     a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
     a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = Cin;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
-    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
+    a.wscale = f16_trailer(wf_t, (size_t)Cout * 9 * Cin * 4);
+    return launch_rows(a, npl_of(flags), workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
 }
 
 T2H_API size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -803,7 +994,11 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
     dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
-    if (flags & T2H_BF16) {
+    if (flags & T2H_F16X2) {
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,2>"); }
+    } else if (flags & T2H_BF16) {
         if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,1>"); }
         else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,1>"); }
         else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,1>"); }
@@ -856,7 +1051,8 @@ T2H_API int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *b
     a.x = x; a.wf = static_cast<const unsigned *>(wf); a.bias = bias; a.mask = mask; a.y = y;
     a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = K; a.Nc = N; a.ldx = ldx; a.ldy = ldy; a.ldm = ldm;
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
-    return launch_rows(a, (flags & T2H_BF16) != 0, workspace, workspace_bytes, as_stream(stream), "gemm_bx3", 1);
+    a.wscale = f16_trailer(wf, (size_t)K * N * 4);
+    return launch_rows(a, npl_of(flags), workspace, workspace_bytes, as_stream(stream), "gemm_bx3", 1);
 }
 
 // ---- ConvTranspose2d(kernel_size = 2, stride = 2) on the 1-tap form -------------------------------------------------------------------
@@ -886,7 +1082,8 @@ T2H_API int t2h_upconv2x2_bx3_fwd(const float *x, const void *wf, const float *b
     a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = Cin; a.Nc = 4 * Cout; a.ldx = Cin; a.ldy = 4 * Cout; a.ldm = 0;
     a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
-    return launch_rows(a, false, nullptr, 0, as_stream(stream), "upconv2x2_bx3_fwd", 1, 1);
+    a.wscale = f16_trailer(wf, (size_t)Cin * 4 * Cout * 4);
+    return launch_rows(a, (flags & T2H_F16X2) ? 2 : 3, nullptr, 0, as_stream(stream), "upconv2x2_bx3_fwd", 1, 1);
 }
 
 T2H_API size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
@@ -907,7 +1104,8 @@ T2H_API int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx
     a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = 4 * Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = 0;
     a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
-    return launch_rows(a, false, workspace, workspace_bytes, as_stream(stream), "upconv2x2_bx3_dgrad", 1, 2);
+    a.wscale = f16_trailer(wf_t, (size_t)Cin * 4 * Cout * 4);
+    return launch_rows(a, (flags & T2H_F16X2) ? 2 : 3, workspace, workspace_bytes, as_stream(stream), "upconv2x2_bx3_dgrad", 1, 2);
 }
 
 static WgradPlan up_wgrad_plan(int B, int H, int W, int Cin, int Cout) {
@@ -950,9 +1148,61 @@ T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, 
     a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
     dim3 grid(p.splits, Cout / CC, Cin / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: too many channel chunks");
-    if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,true>"); }
+    if (flags & T2H_F16X2) {
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,true>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,true>"); }
+    } else if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,true>"); }
     else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,true>"); }
     if (int rc = check_launch("upconv2x2_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
                                p.splits, Cout, (flags & T2H_DEFER_REDUCE) != 0);
+}
+
+// ---- weight preparation for the fp16 two-way split (T2H_F16X2) ------------------------------------------------------------------------
+// buffer = two f16 planes in MFMA B-fragment order (4 bytes per weight) + a 256-byte trailer: [0] bits of max |w|, [1] 2^-e_w, [2] e_w
+T2H_API size_t t2h_conv3x3_f16x2_weights_bytes(int Cin, int Cout) {
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
+    return (size_t)Cout * 9 * Cin * 4 + 256;
+}
+
+static int absmax_into(const float *w, long long rows, int cols, long long ld, unsigned *trailer, hipStream_t s, const char *what) {
+    if (hipMemsetAsync(trailer, 0, 256, s) != hipSuccess) return fail(T2H_ERR_LAUNCH, "%s: hipMemsetAsync failed", what);
+    const long long total = rows * cols;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 4095) / 4096, 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, w, rows, cols, ld, trailer);
+    return check_launch(what);
+}
+
+T2H_API int t2h_conv3x3_f16x2_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream) {
+    if (!w || !wf) return fail(T2H_ERR_ARG, "conv3x3_f16x2_prepare: null pointer");
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || !al16(wf))
+        return fail(T2H_ERR_ARG, "conv3x3_f16x2_prepare: Cin=%d, Cout=%d must be multiples of 32, wf 16-byte aligned", Cin, Cout);
+    hipStream_t s = as_stream(stream);
+    unsigned *trailer = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(wf) + (size_t)Cout * 9 * Cin * 4);
+    if (int rc = absmax_into(w, 1, Cout * 9 * Cin, 0, trailer, s, "conv3x3_f16x2_prepare")) return rc;
+    const int Kc = transposed ? Cout : Cin, Nc = transposed ? Cin : Cout;
+    const long long total = (long long)(Kc / 16) * 9 * (Nc / 32) * 64;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (transposed) hipLaunchKernelGGL((bx3_prepare_kernel<true, true>), dim3(blocks), dim3(256), 0, s, w, Cin, Cout, static_cast<unsigned *>(wf), trailer);
+    else hipLaunchKernelGGL((bx3_prepare_kernel<false, true>), dim3(blocks), dim3(256), 0, s, w, Cin, Cout, static_cast<unsigned *>(wf), trailer);
+    return check_launch("conv3x3_f16x2_prepare");
+}
+
+T2H_API size_t t2h_gemm_f16x2_weights_bytes(int K, int N) {
+    if (K < 16 || N < 32 || K % 16 || N % 32) return 0;
+    return (size_t)K * N * 4 + 256;
+}
+
+T2H_API int t2h_gemm_f16x2_prepare(const float *w, int ldw, int K, int N, int w_is_kn, void *wf, t2h_stream_t stream) {
+    if (!w || !wf) return fail(T2H_ERR_ARG, "gemm_f16x2_prepare: null pointer");
+    if (K < 16 || N < 32 || K % 16 || N % 32 || !al16(wf) || ldw < (w_is_kn ? N : K))
+        return fail(T2H_ERR_ARG, "gemm_f16x2_prepare: K=%d must be a multiple of 16, N=%d of 32, ldw=%d at least the row length", K, N, ldw);
+    hipStream_t s = as_stream(stream);
+    unsigned *trailer = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(wf) + (size_t)K * N * 4);
+    if (int rc = absmax_into(w, w_is_kn ? K : N, w_is_kn ? N : K, ldw, trailer, s, "gemm_f16x2_prepare")) return rc;
+    const long long total = (long long)(K / 16) * (N / 32) * 64;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (w_is_kn) hipLaunchKernelGGL((bx3_prepare_gemm_kernel<true, true>), dim3(blocks), dim3(256), 0, s, w, K, N, ldw, static_cast<unsigned *>(wf), trailer);
+    else hipLaunchKernelGGL((bx3_prepare_gemm_kernel<false, true>), dim3(blocks), dim3(256), 0, s, w, K, N, ldw, static_cast<unsigned *>(wf), trailer);
+    return check_launch("gemm_f16x2_prepare");
 }

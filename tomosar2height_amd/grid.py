@@ -103,10 +103,14 @@ def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
 # T2H_BX3_MIN_PIXELS pixels (default: 256 x 256, where the kernels were measured 1.4-1.8x faster; profiles/conv_bf16x3_lab.hip).
 # 'bf16' (set by TomoSAR2Height.set_mlp_precision('bf16'), BASELINE configs[2]): the same kernels with the leading bf16 part of
 # both operands only -- one MFMA per product, tolerance of that MODE 2e-2 of the height scale (tests/test_full_size_vs_oracle.py).
-CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "bf16x3")
+# 'f16x2': the same kernels on v_mfma_f32_32x32x16_f16 with a TWO-way fp16 split of both operands and one power-of-two scale per
+# staged block -- three MFMAs per product instead of six, fp32-grade unless an element lies more than 2^18 below the largest
+# element of its own staged block (csrc/conv_bx3.hip, "the fp16 two-way split"; include/t2h.h T2H_F16X2).
+CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "f16x2")
 BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(32 * 32)))
-if CONV_PRECISION not in ("fp32", "bf16x3", "bf16"):
-    raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected 'fp32', 'bf16x3' or 'bf16'")
+_CONV_PRECISIONS = ("fp32", "bf16x3", "f16x2", "bf16")
+if CONV_PRECISION not in _CONV_PRECISIONS:
+    raise ValueError(f"T2H_CONV_PRECISION={CONV_PRECISION!r}: expected one of {_CONV_PRECISIONS}")
 _DEFAULT_CONV_PRECISION = CONV_PRECISION
 
 
@@ -115,18 +119,23 @@ def set_conv_precision(name: str = None):
     None restores the process default (T2H_CONV_PRECISION)."""
     global CONV_PRECISION
     name = _DEFAULT_CONV_PRECISION if name is None else name
-    if name not in ("fp32", "bf16x3", "bf16"):
-        raise ValueError("conv precision must be 'fp32', 'bf16x3' or 'bf16'")
+    if name not in _CONV_PRECISIONS:
+        raise ValueError(f"conv precision must be one of {_CONV_PRECISIONS}")
     CONV_PRECISION = name
 
 
 def bx3_applicable(b: int, h: int, wd: int, cin: int, cout: int) -> bool:
-    return (CONV_PRECISION in ("bf16x3", "bf16") and h * wd >= BX3_MIN_PIXELS
+    return (CONV_PRECISION in ("bf16x3", "f16x2", "bf16") and h * wd >= BX3_MIN_PIXELS
             and bool(_lib.load().t2h_conv3x3_bx3_supported(b, h, wd, cin, cout)))
 
 
 def _bx3_flag() -> int:
-    return _lib.BF16 if CONV_PRECISION == "bf16" else 0
+    return _lib.BF16 if CONV_PRECISION == "bf16" else (_lib.F16X2 if CONV_PRECISION == "f16x2" else 0)
+
+
+def _h2() -> bool:
+    """The prepared weights are the fp16 two-plane buffers (T2H_F16X2)."""
+    return CONV_PRECISION == "f16x2"
 
 
 class SplitWeightCache:
@@ -140,66 +149,75 @@ class SplitWeightCache:
 
     def get(self, w: torch.Tensor, transposed: bool) -> torch.Tensor:
         import weakref
-        key = (id(w), bool(transposed))
+        key = (id(w), ("h2t" if transposed else "h2f") if _h2() else bool(transposed))
         e = self.entries.get(key)
         cout, cin = w.shape[0], w.shape[1]
         if e is None or e[0]() is not w:
-            nbytes = int(_lib.load().t2h_conv3x3_bx3_weights_bytes(cin, cout))
+            lib = _lib.load()
+            nbytes = int((lib.t2h_conv3x3_f16x2_weights_bytes if _h2() else lib.t2h_conv3x3_bx3_weights_bytes)(cin, cout))
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf]
         if e[1] != w._version or e[2] != w.data_ptr():
-            self._prepare(w, transposed, e[3])
+            self._prepare(w, key[1], e[3])
             e[1], e[2] = w._version, w.data_ptr()
         return e[3]
 
     @staticmethod
-    def _prepare(w, transposed, buf):
+    def _prepare(w, kind, buf):
         cout, cin = w.shape[0], w.shape[1]
-        _lib.call("t2h_conv3x3_bx3_prepare", _lib.ptr(w), cin, cout, 1 if transposed else 0, _lib.ptr(buf), _lib.stream(),
-                  nbytes=10 * w.numel())
+        h2 = kind in ("h2t", "h2f")
+        transposed = kind in (True, "h2t")
+        _lib.call("t2h_conv3x3_f16x2_prepare" if h2 else "t2h_conv3x3_bx3_prepare", _lib.ptr(w), cin, cout, 1 if transposed else 0,
+                  _lib.ptr(buf), _lib.stream(), nbytes=(12 if h2 else 10) * w.numel())
 
     def get_gemm(self, w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
         """The same for a plain weight matrix of the 1-tap (GEMM) form: ``w`` [N, K] (nn.Linear) or, ``w_is_kn``, [K, N]."""
         import weakref
-        key = (id(w), "kn" if w_is_kn else "nk")
+        key = (id(w), ("kn" if w_is_kn else "nk") + ("_h2" if _h2() else ""))
         e = self.entries.get(key)
         k, n = (w.shape[0], w.shape[1]) if w_is_kn else (w.shape[1], w.shape[0])
         if e is None or e[0]() is not w:
-            buf = torch.empty(int(_lib.load().t2h_gemm_bx3_weights_bytes(k, n)), dtype=torch.uint8, device=w.device)
+            lib = _lib.load()
+            buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
+                              dtype=torch.uint8, device=w.device)
             e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
         if e[1] != w._version or e[2] != w.data_ptr():
-            self._prepare_gemm(w, w_is_kn, e[3])
+            self._prepare_gemm(w, key[1], e[3])
             e[1], e[2] = w._version, w.data_ptr()
         return e[3]
 
     @staticmethod
-    def _prepare_gemm(w, w_is_kn, buf):
+    def _prepare_gemm(w, kind, buf):
+        w_is_kn, h2 = kind.startswith("kn"), kind.endswith("_h2")
         k, n = (w.shape[0], w.shape[1]) if w_is_kn else (w.shape[1], w.shape[0])
-        _lib.call("t2h_gemm_bx3_prepare", _lib.ptr(w), w.stride(0), k, n, 1 if w_is_kn else 0, _lib.ptr(buf), _lib.stream(),
-                  nbytes=10 * w.numel())
+        _lib.call("t2h_gemm_f16x2_prepare" if h2 else "t2h_gemm_bx3_prepare", _lib.ptr(w), w.stride(0), k, n, 1 if w_is_kn else 0,
+                  _lib.ptr(buf), _lib.stream(), nbytes=(12 if h2 else 10) * w.numel())
 
     def get_up(self, w: torch.Tensor, w_is_kn: bool) -> torch.Tensor:
         """The same for a ConvTranspose2d(2, stride 2) weight [Cin, Cout, 2, 2] whose memory is [Cin][2][2][Cout]: the matrix
         [Cin, (tap, co)] as the forward's [K, N] operand (``w_is_kn``) or as the data gradient's [N, K] operand."""
         import weakref
-        key = (id(w), "up_kn" if w_is_kn else "up_nk")
+        key = (id(w), ("up_kn" if w_is_kn else "up_nk") + ("_h2" if _h2() else ""))
         e = self.entries.get(key)
         cin, n4 = w.shape[0], 4 * w.shape[1]
         if e is None or e[0]() is not w:
             k, n = (cin, n4) if w_is_kn else (n4, cin)
-            buf = torch.empty(int(_lib.load().t2h_gemm_bx3_weights_bytes(k, n)), dtype=torch.uint8, device=w.device)
+            lib = _lib.load()
+            buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
+                              dtype=torch.uint8, device=w.device)
             e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
         if e[1] != w._version or e[2] != w.data_ptr():
-            self._prepare_up(w, w_is_kn, e[3])
+            self._prepare_up(w, key[1], e[3])
             e[1], e[2] = w._version, w.data_ptr()
         return e[3]
 
     @staticmethod
-    def _prepare_up(w, w_is_kn, buf):
+    def _prepare_up(w, kind, buf):
+        w_is_kn, h2 = kind.startswith("up_kn"), kind.endswith("_h2")
         cin, n4 = w.shape[0], 4 * w.shape[1]
         k, n = (cin, n4) if w_is_kn else (n4, cin)
-        _lib.call("t2h_gemm_bx3_prepare", _lib.ptr(w), n4, k, n, 1 if w_is_kn else 0, _lib.ptr(buf), _lib.stream(),
-                  nbytes=10 * w.numel())
+        _lib.call("t2h_gemm_f16x2_prepare" if h2 else "t2h_gemm_bx3_prepare", _lib.ptr(w), n4, k, n, 1 if w_is_kn else 0,
+                  _lib.ptr(buf), _lib.stream(), nbytes=(12 if h2 else 10) * w.numel())
 
     def refresh(self):
         """Re-split every live weight into its existing buffer."""
@@ -207,10 +225,10 @@ class SplitWeightCache:
             w = e[0]()
             if w is None:
                 continue
-            if kind in ("up_kn", "up_nk"):
-                self._prepare_up(w, kind == "up_kn", e[3])
-            elif kind in ("kn", "nk"):
-                self._prepare_gemm(w, kind == "kn", e[3])
+            if isinstance(kind, str) and kind.startswith("up_"):
+                self._prepare_up(w, kind, e[3])
+            elif isinstance(kind, str) and kind[:2] in ("kn", "nk"):
+                self._prepare_gemm(w, kind, e[3])
             else:
                 self._prepare(w, kind, e[3])
             e[1], e[2] = w._version, w.data_ptr()
@@ -527,7 +545,7 @@ def _up_bx3(x, weight, w) -> bool:
     """The transposed convolution runs on the split-bf16 kernels (csrc/conv_bx3.hip, 1-tap form with a scattering epilogue /
     gathering loader) when the precision mode asks for them, the shape fits and the weight already lies [Cin][2][2][Cout]."""
     b, cin, h, wd = x.shape
-    return bool(UPCONV_BX3 and CONV_PRECISION in ("bf16x3", "bf16") and w is weight and b * h * wd >= BX3_MIN_PIXELS
+    return bool(UPCONV_BX3 and CONV_PRECISION in ("bf16x3", "f16x2", "bf16") and w is weight and b * h * wd >= BX3_MIN_PIXELS
                 and _lib.load().t2h_upconv2x2_bx3_supported(b, h, wd, cin, weight.shape[1]))
 
 
@@ -550,7 +568,7 @@ class _UpConv2x2(torch.autograd.Function):
         if ctx.bx3:
             _lib.call("t2h_upconv2x2_bx3_fwd", _lib.ptr(x), _lib.ptr(split_weights.get_up(w, True)),
                       _lib.ptr(bias) if bias is not None else None, _lib.ptr(addend) if addend is not None else None, _lib.ptr(y),
-                      b, h, wd, cin, cout, 0, _lib.stream(),
+                      b, h, wd, cin, cout, _lib.F16X2 if _h2() else 0, _lib.stream(),
                       nbytes=4 * (x.numel() + y.numel() * (2 if addend is not None else 1)) + 6 * w.numel(),
                       flops=2 * 4 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_upconv2x2_bx3_fwd[{cin}->{cout},{h}x{wd}]")
             ctx.save_for_backward(x, weight, bias)
@@ -579,7 +597,7 @@ class _UpConv2x2(torch.autograd.Function):
             nws = _lib.ws_bytes("t2h_upconv2x2_bx3_dgrad_workspace_bytes", b, h, wd, cin, cout)
             ws = _lib.workspace(nws, g.device)
             _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(g), _lib.ptr(split_weights.get_up(w, False)), _lib.ptr(dx),
-                      b, h, wd, cin, cout, 0, _lib.ptr(ws), nws, _lib.stream(),
+                      b, h, wd, cin, cout, _lib.F16X2 if _h2() else 0, _lib.ptr(ws), nws, _lib.stream(),
                       nbytes=4 * (g.numel() + dx.numel()) + 6 * w.numel(), flops=flops,
                       tag=_lib.timing() and f"t2h_upconv2x2_bx3_dgrad[{cout}->{cin},{h}x{wd}]")
         elif dx is not None:
@@ -598,8 +616,9 @@ class _UpConv2x2(torch.autograd.Function):
         ws = _lib.workspace(nws, g.device)
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
         _lib.call(up, _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
-                  b, h, wd, cin, cout, (_lib.ACCUM | _lib.defer_reduce(ws)) if direct else 0, _lib.ptr(ws), nws, _lib.stream(),
-                  nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
+                  b, h, wd, cin, cout,
+                  ((_lib.ACCUM | _lib.defer_reduce(ws)) if direct else 0) | (_lib.F16X2 if (_h2() and up.endswith("bx3_wgrad")) else 0),
+                  _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                   tag=_lib.timing() and f"{up}[{cin}->{cout},{h}x{wd}]")
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)

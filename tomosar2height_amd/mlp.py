@@ -83,7 +83,7 @@ def _gemm_bx3(x, w, w_is_kn, bias, mask, y, relu_out, accumulate, tag):
     mp, ldm = (None, 0) if mask is None else _rows(mask, "gemm_bx3 mask")
     nws = _lib.ws_bytes("t2h_gemm_bx3_workspace_bytes", m, k, n)
     ws = _lib.workspace(nws, x.device)
-    flags = (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0)
+    flags = (_lib.RELU_OUT if relu_out else 0) | (_lib.ACCUM if accumulate else 0) | (_lib.F16X2 if grid._h2() else 0)
     _lib.call("t2h_gemm_bx3", xp, ldx, _lib.ptr(grid.split_weights.get_gemm(w, w_is_kn)), bias.data_ptr() if bias is not None else None,
               mp, ldm, yp, ldy, m, k, n, flags, _lib.ptr(ws), nws, _lib.stream(),
               nbytes=4 * (m * k + m * n + n * k + (m * n if mask is not None else 0)), flops=2 * m * k * n, tag=_lib.timing() and tag)
