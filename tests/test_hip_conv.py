@@ -503,13 +503,16 @@ def test_upconv2x2_matches_conv_transpose(b, h, w, cin, cout):
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 32, 32, 512, 256), (1, 64, 64, 256, 128), (1, 128, 128, 128, 64), (2, 16, 32, 64, 64),
                                             (4, 32, 32, 192, 64), (1, 8, 16, 1024, 512)])
-def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, monkeypatch):
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, mode, monkeypatch):
     """The transposed convolutions on csrc/conv_bx3.hip (scattering epilogue / gathering loader on the 1-tap form): forward with bias
     and residual addend, data gradient (split-K slabs at the small planes), against float64, at the error of the fp32-MFMA kernels;
     the kernels actually ran; the fp32 path (T2H_UPCONV_BX3=0 sibling) gives the same values to fp32 rounding."""
     import copy
     from tomosar2height_amd import _lib, grid
     monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 128)
+    monkeypatch.setattr(grid, "CONV_PRECISION", mode)
+    npl = 2 if mode == "f16x2" else 3
     g = torch.Generator().manual_seed(b * 7 + h + cin + cout)
     torch.manual_seed(b + h + cin + cout)
     conv = torch.nn.ConvTranspose2d(cin, cout, 2, stride=2)
@@ -534,8 +537,8 @@ def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, monkeypatch):
         torch.cuda.synchronize()
         names = [r[5] for r in tl.records if r[5].startswith("bx3_")]
         if on:
-            assert names[0].endswith(",64,3,1,1>") and names[1].endswith(",64,3,1,2>"), names
-            assert names[2:] == ([f"bx3_wgrad_kernel<{4 if cin % 128 == 0 else 2},3,true>"] if w >= 32 else []), names
+            assert names[0].endswith(f",64,{npl},1,1>") and names[1].endswith(f",64,{npl},1,2>"), names
+            assert names[2:] == ([f"bx3_wgrad_kernel<{4 if cin % 128 == 0 else 2},{npl},true>"] if w >= 32 else []), names
         else:
             assert not names, names
         outs[on] = (y.detach().clone(), xg.grad.clone(), ag.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
