@@ -416,6 +416,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU path to benchmark)")
     if args.share_gpu:
         local_rank = 0
+        # several processes time-slicing ONE GPU (smoke test of the multi-rank code path): every extra hardware queue multiplies
+        # the context switches (per-launch durations of 100 ms were measured with the side streams on) -- keep one stream per rank
+        os.environ["T2H_OVERLAP_WGRAD"] = "0"
+        os.environ["T2H_OVERLAP_CONV_WGRAD"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None

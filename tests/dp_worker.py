@@ -5,6 +5,10 @@ exercises RCCL initialisation and the all-reduce launch on the hardware.
 
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tests/dp_worker.py dp OUT.json
 """
+import os as _os
+# all ranks share cuda:0 here: one stream per process (see bench.py --share-gpu)
+_os.environ.setdefault("T2H_OVERLAP_WGRAD", "0")
+_os.environ.setdefault("T2H_OVERLAP_CONV_WGRAD", "0")
 import json
 import os
 import sys

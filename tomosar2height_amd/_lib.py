@@ -152,6 +152,7 @@ class reduce_capture:
     def __init__(self, enabled: bool = True):
         self.enabled = enabled and reduce_capture.active is None
         self.keep = []
+        self.outputs = set()
 
     def __enter__(self):
         if self.enabled:
@@ -163,17 +164,28 @@ class reduce_capture:
         if self.enabled:
             reduce_capture.active = None
             rc = load().t2h_reduce_capture_end(stream())
+            cur = torch.cuda.current_stream() if self.keep and self.keep[0].is_cuda else None
+            for ws in self.keep:                 # (slabs written on a side stream are read by this launch on the current one)
+                ws.record_stream(cur)
             self.keep.clear()
+            self.outputs.clear()
             if exc[0] is None:
                 check(rc, "t2h_reduce_capture_end")
 
 
-def defer_reduce(ws=None) -> int:
+def defer_reduce(ws=None, out=None) -> int:
     """Flag for a weight-gradient call whose outputs nobody reads before the current backward pass ends (0 when no capture is
-    active); ``ws``: the call's workspace, kept alive until the batched reduction has run."""
+    active); ``ws``: the call's workspace, kept alive until the batched reduction has run.  ``out``: the gradient tensor -- a second
+    call into the same tensor within one capture is NOT deferred (it reduces at once, on its own stream), so the library never has
+    to flush the recorded ones early, possibly on a stream that has not been joined with their producers'."""
     cap = reduce_capture.active
     if cap is None:
         return 0
+    if out is not None:
+        key = out.data_ptr()
+        if key in cap.outputs:
+            return 0
+        cap.outputs.add(key)
     if ws is not None:
         cap.keep.append(ws)
     return DEFER_REDUCE

@@ -295,7 +295,7 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False, defer=False):
         nws = _lib.ws_bytes("t2h_conv3x3_bx3_wgrad_workspace_bytes", b, h, wd, cin, cout)
         ws = _lib.workspace(nws, gy.device)
         _lib.call(entry, _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-                  b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag() | (_lib.defer_reduce(ws) if defer else 0),
+                  b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | _bx3_flag() | (_lib.defer_reduce(ws, dw) if defer else 0),
                   _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
                   tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
@@ -303,7 +303,7 @@ def conv3x3_wgrad_(gy, x, dw, db, accumulate=False, defer=False):
     nws = _lib.ws_bytes("t2h_conv3x3_wgrad_workspace_bytes", b, h, wd, cin, cout)
     ws = _lib.workspace(nws, gy.device)
     _lib.call("t2h_conv3x3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db) if db is not None else None,
-              b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | (_lib.defer_reduce(ws) if defer else 0), _lib.ptr(ws), nws,
+              b, h, wd, cin, cout, (_lib.ACCUM if accumulate else 0) | (_lib.defer_reduce(ws, dw) if defer else 0), _lib.ptr(ws), nws,
               _lib.stream(),
               nbytes=4 * (gy.numel() + x.numel() + dw.numel()), flops=2 * 9 * cin * cout * b * h * wd,
               tag=_lib.timing() and f"t2h_conv3x3_wgrad[{cin}->{cout},{h}x{wd}]")
@@ -362,7 +362,7 @@ def _conv3x3_param_grads(gm, x, weight, bias):
             # latency-bound and leave most CUs idle; the trainer joins the stream at the end of the tile
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                conv3x3_wgrad_(gm, x, wg, bg, accumulate=True)
+                conv3x3_wgrad_(gm, x, wg, bg, accumulate=True, defer=True)
             gm.record_stream(side)
             x.record_stream(side)
         else:
@@ -617,7 +617,7 @@ class _UpConv2x2(torch.autograd.Function):
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway)
         _lib.call(up, _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
                   b, h, wd, cin, cout,
-                  ((_lib.ACCUM | _lib.defer_reduce(ws)) if direct else 0) | (_lib.F16X2 if (_h2() and up.endswith("bx3_wgrad")) else 0),
+                  ((_lib.ACCUM | _lib.defer_reduce(ws, dw)) if direct else 0) | (_lib.F16X2 if (_h2() and up.endswith("bx3_wgrad")) else 0),
                   _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                   tag=_lib.timing() and f"{up}[{cin}->{cout},{h}x{wd}]")
         ga = g if ctx.has_addend else None

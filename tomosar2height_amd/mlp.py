@@ -64,6 +64,10 @@ def _rows(t: torch.Tensor, what: str):
 GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
 
 
+_BX3_MIN_N = int(os.environ.get("T2H_GEMM_BX3_MIN_N", "128"))
+_BX3_MIN_K = int(os.environ.get("T2H_GEMM_BX3_MIN_K", "128"))
+
+
 def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
     """Where the split-bf16 form wins (measured, profiles/r04g_*): every staged A element has to be split (~6 VALU lane-operations)
     and is then used for n outputs, so narrow outputs (the r = 256 level product: 2752 -> 64, 250 us on fp32 MFMA, 278 us split) and
@@ -72,7 +76,8 @@ def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
     if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
             and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
         return False
-    return force or (n >= 128 and k >= 128 and m >= 4096)
+    min_n, min_k = _BX3_MIN_N, _BX3_MIN_K
+    return force or (n >= min_n and k >= min_k and m >= 4096)
 
 
 def _gemm_bx3(x, w, w_is_kn, bias, mask, y, relu_out, accumulate, tag):
@@ -138,7 +143,7 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False, defer=False):
         return
     ws_bytes = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, k, n)
     ws = _lib.workspace(ws_bytes, dy.device)
-    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag() | (_lib.defer_reduce(ws) if defer else 0)
+    flags = (_lib.RELU_IN if relu_in else 0) | (_lib.ACCUM if accumulate else 0) | _pflag() | (_lib.defer_reduce(ws, dw) if defer else 0)
     _lib.call("t2h_linear_wgrad", gp, ldg, xp, ldx, m, k, n, flags, dw.data_ptr(), db.data_ptr() if db is not None else None,
               ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
               tag=_lib.timing() and f"t2h_linear_wgrad[N={n},K={k}]")
@@ -187,7 +192,7 @@ def _wgrad(dy, x, w, bias, relu_in=False):
         else:
             side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
             with torch.cuda.stream(side):
-                linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True)
+                linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True, defer=True)
             dy.record_stream(side)                                  # keep the allocator from recycling them early
             x.record_stream(side)
         return None, None

@@ -90,14 +90,15 @@ class Trainer:
         self.bucket = None
         self._graph = None
         self.direct_accumulation = os.environ.get("T2H_DIRECT_ACCUM", "1") != "0"
-        # opt-in: weight-gradient GEMMs on a side stream (see mlp.direct_grad_accumulation), joined at the end of every
-        # train_step.  +2..3 % tiles/s; off by default so that per-kernel durations (the roofline accounting) are
-        # those of kernels running alone
-        self.overlap_wgrad = os.environ.get("T2H_OVERLAP_WGRAD", "0") == "1"
+        # weight-gradient GEMMs on a side stream (see mlp.direct_grad_accumulation), joined at the end of every train_step's
+        # backward (T2H_OVERLAP_WGRAD=0: A/B).  On by default since r04: with the fp16-split convolutions most launches of a
+        # B = 1 step leave CUs idle (8.94 -> 8.71 ms with both overlaps).  bench.py's per-kernel table (--kernel-table /
+        # --profile-steps) times kernels one at a time with events around each call, so its durations stay those of kernels alone
+        self.overlap_wgrad = os.environ.get("T2H_OVERLAP_WGRAD", "1") == "1"
         self._side = None
         # the weight gradients of the convolutions on planes up to 128 x 128 (latency-bound launches that leave most CUs idle)
         # beside the following layers' data gradients: T2H_OVERLAP_CONV_WGRAD=1
-        self.overlap_conv_wgrad = os.environ.get("T2H_OVERLAP_CONV_WGRAD", "0") == "1"
+        self.overlap_conv_wgrad = os.environ.get("T2H_OVERLAP_CONV_WGRAD", "1") == "1"
         self._conv_side = None
 
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
@@ -264,15 +265,18 @@ class Trainer:
             direct = self.bucket is not None and self.direct_accumulation
             # the weight gradients accumulate straight into the bucket and nothing reads it before the pass ends: their slab
             # reductions run as ONE batched launch at the end of the pass instead of one launch per layer (T2H_BATCH_REDUCE=0: A/B)
+            # (not with the side streams: there each reduction runs at once beside other kernels, which measures faster than one
+            # batched launch on an otherwise idle chip -- 8.71 against 8.95 ms per step)
             batch = (direct and loss.is_cuda and side is None and conv_side is None
                      and os.environ.get("T2H_BATCH_REDUCE", "1") != "0")
             with mlp.direct_grad_accumulation(direct, side, conv_side), _lib.reduce_capture(batch):
                 loss.backward()
-            for st in (side, conv_side):
-                if st is not None:
-                    # join: the overlap is with this tile's own backward; afterwards the gradients are visible in
-                    # stream order on the current stream like any other result
-                    torch.cuda.current_stream().wait_stream(st)
+                for st in (side, conv_side):
+                    if st is not None:
+                        # join: the overlap is with this tile's own backward; afterwards the gradients are visible in
+                        # stream order on the current stream like any other result -- and the batched reduction, which runs
+                        # when the capture block is left, reads slabs that were written on these streams
+                        torch.cuda.current_stream().wait_stream(st)
         if self.bucket is None:
             self.flush_gradients()          # (the parameters behind the composed maps must have their gradient before the bucket is laid out)
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
