@@ -44,6 +44,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+#ifndef T2H_BX3_BDIRECT
+#define T2H_BX3_BDIRECT 1      // 0: weight slabs through LDS by LDS-DMA, one barrier per step (the r04a-c form; A/B)
+#endif
 constexpr int NT = 256;
 constexpr int TW = 32;        // tile width in pixels = rows of one MFMA tile
 constexpr int CC = 32;        // reduction channels per staged chunk (wgrad; fwd / dgrad: template parameter CCH)
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     constexpr int PLANE = HP * PXB;                                      // bytes per bf16 plane
     constexpr int BSLAB = (BN / 32) * NPL * 1024;                        // bytes per weight slab
     constexpr int HALO_BYTES = NPL * PLANE;
-    constexpr int LDS_WORK = HALO_BYTES + 2 * BSLAB;
+    constexpr bool BDIRECT = T2H_BX3_BDIRECT != 0;
+    constexpr int LDS_WORK = HALO_BYTES + (BDIRECT ? 0 : 2 * BSLAB);
     constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (the epilogue's patches live in the same array)
     constexpr bool H2 = NPL == 2;                                        // the fp16 two-way split with block scales
     constexpr int WPL = H2 ? 2 : 3;                                      // planes per tile in the prepared weight buffer
@@ -331,6 +335,19 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             }
     };
 
+    // BDIRECT: every wave fetches the B fragments of its own column tiles straight from global memory / L2 into registers (the
+    // prepared weights ARE in fragment order: 1 KB per tile and plane, one dwordx4 per lane), one step ahead.  No weight slabs in
+    // LDS, so no barrier per step: the waves of a workgroup meet twice per staged chunk only and run ahead of each other in
+    // between; the loads are ordinary register loads, so the compiler's waitcnts are exact.
+    auto load_b = [&](int c, int st, uint4 (&dst)[TN][NPL]) {
+        const int sidx = (c * NQ + st % NQ) * NTAP + st / NQ;
+        const unsigned char *src = wbase + (size_t)sidx * slab_stride + lane * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) dst[j][pl] = *reinterpret_cast<const uint4 *>(src + ((wn * TN + j) * WPL + pl) * 1024);
+    };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -345,6 +362,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
         publish_block_max(c_beg & 1);
         __syncthreads();
     }
+    uint4 bnext[TN][NPL];
+    if (BDIRECT) load_b(c_beg, 0, bnext);
     int s = 0;                                                           // running step count (selects the weight buffer)
     for (int c = c_beg; c < c_end; ++c) {
         if (H2) {
@@ -366,7 +385,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             e_cur = e_run == E_UNSET ? 0 : e_run;
         }
         halo_store();                                                    // (the previous chunk's last barrier has passed)
-        if (c == c_beg) issue_b(c, 0, bbuf);                             // (later chunks: issued by the previous chunk's last step)
+        if (!BDIRECT && c == c_beg) issue_b(c, 0, bbuf);                 // (later chunks: issued by the previous chunk's last step)
         if (c + 1 < c_end) halo_load(c + 1);                             // in flight under this chunk's MFMAs
         __syncthreads();
 #pragma unroll 1
@@ -376,8 +395,6 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             for (int q = 0; q < NQ; ++q, ++s) {
                 const unsigned char *cur = bbuf + (s & 1) * BSLAB;
                 const int st = tap * NQ + q;
-                if (st + 1 < NSTEP) issue_b(c, st + 1, bbuf + ((s + 1) & 1) * BSLAB);
-                else if (c + 1 < c_end) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
                 uint4 af[TM][NPL], bfr[TN][NPL];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -386,12 +403,30 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) af[i][pl] = *reinterpret_cast<const uint4 *>(a + pl * PLANE);
                 }
+                if (BDIRECT) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl)
-                        bfr[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * NPL + pl) * 1024 + lane * 16);
+                        for (int pl = 0; pl < NPL; ++pl) bfr[j][pl] = bnext[j][pl];
+                    if (st + 1 < NSTEP) load_b(c, st + 1, bnext);
+                    else if (c + 1 < c_end) load_b(c + 1, 0, bnext);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            bfr[j][pl] = *reinterpret_cast<const uint4 *>(cur + ((wn * TN + j) * NPL + pl) * 1024 + lane * 16);
+                }
                 __builtin_amdgcn_sched_barrier(0);                       // all fragment reads in flight before the first MFMA
+                // The next slab's DMA is issued AFTER this step's fragment reads: the compiler cannot tell the DMA's LDS target from
+                // the buffer being read and puts s_waitcnt vmcnt(0) in front of every LDS read that follows a pending LDS-DMA -- issued
+                // first (r04a-c) each step waited out its own prefetch: 3 100 of the 3 900 cycles of a step (rocprofv3 SQ counters,
+                // profiles/r04d_conv_counters.txt).  Now the transfer runs under this step's MFMAs.
+                if (!BDIRECT) {
+                    if (st + 1 < NSTEP) issue_b(c, st + 1, bbuf + ((s + 1) & 1) * BSLAB);
+                    else if (c + 1 < c_end) issue_b(c + 1, 0, bbuf + ((s + 1) & 1) * BSLAB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // smallest terms first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
                 constexpr int ia[6] = {2, 0, 1, 1, 0, 0}, ib[6] = {0, 2, 1, 0, 1, 0};
                 if (H2) {                                                // h2 g1, h1 g2, h1 g1
@@ -414,9 +449,10 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8 *>(&af[i][ia[e]]),
                                                                                      *reinterpret_cast<bf16x8 *>(&bfr[j][ib[e]]), acc[i][j], 0, 0, 0);
                 }
-                __syncthreads();                                         // (also drains the next slab's DMA: vmcnt(0))
+                if (!BDIRECT) __syncthreads();                           // (also drains the next slab's DMA: vmcnt(0))
             }
         }
+        if (BDIRECT) __syncthreads();                                    // every wave is done with this chunk's halo images
     }
 
     // epilogue: one 32 x 32 tile at a time through the wave's LDS patch -> float4 rows along the output channels

@@ -69,10 +69,11 @@ _BX3_MIN_K = int(os.environ.get("T2H_GEMM_BX3_MIN_K", "128"))
 
 
 def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
-    """Where the split-bf16 form wins (measured, profiles/r04g_*): every staged A element has to be split (~6 VALU lane-operations)
-    and is then used for n outputs, so narrow outputs (the r = 256 level product: 2752 -> 64, 250 us on fp32 MFMA, 278 us split) and
-    one-chunk reductions (64 -> 2752) stay on the fp32 kernels; from 128 outputs / 128-deep reductions / 4096 rows up the split form
-    is 7-22 % faster (2368 -> 256 at 64^2: 72 -> 56 us)."""
+    """Where the split form (csrc/conv_bx3.hip, 1-tap) wins, measured.  Every staged A element has to be split and is then used for
+    n outputs, and the kernel streams A with one chunk in flight per workgroup: with the bf16 three-way split narrow outputs lost
+    (the r = 256 level product 2752 -> 64: 250 us on fp32 MFMA, 278 us split); with the fp16 two-way split and the weights fetched
+    straight into registers (r04d) it is 197 us (profiles/gemm_layout_probe.py), so 64 outputs are in.  One-chunk reductions that
+    only WRITE a wide matrix (64 -> 2752: 274 us split against 247 us) stay on the fp32 kernels."""
     if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
             and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
         return False
