@@ -849,13 +849,13 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int up
     do {                                                                                                                    \
         if (npl == 1) {                                                                                                     \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",1," #NTAP_ ">");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",1," #NTAP_ ",0>");                      \
         } else if (npl == 2) {                                                                                              \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 2, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",2," #NTAP_ ">");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",2," #NTAP_ ",0>");                      \
         } else {                                                                                                            \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",3," #NTAP_ ">");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",3," #NTAP_ ",0>");                      \
         }                                                                                                                   \
     } while (0)
 
@@ -1031,17 +1031,17 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
     if (flags & T2H_F16X2) {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,2>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,false>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,2,false>"); }
     } else if (flags & T2H_BF16) {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,1>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,1>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,1>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,1,false>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,1,false>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,1,false>"); }
     } else {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,3>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,false>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,false>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,3,false>"); }
     }
     if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
