@@ -127,7 +127,7 @@ def set_conv_precision(name: str = None):
 
 def bx3_applicable(b: int, h: int, wd: int, cin: int, cout: int) -> bool:
     return (CONV_PRECISION in ("bf16x3", "f16x2", "bf16") and h * wd >= BX3_MIN_PIXELS
-            and bool(_lib.load().t2h_conv3x3_bx3_supported(b, h, wd, cin, cout)))
+            and bool(_lib.ws_bytes("t2h_conv3x3_bx3_supported", b, h, wd, cin, cout)))      # (memoised like the workspace queries)
 
 
 def _bx3_flag() -> int:
@@ -548,7 +548,7 @@ def _up_bx3(x, weight, w) -> bool:
     gathering loader) when the precision mode asks for them, the shape fits and the weight already lies [Cin][2][2][Cout]."""
     b, cin, h, wd = x.shape
     return bool(UPCONV_BX3 and CONV_PRECISION in ("bf16x3", "f16x2", "bf16") and w is weight and b * h * wd >= BX3_MIN_PIXELS
-                and _lib.load().t2h_upconv2x2_bx3_supported(b, h, wd, cin, weight.shape[1]))
+                and _lib.ws_bytes("t2h_upconv2x2_bx3_supported", b, h, wd, cin, weight.shape[1]))
 
 
 class _UpConv2x2(torch.autograd.Function):

@@ -74,7 +74,7 @@ def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
     (the r = 256 level product 2752 -> 64: 250 us on fp32 MFMA, 278 us split); with the fp16 two-way split and the weights fetched
     straight into registers (r04d) it is 197 us (profiles/gemm_layout_probe.py), so 64 outputs are in.  One-chunk reductions that
     only WRITE a wide matrix (64 -> 2752: 274 us split against 247 us) stay on the fp32 kernels."""
-    if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.load().t2h_gemm_bx3_supported(m, k, n))
+    if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.ws_bytes("t2h_gemm_bx3_supported", m, k, n))
             and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
         return False
     min_n, min_k = _BX3_MIN_N, _BX3_MIN_K
