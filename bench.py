@@ -622,9 +622,17 @@ def main():
     timeline = None
     if args.profile_steps > 0 and not args.hip_graph:
         timeline = _lib.KernelTimeline()
-        with timeline:
-            run(args.profile_steps)
-        fence()
+        # per-kernel durations are those of kernels running ALONE: the side streams of the timed step (weight gradients beside the
+        # data-gradient chain) are switched off for this untimed leg, so a kernel's events do not span another kernel's time on
+        # shared CUs.  (The timed region above keeps them on; the sum of these durations therefore exceeds ms_per_step's GPU share.)
+        saved_overlap = (trainer.overlap_wgrad, trainer.overlap_conv_wgrad)
+        trainer.overlap_wgrad = trainer.overlap_conv_wgrad = False
+        try:
+            with timeline:
+                run(args.profile_steps)
+            fence()
+        finally:
+            trainer.overlap_wgrad, trainer.overlap_conv_wgrad = saved_overlap
     # one optimizer boundary on its own (all-reduce + AdamW + bucket zero), between two events on the compute stream
     fence()
     eb, ee = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -700,8 +708,9 @@ def main():
                     out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
-                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps; "
-                                          "class totals: sum(algorithmic flops or bytes) / sum(duration)")
+                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps with the "
+                                          "side streams off (kernels alone); class totals: sum(algorithmic flops or bytes) / "
+                                          "sum(duration)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"])))
                                                   for n in SCATTER_REDUCE_TAGS if n in named]

@@ -92,8 +92,8 @@ class Trainer:
         self.direct_accumulation = os.environ.get("T2H_DIRECT_ACCUM", "1") != "0"
         # weight-gradient GEMMs on a side stream (see mlp.direct_grad_accumulation), joined at the end of every train_step's
         # backward (T2H_OVERLAP_WGRAD=0: A/B).  On by default since r04: with the fp16-split convolutions most launches of a
-        # B = 1 step leave CUs idle (8.94 -> 8.71 ms with both overlaps).  bench.py's per-kernel table (--kernel-table /
-        # --profile-steps) times kernels one at a time with events around each call, so its durations stay those of kernels alone
+        # B = 1 step leave CUs idle (8.94 -> 8.71 ms with both overlaps).  bench.py switches them off for its untimed per-kernel leg
+        # (--profile-steps), so the durations of its kernel table stay those of kernels running alone
         self.overlap_wgrad = os.environ.get("T2H_OVERLAP_WGRAD", "1") == "1"
         self._side = None
         # the weight gradients of the convolutions on planes up to 128 x 128 (latency-bound launches that leave most CUs idle)
