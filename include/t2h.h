@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 11
+#define T2H_ABI_VERSION 12
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -407,6 +407,21 @@ size_t t2h_conv3x3_f16x2_weights_bytes(int Cin, int Cout);
 int t2h_conv3x3_f16x2_prepare(const float *w, int Cin, int Cout, int transposed, void *wf, t2h_stream_t stream);
 size_t t2h_gemm_f16x2_weights_bytes(int K, int N);
 int t2h_gemm_f16x2_prepare(const float *w, int ldw, int K, int N, int w_is_kn, void *wf, t2h_stream_t stream);
+
+/* Every split weight of a model in a few launches (24 buffers per launch; the weights change once per optimizer step, trainer.py:78-84,
+ * and preparing ~110 buffers one by one cost 0.85 ms of host time after each step).  One descriptor per prepared buffer:
+ *   kind 0 / 1: the 3x3 weight [Cout][3][3][Cin] forward / transposed (a = Cin, b = Cout) -- t2h_conv3x3_{bx3,f16x2}_prepare
+ *   kind 2 / 3: a matrix stored [K][N] / [N][K] with row stride ldw (a = K, b = N)        -- t2h_gemm_{bx3,f16x2}_prepare
+ *   h2: 1 = fp16 two-plane buffer (T2H_F16X2), 0 = bf16 three-plane buffer;  trailer_word = planes bytes / 4 (h2 only);
+ *   maxslot (h2 only): 0 or 3, ALTERNATING between consecutive runs on the same buffer, which must start zeroed -- each run clears
+ *   the word the next one accumulates max |w| into, so no memset runs in between. */
+typedef struct t2h_prep_desc {
+    const float *w;
+    void *wf;
+    int kind, h2, a, b, ldw, maxslot;
+    unsigned trailer_word, reserved;
+} t2h_prep_desc;
+int t2h_split_weights_batch(const t2h_prep_desc *descs, int n, t2h_stream_t stream);
 
 /* ConvTranspose2d(kernel_size = 2, stride = 2) (upconv2x2, alto.py:175,215-218,236) on the same 1-tap kernels.  The forward is the
  * GEMM [B H W, Cin] x [Cin, (tap, co)] with a scattering epilogue: column tile -> tap = 2 dy + dx -> output pixel (2y + dy, 2x + dx),

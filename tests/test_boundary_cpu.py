@@ -154,6 +154,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upconv2x2_bx3_wgrad": (n, n, n, n, 1, 16, 32, 64, 64, 0, n, 0, n),
         "t2h_conv3x3_f16x2_prepare": (n, 32, 32, 0, n, n),
         "t2h_gemm_f16x2_prepare": (n, 64, 64, 32, 0, n, n),
+        "t2h_split_weights_batch": (n, 1, n),
         "t2h_gemm_bx3": (n, 64, n, n, n, 0, n, 32, 128, 64, 32, 0, n, 0, n),
         "t2h_upconv2x2_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
         "t2h_upconv2x2_fwd_add": (n, n, n, n, n, 1, 32, 32, 32, 32, 0, n),

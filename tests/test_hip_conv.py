@@ -737,3 +737,36 @@ def test_unsupported_geometry_raises_unless_allowed():
     with t2h.allow_library_fallback():
         y = grid.conv_bias_act(x, conv)
     assert y.shape == (1, 16, 32, 32) and sum(t2h.fallback_counts(reset=True).values()) == 1
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3"])
+def test_batched_weight_preparation_equals_the_single_calls(mode, monkeypatch):
+    """``SplitWeightCache.refresh`` (t2h_split_weights_batch: all buffers in a few launches, alternating max slots for the fp16
+    buffers) leaves exactly the bytes the per-buffer preparation leaves -- 3x3 weights in both orientations, a matrix in both
+    layouts, a transposed-convolution weight -- run after run, and follows in-place weight updates."""
+    from tomosar2height_amd import grid
+    monkeypatch.setattr(grid, "CONV_PRECISION", mode)
+    cache = grid.SplitWeightCache()
+    g = torch.Generator().manual_seed(4)
+    w3 = _cl(torch.randn(64, 32, 3, 3, generator=g))
+    wm = (torch.randn(128, 192, generator=g) * 3).to(_dev())
+    wu = torch.randn(64, 64, 2, 2, generator=g).to(_dev()).contiguous(memory_format=torch.channels_last)
+    def single():
+        fresh = grid.SplitWeightCache()
+        return [fresh.get(w3, False).clone(), fresh.get(w3, True).clone(), fresh.get_gemm(wm, False).clone(),
+                fresh.get_gemm(wm, True).clone(), fresh.get_up(wu, True).clone(), fresh.get_up(wu, False).clone()]
+    bufs = [cache.get(w3, False), cache.get(w3, True), cache.get_gemm(wm, False), cache.get_gemm(wm, True), cache.get_up(wu, True),
+            cache.get_up(wu, False)]
+    planes = (lambda t: t[:-256]) if mode == "f16x2" else (lambda t: t)
+    for rnd in range(4):
+        with torch.no_grad():
+            w3.mul_(1.7); wm.add_(0.25); wu.mul_(-0.6)                      # scale changes: the fp16 buffers' exponents move
+        cache.refresh(stale_only=bool(rnd & 1))
+        want = single()
+        for got, ref in zip(bufs, want):
+            assert torch.equal(planes(got), planes(ref))
+            if mode == "f16x2":                                              # 2^-e_w and e_w of the trailer
+                assert torch.equal(got[-256:].view(torch.int32)[1:3], ref[-256:].view(torch.int32)[1:3])
+    before = [b.clone() for b in bufs]
+    cache.refresh(stale_only=True)                                           # nothing moved: nothing launched, nothing changed
+    assert all(torch.equal(a, b) for a, b in zip(before, bufs))

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -104,6 +104,7 @@ SIGNATURES = {
     "t2h_conv3x3_f16x2_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_gemm_f16x2_weights_bytes": (_sz, [_i, _i]),
     "t2h_gemm_f16x2_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "t2h_split_weights_batch": (_i, [_vp, _i, _vp]),
     "t2h_gemm_bx3": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_reduce_capture_begin": (_i, []),
     "t2h_reduce_capture_pending": (_i, []),
@@ -141,6 +142,13 @@ SIGNATURES = {
 }
 
 RELU_IN, RELU_OUT, ACCUM, BF16, BF16X3, DEFER_REDUCE, F16X2 = 1, 2, 4, 8, 16, 32, 64
+
+
+class PrepDesc(ctypes.Structure):
+    """``t2h_prep_desc`` of include/t2h.h (one prepared weight buffer of ``t2h_split_weights_batch``)."""
+    _fields_ = [("w", ctypes.c_void_p), ("wf", ctypes.c_void_p), ("kind", ctypes.c_int), ("h2", ctypes.c_int), ("a", ctypes.c_int),
+                ("b", ctypes.c_int), ("ldw", ctypes.c_int), ("maxslot", ctypes.c_int), ("trailer_word", ctypes.c_uint),
+                ("reserved", ctypes.c_uint)]
 
 
 class reduce_capture:

@@ -106,13 +106,14 @@ __device__ inline float abs4max(float m, const float4 &v) { return fmaxf(fmaxf(m
 // gradient): k = output channel, col = input channel, tap flipped: W[k][8 - tap][col].
 // H2: two f16 planes of w 2^e_w instead (e_w from the tensor's largest magnitude, left in `trailer[0]` by absmax_kernel; trailer[1]
 // receives 2^-e_w for the consumers' epilogues)
-template <bool TRANSPOSED, bool H2 = false>
-__global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restrict__ w, int Cin, int Cout,
-                                                         unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
+// `maxslot` (H2): index of the trailer word that holds the bits of max |w| (0 for the single-weight entry points; the batched
+// preparation alternates between words 0 and 3 and clears the other one for its next run)
+template <bool TRANSPOSED, bool H2>
+__device__ inline void prepare_conv_body(const float *__restrict__ w, int Cin, int Cout, unsigned *__restrict__ wf,
+                                         unsigned *__restrict__ trailer, int maxslot, long long t) {
     const int Kc = TRANSPOSED ? Cout : Cin, Nc = TRANSPOSED ? Cin : Cout;
     const int ntile = Nc / 32;
     const long long total = (long long)(Kc / 16) * 9 * ntile * 64;        // one thread per (slab, tile, lane)
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int lane = (int)(t & 63);
     const int tile = (int)((t >> 6) % ntile);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
     unsigned p1[4], p2[4], p3[4];
     int ew = 0;
     if (H2) {
-        ew = block_exponent(trailer[0]);
+        ew = block_exponent(trailer[maxslot]);
         ew = ew == E_UNSET ? 0 : ew;
         if (t == 0) { reinterpret_cast<float *>(trailer)[1] = ldexpf(1.0f, -ew); reinterpret_cast<int *>(trailer)[2] = ew; }
     }
@@ -145,25 +146,32 @@ __global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restric
     dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
     if (!H2) dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
 }
+template <bool TRANSPOSED, bool H2 = false>
+__global__ __launch_bounds__(256) void bx3_prepare_kernel(const float *__restrict__ w, int Cin, int Cout,
+                                                         unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
+    prepare_conv_body<TRANSPOSED, H2>(w, Cin, Cout, wf, trailer, 0, (long long)blockIdx.x * 256 + threadIdx.x);
+}
 
 // largest magnitude of a [rows][cols] matrix with row stride ld, as float bits (non-negative floats order like unsigned ints)
-__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w, long long rows, int cols, long long ld,
-                                                    unsigned *__restrict__ out) {
+__device__ inline void absmax_body(const float *__restrict__ w, long long rows, int cols, long long ld, unsigned *__restrict__ out,
+                                   long long first, long long stride) {
     float m = 0.f;
     const long long total = rows * cols;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-        m = fmaxf(m, fabsf(w[(i / cols) * ld + i % cols]));
+    for (long long i = first; i < total; i += stride) m = fmaxf(m, fabsf(w[(i / cols) * ld + i % cols]));
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ w, long long rows, int cols, long long ld,
+                                                    unsigned *__restrict__ out) {
+    absmax_body(w, rows, cols, ld, out, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}
 
 // the same for a plain weight matrix (1-tap form): W given as [N][K] (nn.Linear: k contiguous) or, KN, as [K][N]
-template <bool KN, bool H2 = false>
-__global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__restrict__ w, int K, int N, int ldw,
-                                                              unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
+template <bool KN, bool H2>
+__device__ inline void prepare_gemm_body(const float *__restrict__ w, int K, int N, int ldw, unsigned *__restrict__ wf,
+                                         unsigned *__restrict__ trailer, int maxslot, long long t) {
     const int ntile = N / 32;
     const long long total = (long long)(K / 16) * ntile * 64;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int lane = (int)(t & 63);
     const int tile = (int)((t >> 6) % ntile);
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__re
     unsigned p1[4], p2[4], p3[4];
     int ew = 0;
     if (H2) {
-        ew = block_exponent(trailer[0]);
+        ew = block_exponent(trailer[maxslot]);
         ew = ew == E_UNSET ? 0 : ew;
         if (t == 0) { reinterpret_cast<float *>(trailer)[1] = ldexpf(1.0f, -ew); reinterpret_cast<int *>(trailer)[2] = ew; }
     }
@@ -188,6 +196,56 @@ __global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__re
     dst[0] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
     dst[64] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
     if (!H2) dst[128] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+template <bool KN, bool H2 = false>
+__global__ __launch_bounds__(256) void bx3_prepare_gemm_kernel(const float *__restrict__ w, int K, int N, int ldw,
+                                                              unsigned *__restrict__ wf, unsigned *__restrict__ trailer = nullptr) {
+    prepare_gemm_body<KN, H2>(w, K, N, ldw, wf, trailer, 0, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// ---- batched preparation: every split weight of a model in a few launches (once per optimizer step) -------------------------------
+// One descriptor per prepared buffer (t2h_prep_desc in include/t2h.h; kind 0 / 1 = 3x3 weight forward / transposed, 2 / 3 = matrix
+// [K][N] / [N][K]); `first` = the descriptor's first workgroup in the launch.  fp16 buffers: pass 1 (absmax) leaves the bits of
+// max |w| in trailer word `maxslot` (0 or 3, alternating from run to run: the split pass clears the OTHER word for the next run, so
+// no memset is needed between runs; the buffers start zeroed), pass 2 splits.
+constexpr int kPrepBatch = 24;
+struct PrepBatch {
+    int n;
+    t2h_prep_desc d[kPrepBatch];
+    unsigned first[kPrepBatch + 1];
+};
+__device__ inline int prep_find(const PrepBatch &b, unsigned blk) {
+    int i = 0;
+    while (i + 1 < b.n && blk >= b.first[i + 1]) ++i;
+    return i;
+}
+__global__ __launch_bounds__(256) void prep_absmax_batch_kernel(PrepBatch b) {
+    const int i = prep_find(b, blockIdx.x);
+    const t2h_prep_desc &d = b.d[i];
+    const unsigned nblk = b.first[i + 1] - b.first[i];
+    const bool conv = d.kind < 2;
+    const long long rows = conv ? 1 : (d.kind == 2 ? d.a : d.b);           // matrix rows as stored
+    const int cols = conv ? d.a * 9 * d.b : (d.kind == 2 ? d.b : d.a);
+    absmax_body(d.w, rows, cols, conv ? 0 : d.ldw, static_cast<unsigned *>(d.wf) + d.trailer_word + d.maxslot,
+                (long long)(blockIdx.x - b.first[i]) * 256 + threadIdx.x, (long long)nblk * 256);
+}
+__global__ __launch_bounds__(256) void prep_split_batch_kernel(PrepBatch b) {
+    const int i = prep_find(b, blockIdx.x);
+    const t2h_prep_desc &d = b.d[i];
+    const long long t = (long long)(blockIdx.x - b.first[i]) * 256 + threadIdx.x;
+    unsigned *wf = static_cast<unsigned *>(d.wf), *trailer = wf + d.trailer_word;
+    if (d.h2) {
+        if (t == 0) trailer[d.maxslot ^ 3] = 0u;                            // the other slot, for the next run
+        if (d.kind == 0) prepare_conv_body<false, true>(d.w, d.a, d.b, wf, trailer, d.maxslot, t);
+        else if (d.kind == 1) prepare_conv_body<true, true>(d.w, d.a, d.b, wf, trailer, d.maxslot, t);
+        else if (d.kind == 2) prepare_gemm_body<true, true>(d.w, d.a, d.b, d.ldw, wf, trailer, d.maxslot, t);
+        else prepare_gemm_body<false, true>(d.w, d.a, d.b, d.ldw, wf, trailer, d.maxslot, t);
+    } else {
+        if (d.kind == 0) prepare_conv_body<false, false>(d.w, d.a, d.b, wf, nullptr, 0, t);
+        else if (d.kind == 1) prepare_conv_body<true, false>(d.w, d.a, d.b, wf, nullptr, 0, t);
+        else if (d.kind == 2) prepare_gemm_body<true, false>(d.w, d.a, d.b, d.ldw, wf, nullptr, 0, t);
+        else prepare_gemm_body<false, false>(d.w, d.a, d.b, d.ldw, wf, nullptr, 0, t);
+    }
 }
 
 // ---- fwd / dgrad --------------------------------------------------------------------------------------------------------------
@@ -1241,4 +1299,33 @@ T2H_API int t2h_gemm_f16x2_prepare(const float *w, int ldw, int K, int N, int w_
     if (w_is_kn) hipLaunchKernelGGL((bx3_prepare_gemm_kernel<true, true>), dim3(blocks), dim3(256), 0, s, w, K, N, ldw, static_cast<unsigned *>(wf), trailer);
     else hipLaunchKernelGGL((bx3_prepare_gemm_kernel<false, true>), dim3(blocks), dim3(256), 0, s, w, K, N, ldw, static_cast<unsigned *>(wf), trailer);
     return check_launch("gemm_f16x2_prepare");
+}
+
+// ---- batched preparation --------------------------------------------------------------------------------------------------------------
+T2H_API int t2h_split_weights_batch(const t2h_prep_desc *descs, int n, t2h_stream_t stream) {
+    if (n < 0 || (n > 0 && !descs)) return fail(T2H_ERR_ARG, "split_weights_batch: bad descriptor list");
+    hipStream_t s = as_stream(stream);
+    for (int base = 0; base < n; base += kPrepBatch) {
+        PrepBatch bm{}, bs{};
+        unsigned mblocks = 0, sblocks = 0;
+        const int cnt = std::min(kPrepBatch, n - base);
+        for (int i = 0; i < cnt; ++i) {
+            const t2h_prep_desc &d = descs[base + i];
+            const bool conv = d.kind < 2;
+            if (!d.w || !d.wf || d.kind < 0 || d.kind > 3 || d.a < 16 || d.b < 16 || !al16(d.wf) || (d.h2 && d.maxslot != 0 && d.maxslot != 3))
+                return fail(T2H_ERR_ARG, "split_weights_batch: descriptor %d is malformed", base + i);
+            // (a, b) = (Cin, Cout) for the 3x3 weights, (K, N) for the matrices
+            const int Kc = conv ? (d.kind == 1 ? d.b : d.a) : d.a, Nc = conv ? (d.kind == 1 ? d.a : d.b) : d.b;
+            if (Kc % 16 || Nc % 32) return fail(T2H_ERR_ARG, "split_weights_batch: descriptor %d: K=%d %% 16, N=%d %% 32", base + i, Kc, Nc);
+            const long long threads = (long long)(Kc / 16) * (conv ? 9 : 1) * (Nc / 32) * 64;
+            const long long elems = conv ? (long long)d.a * 9 * d.b : (long long)d.a * d.b;
+            if (threads > (1LL << 31) || elems > (1LL << 31)) return fail(T2H_ERR_ARG, "split_weights_batch: descriptor %d too large", base + i);
+            bs.d[i] = d; bs.first[i] = sblocks; sblocks += (unsigned)((threads + 255) / 256);
+            if (d.h2) { bm.d[bm.n] = d; bm.first[bm.n] = mblocks; mblocks += (unsigned)std::min<long long>((elems + 4095) / 4096, 64); ++bm.n; }
+        }
+        bs.n = cnt; bs.first[cnt] = sblocks; bm.first[bm.n] = mblocks;
+        if (bm.n) hipLaunchKernelGGL(prep_absmax_batch_kernel, dim3(mblocks), dim3(256), 0, s, bm);
+        hipLaunchKernelGGL(prep_split_batch_kernel, dim3(sblocks), dim3(256), 0, s, bs);
+    }
+    return check_launch("split_weights_batch");
 }

@@ -157,10 +157,10 @@ class SplitWeightCache:
             lib = _lib.load()
             nbytes = int((lib.t2h_conv3x3_f16x2_weights_bytes if _h2() else lib.t2h_conv3x3_bx3_weights_bytes)(cin, cout))
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf, 3]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare(w, key[1], e[3])
-            e[1], e[2] = w._version, w.data_ptr()
+            e[1], e[2], e[4] = w._version, w.data_ptr(), 3
         return e[3]
 
     @staticmethod
@@ -181,10 +181,10 @@ class SplitWeightCache:
             lib = _lib.load()
             buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
                               dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare_gemm(w, key[1], e[3])
-            e[1], e[2] = w._version, w.data_ptr()
+            e[1], e[2], e[4] = w._version, w.data_ptr(), 3
         return e[3]
 
     @staticmethod
@@ -206,10 +206,10 @@ class SplitWeightCache:
             lib = _lib.load()
             buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
                               dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare_up(w, key[1], e[3])
-            e[1], e[2] = w._version, w.data_ptr()
+            e[1], e[2], e[4] = w._version, w.data_ptr(), 3
         return e[3]
 
     @staticmethod
@@ -220,19 +220,40 @@ class SplitWeightCache:
         _lib.call("t2h_gemm_f16x2_prepare" if h2 else "t2h_gemm_bx3_prepare", _lib.ptr(w), n4, k, n, 1 if w_is_kn else 0,
                   _lib.ptr(buf), _lib.stream(), nbytes=(12 if h2 else 10) * w.numel())
 
-    def refresh(self):
-        """Re-split every live weight into its existing buffer."""
+    def refresh(self, stale_only: bool = False):
+        """Re-split every live weight (``stale_only``: those whose version counter or storage moved) into its existing buffer, all
+        of them in a few launches (``t2h_split_weights_batch``: 24 buffers per launch instead of 1-3 launches per buffer --
+        ``Trainer.optimizer_boundary`` calls this right after the optimizer step, so the tiles that follow find every buffer
+        current and launch nothing)."""
+        todo = []
         for (_, kind), e in list(self.entries.items()):
             w = e[0]()
-            if w is None:
+            if w is None or not w.is_cuda or (stale_only and e[1] == w._version and e[2] == w.data_ptr()):
                 continue
-            if isinstance(kind, str) and kind.startswith("up_"):
-                self._prepare_up(w, kind, e[3])
+            d = _lib.PrepDesc()
+            d.w, d.wf = w.data_ptr(), e[3].data_ptr()
+            if isinstance(kind, str) and kind.startswith("up_"):           # [Cin, Cout, 2, 2] as the matrix [Cin][4 Cout]
+                kn, h2 = kind.startswith("up_kn"), kind.endswith("_h2")
+                cin, n4 = w.shape[0], 4 * w.shape[1]
+                d.kind, d.a, d.b, d.ldw = (2, cin, n4, n4) if kn else (3, n4, cin, n4)
             elif isinstance(kind, str) and kind[:2] in ("kn", "nk"):
-                self._prepare_gemm(w, kind, e[3])
+                kn, h2 = kind.startswith("kn"), kind.endswith("_h2")
+                if w.dim() != 2 or w.stride(1) != 1:
+                    continue
+                d.kind, d.a, d.b, d.ldw = (2, w.shape[0], w.shape[1], w.stride(0)) if kn else (3, w.shape[1], w.shape[0], w.stride(0))
             else:
-                self._prepare(w, kind, e[3])
-            e[1], e[2] = w._version, w.data_ptr()
+                h2 = kind in ("h2t", "h2f")
+                if not w.permute(0, 2, 3, 1).is_contiguous():
+                    continue
+                d.kind, d.a, d.b, d.ldw = (1 if kind in (True, "h2t") else 0), w.shape[1], w.shape[0], 0
+            d.h2, d.maxslot, d.trailer_word = int(h2), e[4], (e[3].numel() - 256) // 4 if h2 else 0
+            todo.append((d, e, w))
+        if not todo:
+            return
+        arr = (_lib.PrepDesc * len(todo))(*[t[0] for t in todo])
+        _lib.call("t2h_split_weights_batch", ctypes.addressof(arr), len(todo), _lib.stream())
+        for d, e, w in todo:
+            e[1], e[2], e[4] = w._version, w.data_ptr(), (e[4] ^ 3) if d.h2 else e[4]
 
 
 split_weights = SplitWeightCache()

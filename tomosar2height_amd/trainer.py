@@ -326,11 +326,11 @@ class Trainer:
             # included, bumps the parameters' version counters, which ComposeCache.get compares -- but a replayed hipGraph
             # runs no Python per tile.)
             self.compose_cache.refresh()
-        if self._graph is not None:
-            # a replayed hipGraph runs no Python per tile: the split (bf16 x 3) copies of the convolution weights and of the
-            # composed maps are refreshed here, in place (eagerly they follow the tensors' version counters by themselves)
-            from . import grid
-            grid.split_weights.refresh()
+        # the split copies of the convolution weights (and of the matrices of the grid-side products) follow the new weights here,
+        # all of them in a few launches (grid.SplitWeightCache.refresh): a replayed hipGraph runs no Python per tile, and eagerly
+        # the first tile after the step would otherwise prepare ~110 buffers one by one (0.85 ms of host time)
+        from . import grid
+        grid.split_weights.refresh(stale_only=self._graph is None)
         if self.scheduler is not None:
             self.scheduler.step()                                         # train.py:188-190: once per iteration
         with torch.no_grad():
