@@ -132,6 +132,25 @@ def pmc_traffic():
         return {}, None
 
 
+# entry points that are several device kernels and note no symbol of their own: HBM traffic per CALL = the launch-weighted sum of
+# their kernels' PMC traffic over the entry point's calls per step (bench-pass figures of profiles/pmc_traffic.json)
+ENTRY_KERNELS = {"t2h_sample_bwd_from_sums": ("sample_bwd_walk_kernel<0>", "sample_bwd_walk_kernel<1>", "sample_bwd_gather4_kernel",
+                                              "sample_bwd_gather9_kernel")}
+
+
+def entry_traffic(symbol, calls_per_step):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            d = json.load(f)
+        per, det = d["bytes_per_launch"], d["detail"]
+        parts = [k for k in ENTRY_KERNELS.get(symbol, ()) if k in per and "launches_per_step" in det.get(k, {})]
+        if not parts or calls_per_step <= 0:
+            return None
+        return int(sum(per[k] * det[k]["launches_per_step"] for k in parts) / calls_per_step)
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def rocprof_durations():
     """Per-kernel-symbol durations of a `rocprofv3 --kernel-trace` run of THIS command (steady state, last 6 tile-steps), committed
     by profiles/run_profiles.sh as profiles/rocprof_kernels.json.  NOT measured in this run: HIP-event pairs around single launches
@@ -696,7 +715,10 @@ def main():
             traffic, traffic_src = pmc_traffic() if (args.points == 131072 and not args.from_producer) else ({}, None)
             named = {k["kernel"]: k for k in tags}
             if syms:
-                out["roofline"] = roof(syms[0], traffic.get(syms[0]["kernel"]))       # the kernel symbol with the largest time share
+                top_traffic = traffic.get(syms[0]["kernel"])
+                if top_traffic is None and traffic:
+                    top_traffic = entry_traffic(syms[0]["kernel"], syms[0]["launches_per_step"])
+                out["roofline"] = roof(syms[0], top_traffic)                          # the kernel symbol with the largest time share
                 prof_us, prof_src = rocprof_durations()
                 if syms[0]["kernel"] in prof_us and args.points == 131072 and args.train_batch == 1 and not args.use_image:
                     # the profiler's duration of the same symbol (committed trace of the same command): `frac` stays on the
