@@ -358,7 +358,33 @@ def ws_bytes(name: str, *args) -> int:
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Scratch buffer from PyTorch's caching allocator (the library itself never allocates)."""
-    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    o = _on_stream
+    if o is not None:
+        t.record_stream(o[1])           # allocated under torch's current stream, used on the overriding one
+    return t
+
+
+_on_stream = None       # (raw hipStream_t, torch stream) while an ``on_stream`` block is active
+
+
+class on_stream:
+    """``with _lib.on_stream(side):`` -- the C-ABI launches (``_lib.stream()``) and workspaces of the block go to ``side`` WITHOUT
+    switching torch's current stream: ``torch.cuda.stream(...)`` / ``torch.cuda.current_stream()`` each cost a device-count query
+    (13 us, ~110 of them per tile-step with the weight gradients on a side stream: 1.4 ms of host time).  Only for blocks that
+    launch through this module; tensors the block reads must be ``record_stream``-ed by the caller as with any side stream."""
+
+    def __init__(self, st):
+        self.pair = (st.cuda_stream, st)
+
+    def __enter__(self):
+        global _on_stream
+        self.prev, _on_stream = _on_stream, self.pair
+        return self
+
+    def __exit__(self, *exc):
+        global _on_stream
+        _on_stream = self.prev
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -368,6 +394,9 @@ _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 def stream() -> int:
     """The current torch stream of the current device as a raw hipStream_t.  Called once per launch (~470 times per
     tile-step): the raw getter avoids constructing a ``torch.cuda.Stream`` object each time (~3 us -> ~0.3 us)."""
+    o = _on_stream
+    if o is not None:
+        return o[0]
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream

@@ -383,8 +383,7 @@ def _conv3x3_param_grads(gm, x, weight, bias):
             # small planes: the weight gradient (off the backward's critical path: nothing reads the bucket before the
             # optimizer step) runs on a side stream beside the next layers' data gradients -- these launches are
             # latency-bound and leave most CUs idle; the trainer joins the stream at the end of the tile
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+            with mlp.fork_to(side):
                 conv3x3_wgrad_(gm, x, wg, bg, accumulate=True, defer=True)
             gm.record_stream(side)
             x.record_stream(side)
@@ -640,9 +639,7 @@ class _UpConv2x2(torch.autograd.Function):
         # 3x3 weight gradients on the trainer's side stream when there is one (_conv3x3_param_grads) -- unless g is also handed on
         # as the addend's gradient: its consumer may accumulate into it in place on the main stream (mlp.sole_owner)
         side = mlp._CONV_WGRAD_STREAM if (direct and not ctx.has_addend) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        with mlp.fork_to(side) if side is not None else contextlib.nullcontext():
             ws = _lib.workspace(nws, g.device)
             _lib.call(up, _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
                       b, h, wd, cin, cout,

@@ -152,7 +152,15 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False, defer=False):
 
 _DIRECT_ACCUM = False
 _WGRAD_STREAM = None
-_CONV_WGRAD_STREAM = None        # side stream for the small-plane convolution weight gradients (grid._conv3x3_param_grads)
+_CONV_WGRAD_STREAM = None        # side stream for the convolution weight gradients (grid._conv3x3_param_grads)
+_MAIN_STREAM = None              # torch's current stream when the block was entered (what the side streams fork from)
+
+
+def fork_to(side):
+    """Order ``side`` behind everything issued so far on the stream the backward pass runs on, then launch there:
+    ``with mlp.fork_to(side): <C-ABI calls>`` (``_lib.on_stream``: torch's current stream is not switched)."""
+    side.wait_stream(_MAIN_STREAM if _MAIN_STREAM is not None else torch.cuda.current_stream())
+    return _lib.on_stream(side)
 
 
 class direct_grad_accumulation:
@@ -171,17 +179,21 @@ class direct_grad_accumulation:
         self.conv_side_stream = conv_side_stream if enabled else None
 
     def __enter__(self):
-        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM
+        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM, _MAIN_STREAM
         self.prev, _DIRECT_ACCUM = _DIRECT_ACCUM, self.enabled
         self.prev_stream, _WGRAD_STREAM = _WGRAD_STREAM, self.side_stream
         self.prev_conv_stream, _CONV_WGRAD_STREAM = _CONV_WGRAD_STREAM, self.conv_side_stream
+        self.prev_main = _MAIN_STREAM
+        if self.side_stream is not None or self.conv_side_stream is not None:
+            _MAIN_STREAM = torch.cuda.current_stream()          # (once per pass: the autograd engine runs the backward on it)
         return self
 
     def __exit__(self, *exc):
-        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM
+        global _DIRECT_ACCUM, _WGRAD_STREAM, _CONV_WGRAD_STREAM, _MAIN_STREAM
         _DIRECT_ACCUM = self.prev
         _WGRAD_STREAM = self.prev_stream
         _CONV_WGRAD_STREAM = self.prev_conv_stream
+        _MAIN_STREAM = self.prev_main
 
 
 def _wgrad(dy, x, w, bias, relu_in=False):
@@ -191,8 +203,7 @@ def _wgrad(dy, x, w, bias, relu_in=False):
         if side is None:
             linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True, defer=True)
         else:
-            side.wait_stream(torch.cuda.current_stream())          # dy / x are produced on the main stream
-            with torch.cuda.stream(side):
+            with fork_to(side):                                     # dy / x are produced on the main stream
                 linear_wgrad_(dy, x, w.grad, None if bias is None else bias.grad, relu_in=relu_in, accumulate=True, defer=True)
             dy.record_stream(side)                                  # keep the allocator from recycling them early
             x.record_stream(side)
