@@ -697,9 +697,8 @@ def main():
                        "grid_convs": ({"bf16x3": "t2h csrc/conv_bx3.hip: every fp32 product from six bf16 MFMAs (exact 3-way operand "
                                                  "split, fp32 accumulate; error vs float64 = the fp32 MFMA kernels'), planes >= 32 wide; "
                                                  "csrc/conv.hip (fp32 MFMA) for the rest",
-                                       "f16x2": "t2h csrc/conv_bx3.hip: every fp32 product from three fp16 MFMAs (two-way fp16 operand split, "
-                                                "one power-of-two scale per staged block, fp32 accumulate; error vs float64 at the fp32 MFMA "
-                                                "kernels' level), planes >= 32 wide; csrc/conv.hip (fp32 MFMA) for the rest",
+                                       "f16x2": "t2h conv_bx3.hip: fp32 products from 3 fp16 MFMAs (2-way operand split, power-of-two "
+                                                "block scales, fp32 accumulate; error vs float64 at the fp32 kernels' level)",
                                        "bf16": "t2h csrc/conv_bx3.hip, operands rounded to bf16 (one MFMA per product, fp32 accumulate)",
                                        "fp32": "t2h implicit-GEMM on fp32 MFMA (csrc/conv.hip)"}[grid.CONV_PRECISION]
                                       if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen"),
@@ -730,9 +729,8 @@ def main():
                     out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
-                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps with the "
-                                          "side streams off (kernels alone); class totals: sum(algorithmic flops or bytes) / "
-                                          "sum(duration)")
+                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps, side "
+                                          "stream off (kernels alone)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"])))
                                                   for n in SCATTER_REDUCE_TAGS if n in named]

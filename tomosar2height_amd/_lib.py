@@ -358,33 +358,41 @@ def ws_bytes(name: str, *args) -> int:
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Scratch buffer from PyTorch's caching allocator (the library itself never allocates)."""
-    t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
-    o = _on_stream
-    if o is not None:
-        t.record_stream(o[1])           # allocated under torch's current stream, used on the overriding one
-    return t
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
-_on_stream = None       # (raw hipStream_t, torch stream) while an ``on_stream`` block is active
+_on_stream = None       # raw hipStream_t while an ``on_stream`` block is active
+_set_stream = getattr(torch._C, "_cuda_setStream", None)
 
 
 class on_stream:
-    """``with _lib.on_stream(side):`` -- the C-ABI launches (``_lib.stream()``) and workspaces of the block go to ``side`` WITHOUT
-    switching torch's current stream: ``torch.cuda.stream(...)`` / ``torch.cuda.current_stream()`` each cost a device-count query
-    (13 us, ~110 of them per tile-step with the weight gradients on a side stream: 1.4 ms of host time).  Only for blocks that
-    launch through this module; tensors the block reads must be ``record_stream``-ed by the caller as with any side stream."""
+    """``with _lib.on_stream(side, back):`` -- what ``with torch.cuda.stream(side):`` does for a block that was entered with
+    ``back`` current (launches AND allocations of the block belong to ``side``: its workspaces are recycled in the side stream's
+    own order), without the context manager's bookkeeping: ``torch.cuda.stream(...)`` / ``torch.cuda.current_stream()`` each cost
+    a device-count query (13 us; ~110 of them per tile-step with the weight gradients on a side stream = 1.4 ms of host time).
+    Tensors the block reads must be ``record_stream``-ed by the caller as with any side stream."""
 
-    def __init__(self, st):
-        self.pair = (st.cuda_stream, st)
+    def __init__(self, st, back):
+        self.st, self.back = st, back
 
     def __enter__(self):
         global _on_stream
-        self.prev, _on_stream = _on_stream, self.pair
+        st = self.st
+        self.prev, _on_stream = _on_stream, st.cuda_stream
+        if _set_stream is not None:
+            _set_stream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+        else:
+            torch.cuda.set_stream(st)
         return self
 
     def __exit__(self, *exc):
         global _on_stream
         _on_stream = self.prev
+        b = self.back
+        if _set_stream is not None:
+            _set_stream(stream_id=b.stream_id, device_index=b.device_index, device_type=b.device_type)
+        else:
+            torch.cuda.set_stream(b)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -396,7 +404,7 @@ def stream() -> int:
     tile-step): the raw getter avoids constructing a ``torch.cuda.Stream`` object each time (~3 us -> ~0.3 us)."""
     o = _on_stream
     if o is not None:
-        return o[0]
+        return o
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream

@@ -385,8 +385,7 @@ def _conv3x3_param_grads(gm, x, weight, bias):
             # latency-bound and leave most CUs idle; the trainer joins the stream at the end of the tile
             with mlp.fork_to(side):
                 conv3x3_wgrad_(gm, x, wg, bg, accumulate=True, defer=True)
-            gm.record_stream(side)
-            x.record_stream(side)
+            mlp.hold(gm, x)
         else:
             conv3x3_wgrad_(gm, x, wg, bg, accumulate=True, defer=True)
         return None, None
@@ -647,8 +646,7 @@ class _UpConv2x2(torch.autograd.Function):
                       _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                       tag=_lib.timing() and f"{up}[{cin}->{cout},{h}x{wd}]")
         if side is not None:
-            g.record_stream(side)
-            x.record_stream(side)
+            mlp.hold(g, x)
         ga = g if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
