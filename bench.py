@@ -22,6 +22,8 @@ Legs, in this order (rank 0 prints ONE compact JSON line at the very end, nothin
      stream the kernels run on -> per-kernel table (written to ``--kernel-table``, not printed) and the ``roofline``
      objects: launches are aggregated per DEVICE KERNEL SYMBOL (t2h_last_kernel_name), the way
      ``rocprofv3 --kernel-trace --stats`` aggregates, so the two can be compared directly.
+     The trainer's side stream (weight gradients beside the data-gradient chain, on in the timed region) is OFF in this leg:
+     a kernel's two events then bracket that kernel alone (profiles/run_profiles.sh runs the profiler passes the same way).
   3. ``--check-dp`` (optional): the data-parallel equivalence check of SURVEY.md 8e.
   4. cpu_baseline (rank 0, N = 1 only): the oracle torch restatement on the host cores, SURVEY.md 8d protocol.
 """
