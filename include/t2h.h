@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 12
+#define T2H_ABI_VERSION 13
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -321,9 +321,11 @@ int t2h_upsample_bilinear_nhwc_fwd(const float *in, const float *addend, int B, 
 int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream);
 int t2h_maxpool2x2_nhwc_bwd(const float *gout, const uint8_t *which, int B, int H, int W, int C, float *gin,
                             t2h_stream_t stream);
-/* ... with `addend` [B, H, W, C] (may be NULL) added: the pooled plane is also a U-Net skip connection (alto.py:135-138). */
+/* ... with `addend` [B, H, W, C] (may be NULL) added: the pooled plane is also a U-Net skip connection (alto.py:135-138).
+ * ld_addend: its pixel stride in floats (>= C): the skip's gradient arrives as one half of a concatenation's gradient
+ * (alto.py:227: torch.cat((from_up, from_down), 1)) and is read in place. */
 int t2h_maxpool2x2_nhwc_bwd_add(const float *gout, const uint8_t *which, int B, int H, int W, int C, const float *addend,
-                                float *gin, t2h_stream_t stream);
+                                int ld_addend, float *gin, t2h_stream_t stream);
 int t2h_upsample_bilinear_nhwc_bwd(const float *gout, int B, int C, int h, int w, int H, int W, float *gin,
                                    t2h_stream_t stream);
 /* nn.Upsample(mode='bilinear', scale_factor=2) -- align_corners=False, ATen's half-pixel source index -- on NHWC planes:
@@ -437,11 +439,13 @@ int t2h_upconv2x2_bx3_supported(int B, int H, int W, int Cin, int Cout);
 int t2h_upconv2x2_bx3_fwd(const float *x, const void *wf, const float *bias, const float *addend, float *y, int B, int H, int W,
                           int Cin, int Cout, int flags, t2h_stream_t stream);
 size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
+/* lddy: pixel stride of dy in floats (>= Cout, a multiple of 4): the output's gradient is usually the `from_up` half of a
+ * concatenation's gradient (alto.py:227) and is read in place */
+int t2h_upconv2x2_bx3_dgrad(const float *dy, int lddy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
                             void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 size_t t2h_upconv2x2_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout, int flags,
-                            void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+int t2h_upconv2x2_bx3_wgrad(const float *dy, int lddy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
+                            int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
 
 /* Batched slab reductions.  Every weight-gradient entry point (t2h_linear_wgrad, t2h_conv3x3_wgrad, t2h_conv3x3_bx3_wgrad,
  * t2h_upconv2x2_wgrad[_bias]) ends with a launch that sums its split slabs (fixed order: deterministic) into dw / db.  Within one

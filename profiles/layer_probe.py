@@ -99,9 +99,9 @@ if args.only in ("", "upconv"):
         ws_bw = _lib.workspace(lib.t2h_upconv2x2_bx3_wgrad_workspace_bytes(1, h, h, cin, cout), dev)
         db = torch.empty(cout, device=dev)
         for name, fn in (
-                ("bx3_wgrad", lambda: _lib.call("t2h_upconv2x2_bx3_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), 1, h, h, cin, cout, 0, _lib.ptr(ws_bw), ws_bw.numel(), _lib.stream())),
+                ("bx3_wgrad", lambda: _lib.call("t2h_upconv2x2_bx3_wgrad", _lib.ptr(gy), cout, _lib.ptr(x), _lib.ptr(dw), _lib.ptr(db), 1, h, h, cin, cout, 0, _lib.ptr(ws_bw), ws_bw.numel(), _lib.stream())),
                 ("bx3_fwd", lambda: _lib.call("t2h_upconv2x2_bx3_fwd", _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
-                ("bx3_dgrad", lambda: _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(gy), _lib.ptr(wft), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_b), ws_b.numel(), _lib.stream())),
+                ("bx3_dgrad", lambda: _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(gy), cout, _lib.ptr(wft), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_b), ws_b.numel(), _lib.stream())),
                 ("fwd", lambda: _lib.call("t2h_upconv2x2_fwd_add", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), None, _lib.ptr(y), 1, h, h, cin, cout, 0, _lib.stream())),
                 ("dgrad", lambda: _lib.call("t2h_upconv2x2_dgrad", _lib.ptr(gy), _lib.ptr(w), _lib.ptr(dx), 1, h, h, cin, cout, 0, _lib.ptr(ws_d), ws_d.numel(), _lib.stream())),
                 ("wgrad", lambda: _lib.call("t2h_upconv2x2_wgrad", _lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), 1, h, h, cin, cout, 0, _lib.ptr(ws_w), ws_w.numel(), _lib.stream()))):

@@ -150,8 +150,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_conv3x3_bx3_wgrad": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_gemm_bx3_prepare": (n, 64, 64, 32, 0, n, n),
         "t2h_upconv2x2_bx3_fwd": (n, n, n, n, n, 1, 16, 16, 64, 64, 0, n),
-        "t2h_upconv2x2_bx3_dgrad": (n, n, n, 1, 16, 16, 64, 64, 0, n, 0, n),
-        "t2h_upconv2x2_bx3_wgrad": (n, n, n, n, 1, 16, 32, 64, 64, 0, n, 0, n),
+        "t2h_upconv2x2_bx3_dgrad": (n, 64, n, n, 1, 16, 16, 64, 64, 0, n, 0, n),
+        "t2h_upconv2x2_bx3_wgrad": (n, 64, n, n, n, 1, 16, 32, 64, 64, 0, n, 0, n),
         "t2h_conv3x3_f16x2_prepare": (n, 32, 32, 0, n, n),
         "t2h_gemm_f16x2_prepare": (n, 64, 64, 32, 0, n, n),
         "t2h_split_weights_batch": (n, 1, n),
@@ -163,7 +163,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upconv2x2_wgrad_bias": (n, n, n, n, 1, 32, 32, 32, 32, 0, n, 0, n),
         "t2h_maxpool2x2_nhwc_fwd": (n, 1, 64, 64, 32, n, n, n),
         "t2h_maxpool2x2_nhwc_bwd": (n, n, 1, 64, 64, 32, n, n),
-        "t2h_maxpool2x2_nhwc_bwd_add": (n, n, 1, 64, 64, 32, n, n, n),
+        "t2h_maxpool2x2_nhwc_bwd_add": (n, n, 1, 64, 64, 32, n, 32, n, n),
         "t2h_mosaic_accumulate": (n, 64, 64, n, n, n, 100, 100, 0, 0, 1, n),
         "t2h_mosaic_finalize": (n, n, 100, n),
         "t2h_tile_crop_normalise": (n, 100, 0.0, 0.0, 1.0, 1.0, 512.0, 512.0, 190.2, n, n, n, n, n, 0, n),

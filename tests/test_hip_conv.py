@@ -770,3 +770,41 @@ def test_batched_weight_preparation_equals_the_single_calls(mode, monkeypatch):
     before = [b.clone() for b in bufs]
     cache.refresh(stale_only=True)                                           # nothing moved: nothing launched, nothing changed
     assert all(torch.equal(a, b) for a, b in zip(before, bufs))
+
+
+def test_sliced_gradients_are_read_in_place(monkeypatch):
+    """``torch.cat``'s backward hands each input a channel SLICE of the concatenation's gradient (alto.py:227).  The transposed
+    convolution (data and weight gradient on the split kernels), the 1x1 convolution and the max-pool's skip gradient read such a
+    slice in place through a pixel stride -- no dense copy -- and give the gradients of the float64 reference."""
+    import copy
+    from tomosar2height_amd import grid
+    monkeypatch.setattr(grid, "BX3_MIN_PIXELS", 128)
+    torch.manual_seed(12)
+    g = torch.Generator().manual_seed(12)
+    up = torch.nn.ConvTranspose2d(64, 64, 2, stride=2)
+    c1 = torch.nn.Conv2d(64, 32, 1)
+    x = torch.randn(1, 64, 16, 32, generator=g)
+    skip = torch.randn(1, 32, 32, 64, generator=g)
+    mix = torch.randn(1, 64 + 32 + 32, 32, 64, generator=g)
+    upr, c1r = copy.deepcopy(up).double(), copy.deepcopy(c1).double()
+    xr, sr = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    yr = upr(xr)
+    pr = F.max_pool2d(sr, 2, 2)
+    (torch.cat((yr, c1r(yr), sr), 1) * mix.double()).sum().backward(retain_graph=True)
+    (pr * pr).sum().backward()
+    up, c1 = up.to(_dev()).to(memory_format=torch.channels_last), c1.to(_dev()).to(memory_format=torch.channels_last)
+    xg, sg = _cl(x).requires_grad_(True), _cl(skip).requires_grad_(True)
+    copies = []
+    real_as_cl = grid._as_cl
+    monkeypatch.setattr(grid, "_as_cl", lambda t: (copies.append(tuple(t.shape)) if not grid.is_cl(t) else None, real_as_cl(t))[1])
+    y = grid.upconv2x2(xg, up)
+    pooled, thru = grid.maxpool2x2_thru(sg)
+    loss = (torch.cat((y, grid.conv1x1(y, c1), thru), 1) * _cl(mix)).sum() + (pooled * pooled).sum()
+    loss.backward()
+    assert not copies, f"dense copies of sliced gradients: {copies}"
+    _close(xg.grad, xr.grad)
+    _close(sg.grad, sr.grad)
+    _close(up.weight.grad, upr.weight.grad)
+    _close(up.bias.grad, upr.bias.grad)
+    _close(c1.weight.grad, c1r.weight.grad)
+    _close(c1.bias.grad, c1r.bias.grad)

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -97,9 +97,9 @@ SIGNATURES = {
     "t2h_upconv2x2_bx3_supported": (_i, [_i, _i, _i, _i, _i]),
     "t2h_upconv2x2_bx3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_upconv2x2_bx3_dgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "t2h_upconv2x2_bx3_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_upconv2x2_bx3_dgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_upconv2x2_bx3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "t2h_upconv2x2_bx3_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "t2h_upconv2x2_bx3_wgrad": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_conv3x3_f16x2_weights_bytes": (_sz, [_i, _i]),
     "t2h_conv3x3_f16x2_prepare": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "t2h_gemm_f16x2_weights_bytes": (_sz, [_i, _i]),
@@ -118,7 +118,7 @@ SIGNATURES = {
     "t2h_upconv2x2_wgrad_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "t2h_maxpool2x2_nhwc_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "t2h_maxpool2x2_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "t2h_maxpool2x2_nhwc_bwd_add": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "t2h_maxpool2x2_nhwc_bwd_add": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "t2h_mosaic_accumulate": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2h_mosaic_finalize": (_i, [_vp, _vp, _i64, _vp]),
     "t2h_tile_crop_workspace_bytes": (_sz, [_i64]),

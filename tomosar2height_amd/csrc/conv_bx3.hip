@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 const int k0 = c * CCH, tap = k0 / p.up_cout, co0 = k0 - tap * p.up_cout;      // (CCH divides up_cout)
                 if (idx < NF4)
                     v = *reinterpret_cast<const float4 *>(p.x + up_pixel(((long long)b * p.H + gy) * p.W + gx, tap, p.up_logW, p.up_logH) *
-                                                                    p.up_cout + co0 + c4 * 4);
+                                                                    p.ldx + co0 + c4 * 4);
             } else if (idx < NF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
                 v = *reinterpret_cast<const float4 *>(p.x + (((size_t)b * p.H + gy) * p.W + gx) * p.ldx + c * CCH + c4 * 4);
             hreg[f] = v;
@@ -600,6 +600,7 @@ struct WgradArgs {
     float *colslab;          // [splits][Cout] or null
     int H, W, Cin, Cout;
     int n_units, units_per_split;
+    int ldx;                 // pixel stride of x in floats (UP: of the layer's output gradient, which may be a channel slice)
 };
 
 // COT = 32-channel tiles of Cout per workgroup (4, 2 or 1): the workgroup's (COT x 9) output tiles are dealt to the four waves
@@ -647,9 +648,9 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             const int gy = y + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (UP) {      // px = (output row parity, 64 output pixels): rows 2 row, 2 row + 1 of the [*, 2 W] plane, columns 2 x0 ..
-                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(2 * row + (px >> 6)) * (2 * p.W) + 2 * x0 + (px & 63)) * p.Cin + ci0 + c4 * 4);
+                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(2 * row + (px >> 6)) * (2 * p.W) + 2 * x0 + (px & 63)) * p.ldx + ci0 + c4 * 4);
             } else if (idx < XF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(row + hy - 1) * p.W + gx) * p.Cin + ci0 + c4 * 4);
+                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(row + hy - 1) * p.W + gx) * p.ldx + ci0 + c4 * 4);
             xr[f] = v;
         }
 #pragma unroll
@@ -1085,7 +1086,7 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     float *colslab = slab + (size_t)p.splits * Cout * Ncols;
     WgradArgs a{};
     a.dy = dy; a.x = x; a.slab = slab; a.colslab = db ? colslab : nullptr;
-    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
+    a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.n_units = p.n_units; a.units_per_split = p.units_per_split; a.ldx = Cin;
     dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
     if (flags & T2H_F16X2) {
@@ -1187,15 +1188,16 @@ T2H_API size_t t2h_upconv2x2_bx3_dgrad_workspace_bytes(int B, int H, int W, int 
     return r.splits > 1 ? (size_t)r.splits * M * Cin * sizeof(float) : 0;
 }
 
-T2H_API int t2h_upconv2x2_bx3_dgrad(const float *dy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout, int flags,
-                                    void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+T2H_API int t2h_upconv2x2_bx3_dgrad(const float *dy, int lddy, const void *wf_t, float *dx, int B, int H, int W, int Cin, int Cout,
+                                    int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!dy || !wf_t || !dx) return fail(T2H_ERR_ARG, "upconv2x2_bx3_dgrad: null pointer");
     if (int rc = check_up_bx3("upconv2x2_bx3_dgrad", B, H, W, Cin, Cout)) return rc;
+    if (lddy < Cout || lddy % 4) return fail(T2H_ERR_ARG, "upconv2x2_bx3_dgrad: lddy=%d must be >= Cout=%d and a multiple of 4", lddy, Cout);
     if (!al16(dy) || !al16(wf_t) || !al16(dx)) return fail(T2H_ERR_ARG, "upconv2x2_bx3_dgrad: pointers must be 16-byte aligned");
     const long long M = (long long)B * H * W;
     RowsArgs a{};
     a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.y = dx;
-    a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = 4 * Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = 0;
+    a.B = 1; a.H = (int)(M / 32); a.W = 32; a.Kc = 4 * Cout; a.Nc = Cin; a.ldx = lddy; a.ldy = Cin; a.ldm = 0;
     a.up_logW = ilog2i(W); a.up_logH = ilog2i(H); a.up_cout = Cout;
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
     a.wscale = f16_trailer(wf_t, (size_t)Cin * 4 * Cout * 4);
@@ -1223,10 +1225,11 @@ T2H_API size_t t2h_upconv2x2_bx3_wgrad_workspace_bytes(int B, int H, int W, int 
     return (size_t)p.splits * ((size_t)Cin * 4 * Cout + Cout) * sizeof(float);
 }
 
-T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
-                                    int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, int lddy, const float *x, float *dw, float *db, int B, int H, int W, int Cin,
+                                    int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
     if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: null pointer");
     if (int rc = check_up_bx3("upconv2x2_bx3_wgrad", B, H, W, Cin, Cout)) return rc;
+    if (lddy < Cout || lddy % 4) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: lddy=%d must be >= Cout=%d and a multiple of 4", lddy, Cout);
     if (W < TW) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: W=%d below the %d-pixel unit", W, TW);
     if (!al16(dy) || !al16(x)) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: pointers must be 16-byte aligned");
     const size_t need = t2h_upconv2x2_bx3_wgrad_workspace_bytes(B, H, W, Cin, Cout);
@@ -1239,7 +1242,7 @@ T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, const float *x, float *dw, 
     float *colslab = slab + (size_t)p.splits * Cin * Ncols;
     WgradArgs a{};
     a.dy = x; a.x = dy; a.slab = slab; a.colslab = db ? colslab : nullptr;           // (roles swapped, see the kernel)
-    a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.n_units = p.n_units; a.units_per_split = p.units_per_split;
+    a.H = H; a.W = W; a.Cin = Cout; a.Cout = Cin; a.n_units = p.n_units; a.units_per_split = p.units_per_split; a.ldx = lddy;
     dim3 grid(p.splits, Cout / CC, Cin / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: too many channel chunks");
     if (flags & T2H_F16X2) {

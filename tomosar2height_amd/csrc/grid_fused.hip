@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kT) void maxpool2x2_fwd_kernel(const float *__restr
 // gin[2y+dy, 2x+dx, c] = (which == 2 dy + dx) ? g[y, x, c] : 0 -- every input element written exactly once
 __global__ __launch_bounds__(kT) void maxpool2x2_bwd_kernel(const float *__restrict__ g, const uint8_t *__restrict__ which, int B,
                                                             int H, int W, int C, int lg, const float *__restrict__ addend,
-                                                            float *__restrict__ gin) {
+                                                            int ld_add, float *__restrict__ gin) {
     long long t = (long long)blockIdx.x * kT + threadIdx.x;
     long long pix = t >> lg;
     const int h = H / 2, w = W / 2;
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(kT) void maxpool2x2_bwd_kernel(const float *__restr
             float4 o = make_float4(a.x == k ? gv.x : 0.f, a.y == k ? gv.y : 0.f, a.z == k ? gv.z : 0.f, a.w == k ? gv.w : 0.f);
             float *dst = (k & 2 ? p10 : p00) + (k & 1) * C + c;
             if (addend) {       // the plane's other gradient (the U-Net skip connection)
-                const float4 ad = *reinterpret_cast<const float4 *>(addend + (dst - gin));
+                // (addend: pixel stride ld_add >= C -- a channel slice of a wider NHWC tensor, e.g. one half of a concatenation's gradient)
+                const size_t off = (size_t)(dst - gin);
+                const float4 ad = *reinterpret_cast<const float4 *>(addend + (off / C) * ld_add + off % C);
                 o.x = __fadd_rn(ad.x, o.x); o.y = __fadd_rn(ad.y, o.y); o.z = __fadd_rn(ad.z, o.z); o.w = __fadd_rn(ad.w, o.w);
             }
             *reinterpret_cast<float4 *>(dst) = o;
@@ -450,18 +452,19 @@ T2H_API int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C,
 
 T2H_API int t2h_maxpool2x2_nhwc_bwd(const float *gout, const uint8_t *which, int B, int H, int W, int C, float *gin,
                                     t2h_stream_t stream) {
-    return t2h_maxpool2x2_nhwc_bwd_add(gout, which, B, H, W, C, nullptr, gin, stream);
+    return t2h_maxpool2x2_nhwc_bwd_add(gout, which, B, H, W, C, nullptr, 0, gin, stream);
 }
 
 T2H_API int t2h_maxpool2x2_nhwc_bwd_add(const float *gout, const uint8_t *which, int B, int H, int W, int C, const float *addend,
-                                        float *gin, t2h_stream_t stream) {
+                                        int ld_addend, float *gin, t2h_stream_t stream) {
     if (!gout || !gin || !which || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || C % 4)
         return fail(T2H_ERR_ARG, "maxpool2x2_nhwc_bwd: bad argument (even H, W and C %% 4 == 0 required)");
-    if (addend && ((uintptr_t)addend & 15)) return fail(T2H_ERR_ARG, "maxpool2x2_nhwc_bwd: addend must be 16-byte aligned");
+    if (addend && (((uintptr_t)addend & 15) || ld_addend < C || ld_addend % 4))
+        return fail(T2H_ERR_ARG, "maxpool2x2_nhwc_bwd: addend must be 16-byte aligned with a pixel stride >= C, a multiple of 4");
     int lg = lg_for(C);
     long long threads = ((long long)B * (H / 2) * (W / 2)) << lg;
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)((threads + kT - 1) / kT)), dim3(kT), 0, as_stream(stream), gout, which,
-                       B, H, W, C, lg, addend, gin);
+                       B, H, W, C, lg, addend, ld_addend, gin);
     return check_launch("maxpool2x2_nhwc_bwd");
 }
 

@@ -45,6 +45,19 @@ def _as_cl(x: torch.Tensor) -> torch.Tensor:
     return x if is_cl(x) else x.contiguous(memory_format=torch.channels_last)
 
 
+def _cl_ld(x: torch.Tensor):
+    """(tensor, pixel stride in floats): ``x`` itself when it is NHWC with a pixel stride >= C -- dense, or a channel slice of a
+    wider NHWC tensor, which is how ``torch.cat``'s backward hands each input its gradient (alto.py:227) -- read in place by the
+    kernels that take a stride; a dense NHWC copy otherwise."""
+    if x.dim() == 4 and x.is_cuda and x.dtype == torch.float32:
+        b, c, h, w = x.shape
+        sb, sc, sh, sw = x.stride()
+        if (sc == 1 or c == 1) and sw >= c and sw % 4 == 0 and sh == w * sw and (sb == h * sh or b == 1) and x.data_ptr() % 16 == 0:
+            return x, sw
+    x = _as_cl(x)
+    return x, x.shape[1]
+
+
 def _empty_cl(b, c, h, w, device) -> torch.Tensor:
     return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
 
@@ -513,14 +526,14 @@ class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, bias = ctx.saved_tensors
-        g = _as_cl(g)
+        g, ldg = _cl_ld(g)                                  # (a channel slice of a concatenation's gradient is read in place)
         b, cin, h, wd = x.shape
         cout, m = weight.shape[0], b * h * wd
         w2 = weight.reshape(cout, cin).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty_cl(b, cin, h, wd, x.device)
-            _lib.call("t2h_linear_dgrad", _lib.ptr(g), cout, _lib.ptr(w2), _lib.ptr(dx), cin, m, cin, cout, None, 0, 0,
+            _lib.call("t2h_linear_dgrad", _lib.ptr(g), ldg, _lib.ptr(w2), _lib.ptr(dx), cin, m, cin, cout, None, 0, 0,
                       _lib.stream(), nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
                       tag=_lib.timing() and f"t2h_linear_dgrad[N={cout},K={cin}]")
         wg, bg = weight.grad, (bias.grad if bias is not None else None)
@@ -531,7 +544,7 @@ class _Conv1x1(torch.autograd.Function):
         lib = _lib.load()
         nws = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, cin, cout)
         ws = _lib.workspace(nws, g.device)
-        _lib.call("t2h_linear_wgrad", _lib.ptr(g), cout, _lib.ptr(x), cin, m, cin, cout, _lib.ACCUM if direct else 0,
+        _lib.call("t2h_linear_wgrad", _lib.ptr(g), ldg, _lib.ptr(x), cin, m, cin, cout, _lib.ACCUM if direct else 0,
                   _lib.ptr(dw), _lib.ptr(db) if db is not None else None, _lib.ptr(ws), nws, _lib.stream(),
                   nbytes=4 * (m * cin + m * cout + cin * cout), flops=2 * m * cin * cout,
                   tag=_lib.timing() and f"t2h_linear_wgrad[N={cout},K={cin}]")
@@ -605,10 +618,13 @@ class _UpConv2x2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, bias = ctx.saved_tensors
-        g = _as_cl(g)
-        w = _w_cl(weight)
         b, cin, h, wd = x.shape
         cout = weight.shape[1]
+        up = "t2h_upconv2x2_bx3_wgrad" if (ctx.bx3 and BX3_WGRAD and wd >= 32) else "t2h_upconv2x2_wgrad_bias"
+        g0 = g
+        # the split kernels read a channel slice of a concatenation's gradient in place (pixel stride ldg); the fp32 ones want it dense
+        g, ldg = _cl_ld(g) if (ctx.bx3 and up == "t2h_upconv2x2_bx3_wgrad") else (_as_cl(g), cout)
+        w = _w_cl(weight)
         lib = _lib.load()
         flops = 2 * 4 * cin * cout * b * h * wd
         dx = None
@@ -617,7 +633,7 @@ class _UpConv2x2(torch.autograd.Function):
         if dx is not None and ctx.bx3:
             nws = _lib.ws_bytes("t2h_upconv2x2_bx3_dgrad_workspace_bytes", b, h, wd, cin, cout)
             ws = _lib.workspace(nws, g.device)
-            _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(g), _lib.ptr(split_weights.get_up(w, False)), _lib.ptr(dx),
+            _lib.call("t2h_upconv2x2_bx3_dgrad", _lib.ptr(g), ldg, _lib.ptr(split_weights.get_up(w, False)), _lib.ptr(dx),
                       b, h, wd, cin, cout, _lib.F16X2 if _h2() else 0, _lib.ptr(ws), nws, _lib.stream(),
                       nbytes=4 * (g.numel() + dx.numel()) + 6 * w.numel(), flops=flops,
                       tag=_lib.timing() and f"t2h_upconv2x2_bx3_dgrad[{cout}->{cin},{h}x{wd}]")
@@ -632,7 +648,6 @@ class _UpConv2x2(torch.autograd.Function):
                   and (bias is None or (bg is not None and bg.is_contiguous())))
         dw = wg if direct else torch.empty_like(weight, memory_format=torch.channels_last)
         db = bg if direct else (torch.empty_like(bias) if bias is not None else None)
-        up = "t2h_upconv2x2_bx3_wgrad" if (ctx.bx3 and BX3_WGRAD and wd >= 32) else "t2h_upconv2x2_wgrad_bias"
         nws = _lib.ws_bytes(up.replace("_bias", "") + "_workspace_bytes", b, h, wd, cin, cout)
         # weight AND bias gradient from one kernel (the bias gradient is the column sum of the dY tiles it stages anyway); like the
         # 3x3 weight gradients on the trainer's side stream when there is one (_conv3x3_param_grads) -- unless g is also handed on
@@ -640,14 +655,14 @@ class _UpConv2x2(torch.autograd.Function):
         side = mlp._CONV_WGRAD_STREAM if (direct and not ctx.has_addend) else None
         with mlp.fork_to(side) if side is not None else contextlib.nullcontext():
             ws = _lib.workspace(nws, g.device)
-            _lib.call(up, _lib.ptr(g), _lib.ptr(x), _lib.ptr(dw), None if db is None else _lib.ptr(db),
-                      b, h, wd, cin, cout,
+            _lib.call(up, _lib.ptr(g), *((ldg,) if up == "t2h_upconv2x2_bx3_wgrad" else ()), _lib.ptr(x), _lib.ptr(dw),
+                      None if db is None else _lib.ptr(db), b, h, wd, cin, cout,
                       ((_lib.ACCUM | _lib.defer_reduce(ws, dw)) if direct else 0) | (_lib.F16X2 if (_h2() and up.endswith("bx3_wgrad")) else 0),
                       _lib.ptr(ws), nws, _lib.stream(), nbytes=4 * (g.numel() + x.numel() + dw.numel()), flops=flops,
                       tag=_lib.timing() and f"{up}[{cin}->{cout},{h}x{wd}]")
         if side is not None:
             mlp.hold(g, x)
-        ga = g if ctx.has_addend else None
+        ga = g0 if ctx.has_addend else None
         return (dx, None, None, ga) if direct else (dx, dw, db, ga)
 
 
@@ -816,10 +831,10 @@ class _MaxPool2x2Thru(torch.autograd.Function):
         (which,) = ctx.saved_tensors
         b, c, h, w = ctx.shape
         g = _as_cl(g)
-        addend = None if gthru is None else _as_cl(gthru)
+        addend, ld_add = (None, 0) if gthru is None else _cl_ld(gthru)   # (the skip's gradient: a slice of the concatenation's)
         gin = _empty_cl(b, c, h, w, g.device)
         _lib.call("t2h_maxpool2x2_nhwc_bwd_add", _lib.ptr(g), _lib.ptr(which), b, h, w, c,
-                  None if addend is None else _lib.ptr(addend), _lib.ptr(gin), _lib.stream(),
+                  None if addend is None else _lib.ptr(addend), ld_add, _lib.ptr(gin), _lib.stream(),
                   nbytes=5 * g.numel() + 4 * gin.numel() * (2 if addend is not None else 1), tag="t2h_maxpool2x2_bwd")
         return gin
 
