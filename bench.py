@@ -129,7 +129,7 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json (rocprofv3 --pmc passes of profile {d.get('tag', '?')}, not this run)"
+        return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json (rocprofv3 --pmc passes, profile {d.get('tag', '?')})"
     except (OSError, ValueError):
         return {}, None
 
@@ -182,10 +182,9 @@ def point_update_note():
     from tomosar2height_amd import deferred, mlp
     parts = []
     if mlp.GRID_FIRST_MIN_RATIO > 0:
-        parts.append(f"fc_comm.0 on the pixels where a level has >= {mlp.GRID_FIRST_MIN_RATIO:g} points per pixel")
+        parts.append(f"fc_comm.0 on the pixels at levels with >= {mlp.GRID_FIRST_MIN_RATIO:g} points/pixel")
     if deferred.DEFER_MIN_CHANNELS > 0:
-        parts.append(f"per-point features deferred (fc_comm.2 / fc_c on per-cell sums) from the first level with >= "
-                     f"{deferred.DEFER_MIN_CHANNELS} channels")
+        parts.append(f"fc_comm.2 / fc_c on per-cell sums from the first level with >= {deferred.DEFER_MIN_CHANNELS} channels")
     return "; ".join(parts) if parts else "point-wise as the reference (alto.py:121-130)"
 
 
