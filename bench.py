@@ -560,9 +560,7 @@ def main():
             state["i"] += k
             done += k
             if events is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                events.append(ev)
+                events.append(trainer.step_event())          # (end of the last tile whose backward has been issued)
                 state.setdefault("event_tiles", []).append(k)
 
     def fence():
@@ -645,14 +643,15 @@ def main():
         # per-kernel durations are those of kernels running ALONE: the side streams of the timed step (weight gradients beside the
         # data-gradient chain) are switched off for this untimed leg, so a kernel's events do not span another kernel's time on
         # shared CUs.  (The timed region above keeps them on; the sum of these durations therefore exceeds ms_per_step's GPU share.)
-        saved_overlap = (trainer.overlap_wgrad, trainer.overlap_conv_wgrad)
-        trainer.overlap_wgrad = trainer.overlap_conv_wgrad = False
+        saved_overlap = (trainer.overlap_wgrad, trainer.overlap_conv_wgrad, trainer.pipeline_tiles)
+        trainer.flush_pipeline()
+        trainer.overlap_wgrad = trainer.overlap_conv_wgrad = trainer.pipeline_tiles = False
         try:
             with timeline:
                 run(args.profile_steps)
             fence()
         finally:
-            trainer.overlap_wgrad, trainer.overlap_conv_wgrad = saved_overlap
+            trainer.overlap_wgrad, trainer.overlap_conv_wgrad, trainer.pipeline_tiles = saved_overlap
     # one optimizer boundary on its own (all-reduce + AdamW + bucket zero), between two events on the compute stream
     fence()
     eb, ee = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -596,6 +596,41 @@ def test_side_stream_wgrad_overlap_gives_identical_gradients():
         assert (a[k] - b[k]).abs().max().item() <= 1e-4 * scale, k
 
 
+def test_pipelined_tiles_give_identical_gradients():
+    """``Trainer.pipeline_tiles``: tile i + 1's forward is issued before tile i's backward, each tile on its own stream of a
+    ping-pong pair.  Same kernels and the same accumulation order per buffer as one tile after the other: the accumulated
+    gradients, the loss accumulator and the weights after the optimizer step are identical bit for bit -- also across an
+    optimizer boundary (the next window's forward waits for the new weights)."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    tiles = [{"inputs": synth_cloud(20000, seed=300 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(7)]
+
+    def run(pipelined):
+        model = det_init_(TomoSAR2Height(cfg), seed=15).to(_dev())
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=1e-3), device=_dev(), optimize_every=4, use_cloud=True)
+        tr.pipeline_tiles = pipelined
+        ended = [tr.train_step(t) for t in tiles]                 # 4 tiles + optimizer step, then 3 tiles of the next window
+        assert ended == [False, False, False, True, False, False, False]
+        tr.flush_pipeline()
+        tr.flush_gradients()
+        torch.cuda.synchronize()
+        assert (tr._tile_streams is not None) == pipelined
+        return ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                {k: p.detach().clone() for k, p in model.named_parameters()}, float(tr.accumulated_loss), float(tr.last_avg_loss))
+
+    (ga, wa, la, lavg_a), (gb, wb, lb, lavg_b) = run(False), run(True)
+    assert la == lb and lavg_a == lavg_b
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+
+
 def test_tile_index_built_ahead_on_a_side_stream_gives_the_same_step():
     """``Trainer.prepare`` builds the next tile's index (cell sort, sampling adjoint, cell counts) on a side stream while the
     current step runs; the step on the prebuilt index is the step on the raw cloud, bit for bit (same kernels, same order)."""
@@ -733,8 +768,8 @@ def test_optimizer_stepped_outside_the_trainer_is_noticed(fused):
     tr = Trainer(model, opt, device=_dev(), optimize_every=100, use_cloud=True)
     tr.train_step(tiles[0])                                # (the very first tile flushes at once: the bucket is laid out from it)
     tr.train_step(tiles[1])
-    assert tr.compose_cache.pending
-    opt.step()                                             # the misuse: gradients of tile 1 are still in the cache
+    assert tr.compose_cache.pending or tr._pending is not None     # (tile pipeline: tile 1's backward has not even been issued)
+    opt.step()                                             # the misuse: gradients of tile 1 are still in the cache / the pipeline
     with pytest.raises(RuntimeError, match="unflushed"):
         tr.train_step(tiles[0])
 

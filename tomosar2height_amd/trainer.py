@@ -100,6 +100,13 @@ class Trainer:
         # beside the following layers' data gradients: T2H_OVERLAP_CONV_WGRAD=1
         self.overlap_conv_wgrad = os.environ.get("T2H_OVERLAP_CONV_WGRAD", "1") == "1"
         self._conv_side = None
+        # the tiles of an accumulation window are independent: tile i + 1's forward runs beside tile i's backward, each tile on
+        # its own stream of a ping-pong pair (see ``_train_step_pipelined``); T2H_PIPELINE_TILES=0: one tile after the other
+        self.pipeline_tiles = os.environ.get("T2H_PIPELINE_TILES", "1") == "1"
+        self._tile_streams = None
+        self._pending = None            # (loss, l1, ce, stream) of the tile whose backward has not been issued yet
+        self._bwd_done = None           # event: end of the last issued backward (the next one accumulates into the same buffers)
+        self._tile_parity = 0
 
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
         # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
@@ -241,6 +248,10 @@ class Trainer:
                              f"({self.accumulated_steps} of {self.local_every} tiles accumulated)")
         if n_tiles == 1 and isinstance(data, (list, tuple)):
             data = data[0]
+        if (self.pipeline_tiles and n_tiles == 1 and self.bucket is not None and self._graph is None
+                and torch.is_tensor(data.get("dsm")) and next(self.model.parameters()).is_cuda):
+            return self._train_step_pipelined(data)
+        self.flush_pipeline()
         if n_tiles == 1 and self._graph_matches(data):
             g = self._graph
             for k, buf in g["static"].items():
@@ -252,31 +263,7 @@ class Trainer:
             with self._own_cache():
                 loss_l1, loss_ce = self._losses(data, 0.0001)             # trainer.py:63-69
             loss = loss_l1 + loss_ce
-            side = None
-            if self.overlap_wgrad and self.bucket is not None and loss.is_cuda:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=loss.device)
-                side = self._side
-            conv_side = None
-            if self.overlap_conv_wgrad and self.bucket is not None and loss.is_cuda:
-                if self._conv_side is None:
-                    self._conv_side = torch.cuda.Stream(device=loss.device)
-                conv_side = self._conv_side
-            direct = self.bucket is not None and self.direct_accumulation
-            # the weight gradients accumulate straight into the bucket and nothing reads it before the pass ends: their slab
-            # reductions run as ONE batched launch at the end of the pass instead of one launch per layer (T2H_BATCH_REDUCE=0: A/B)
-            # (not with the side streams: there each reduction runs at once beside other kernels, which measures faster than one
-            # batched launch on an otherwise idle chip -- 8.71 against 8.95 ms per step)
-            batch = (direct and loss.is_cuda and side is None and conv_side is None
-                     and os.environ.get("T2H_BATCH_REDUCE", "1") != "0")
-            with mlp.direct_grad_accumulation(direct, side, conv_side), _lib.reduce_capture(batch):
-                loss.backward()
-                for st in (side, conv_side):
-                    if st is not None:
-                        # join: the overlap is with this tile's own backward; afterwards the gradients are visible in
-                        # stream order on the current stream like any other result -- and the batched reduction, which runs
-                        # when the capture block is left, reads slabs that were written on these streams
-                        torch.cuda.current_stream().wait_stream(st)
+            self._backward(loss)
         if self.bucket is None:
             self.flush_gradients()          # (the parameters behind the composed maps must have their gradient before the bucket is laid out)
             # first tile: the set of parameters that receive gradients is now known (it is static); from here on
@@ -293,8 +280,113 @@ class Trainer:
         self.optimizer_boundary()
         return True
 
+    def _backward(self, loss):
+        """``loss.backward()`` of one tile (or micro-batch) with the weight gradients on the side streams."""
+        side = None
+        if self.overlap_wgrad and self.bucket is not None and loss.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=loss.device)
+            side = self._side
+        conv_side = None
+        if self.overlap_conv_wgrad and self.bucket is not None and loss.is_cuda:
+            if self._conv_side is None:
+                self._conv_side = torch.cuda.Stream(device=loss.device)
+            conv_side = self._conv_side
+        direct = self.bucket is not None and self.direct_accumulation
+        # the weight gradients accumulate straight into the bucket and nothing reads it before the pass ends: their slab
+        # reductions run as ONE batched launch at the end of the pass instead of one launch per layer (T2H_BATCH_REDUCE=0: A/B)
+        # (not with the side streams: there each reduction runs at once beside other kernels, which measures faster than one
+        # batched launch on an otherwise idle chip -- 8.71 against 8.95 ms per step)
+        batch = (direct and loss.is_cuda and side is None and conv_side is None
+                 and os.environ.get("T2H_BATCH_REDUCE", "1") != "0")
+        with mlp.direct_grad_accumulation(direct, side, conv_side), _lib.reduce_capture(batch):
+            loss.backward()
+            for st in (side, conv_side):
+                if st is not None:
+                    # join: the overlap is with this tile's own backward; afterwards the gradients are visible in
+                    # stream order on the current stream like any other result -- and the batched reduction, which runs
+                    # when the capture block is left, reads slabs that were written on these streams
+                    torch.cuda.current_stream().wait_stream(st)
+
+    # ------------------------------------------------------------------------------------------ tiles in a two-stage pipeline
+    def _train_step_pipelined(self, data) -> bool:
+        """One tile of a window whose tiles overlap: the forward of tile i is issued -- on stream S[i % 2] -- BEFORE the backward
+        of tile i - 1, which runs on S[(i - 1) % 2] (autograd runs a node's backward on the stream of its forward).  A tile
+        lives on one stream from its first kernel to its last, so its activations are allocated, used and recycled in that
+        stream's order; what the two streams share is ordered by events: the weights (read-only inside a window), the gradient
+        bucket and the loss accumulators (tile i's backward waits for the end of tile i - 1's), the side stream of the weight
+        gradients (forks from and joins the backward's stream).  Same kernels, same summation order per buffer as one tile
+        after the other -- bit-identical gradients (``test_pipelined_tiles_give_identical_gradients``) -- with the chip's idle
+        CUs of a B = 1 step filled by the neighbouring tile."""
+        dev = next(self.model.parameters()).device
+        main = torch.cuda.current_stream(dev)
+        if self._tile_streams is None:
+            self._tile_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        st = self._tile_streams[self._tile_parity]
+        self._tile_parity ^= 1
+        st.wait_stream(main)                                  # the tile's tensors, the weights of the last optimizer step
+        with torch.cuda.stream(st):
+            with self._own_cache():
+                loss_l1, loss_ce = self._losses(data, 0.0001)
+            loss = loss_l1 + loss_ce
+        self._issue_pending_backward()
+        self._pending = (loss, loss_l1, loss_ce, st, self._weights_version())
+        self.accumulated_steps += 1
+        if self.accumulated_steps < self.local_every:
+            return False
+        self.optimizer_boundary()
+        return True
+
+    def _issue_pending_backward(self):
+        if self._pending is None:
+            return
+        loss, loss_l1, loss_ce, st, version = self._pending
+        self._pending = None
+        if version != self._weights_version():
+            self._reset_accumulators()
+            raise RuntimeError("the weights changed (an optimizer step outside the Trainer?) while the backward of the previous tile "
+                               "was still unflushed in the tile pipeline: call Trainer.flush_gradients() before stepping an "
+                               "optimizer yourself -- the accumulated gradients of this window have been dropped")
+        if self._bwd_done is not None:
+            st.wait_event(self._bwd_done)                     # the previous tile's backward has the same accumulators
+        with torch.cuda.stream(st):
+            self._backward(loss)
+            self.accumulated_loss += loss.detach()
+            self.accumulated_loss_dict["loss_ce"] += loss_ce.detach()
+            self.accumulated_loss_dict["loss_l1"] += loss_l1.detach()
+            self._bwd_done = st.record_event(torch.cuda.Event(enable_timing=True))
+
+    def _weights_version(self) -> int:
+        """Version counter of one trained parameter (every optimizer, FlatAdamW included, bumps all of them together)."""
+        p = getattr(self, "_sentinel", None)
+        if p is None:
+            p = self._sentinel = next(q for q in self.model.parameters() if q.requires_grad)
+        return p._version
+
+    def step_event(self):
+        """A timing-enabled event at the end of the GPU work of the most recent tile whose backward has been issued (the tile
+        before the last ``train_step`` when the tile pipeline is on): consecutive ones are one tile-step apart."""
+        if self._bwd_done is not None:
+            return self._bwd_done
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def flush_pipeline(self):
+        """Issue the backward that ``_train_step_pipelined`` still holds back and make the calling stream wait for the tile
+        streams: afterwards gradients and loss accumulators are complete in the caller's stream order."""
+        if self._pending is None and self._bwd_done is None:
+            return
+        self._issue_pending_backward()
+        main = torch.cuda.current_stream()
+        for st in self._tile_streams or ():
+            main.wait_stream(st)
+        self._bwd_done = None
+
     def flush_gradients(self):
-        """Make every parameter's ``.grad`` complete for the tiles seen so far (back-propagates what the ComposeCache holds)."""
+        """Make every parameter's ``.grad`` complete for the tiles seen so far (issues the backward that the tile pipeline still
+        holds back, back-propagates what the ComposeCache holds)."""
+        self.flush_pipeline()
         if self.compose_cache is not None:
             self.compose_cache.flush()
 
@@ -302,6 +394,7 @@ class Trainer:
         """End of an optimizer step (trainer.py:78-89): [all-reduce(SUM) of the flat gradient bucket over the ranks,]
         ``optimizer.step()``, loss averaging, gradients to zero.  ``on_reduced(flat_grad)``, if set, sees the complete
         accumulated (and reduced) gradient just before the optimizer consumes it (tests, ``bench.py --check-dp``)."""
+        self.flush_pipeline()
         self.flush_gradients()
         if self.world > 1:
             self.bucket.all_reduce(self.group)                            # one SUM all-reduce per step
@@ -348,6 +441,12 @@ class Trainer:
         self._reset_accumulators()
 
     def _reset_accumulators(self):
+        self._pending = None
+        if self._tile_streams is not None:                 # (nothing of the tile pipeline may still be accumulating)
+            cur = torch.cuda.current_stream()
+            for st in self._tile_streams:
+                cur.wait_stream(st)
+        self._bwd_done = None
         if self.compose_cache is not None and self.compose_cache.pending:    # (error path: drop what was accumulated)
             for e in self.compose_cache.levels:
                 e["ga"].zero_()
