@@ -22,8 +22,9 @@ Legs, in this order (rank 0 prints ONE compact JSON line at the very end, nothin
      stream the kernels run on -> per-kernel table (written to ``--kernel-table``, not printed) and the ``roofline``
      objects: launches are aggregated per DEVICE KERNEL SYMBOL (t2h_last_kernel_name), the way
      ``rocprofv3 --kernel-trace --stats`` aggregates, so the two can be compared directly.
-     The trainer's side stream (weight gradients beside the data-gradient chain, on in the timed region) is OFF in this leg:
-     a kernel's two events then bracket that kernel alone (profiles/run_profiles.sh runs the profiler passes the same way).
+     The trainer's overlaps (weight gradients on a side stream beside the data-gradient chain; tile i + 1's forward beside tile
+     i's backward -- both on in the timed region) are OFF in this leg: a kernel's two events then bracket that kernel alone
+     (profiles/run_profiles.sh runs the profiler passes the same way).
   3. ``--check-dp`` (optional): the data-parallel equivalence check of SURVEY.md 8e.
   4. cpu_baseline (rank 0, N = 1 only): the oracle torch restatement on the host cores, SURVEY.md 8d protocol.
 """
@@ -440,6 +441,7 @@ def main():
         # the context switches (per-launch durations of 100 ms were measured with the side streams on) -- keep one stream per rank
         os.environ["T2H_OVERLAP_WGRAD"] = "0"
         os.environ["T2H_OVERLAP_CONV_WGRAD"] = "0"
+        os.environ["T2H_PIPELINE_TILES"] = "0"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -640,9 +642,10 @@ def main():
     timeline = None
     if args.profile_steps > 0 and not args.hip_graph:
         timeline = _lib.KernelTimeline()
-        # per-kernel durations are those of kernels running ALONE: the side streams of the timed step (weight gradients beside the
-        # data-gradient chain) are switched off for this untimed leg, so a kernel's events do not span another kernel's time on
-        # shared CUs.  (The timed region above keeps them on; the sum of these durations therefore exceeds ms_per_step's GPU share.)
+        # per-kernel durations are those of kernels running ALONE: the overlaps of the timed step (weight gradients on a side
+        # stream, the next tile's forward beside this tile's backward) are switched off for this untimed leg, so a kernel's events
+        # do not span another kernel's time on shared CUs.  (The timed region above keeps them on; the sum of these durations
+        # therefore exceeds ms_per_step.)
         saved_overlap = (trainer.overlap_wgrad, trainer.overlap_conv_wgrad, trainer.pipeline_tiles)
         trainer.flush_pipeline()
         trainer.overlap_wgrad = trainer.overlap_conv_wgrad = trainer.pipeline_tiles = False
@@ -729,8 +732,8 @@ def main():
                     out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
-                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps, side "
-                                          "stream off (kernels alone)")
+                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps, "
+                                          "overlaps off (kernels alone)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"])))
                                                   for n in SCATTER_REDUCE_TAGS if n in named]

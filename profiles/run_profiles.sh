@@ -10,9 +10,9 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-# the profiler passes time kernels ALONE (side streams off), like the per-kernel leg inside bench.py whose durations they must agree
+# the profiler passes time kernels ALONE (side streams and the tile pipeline off), like the per-kernel leg inside bench.py whose durations they must agree
 # with; the bench legs further down run the product's default (weight gradients on side streams)
-export T2H_OVERLAP_WGRAD=0 T2H_OVERLAP_CONV_WGRAD=0
+export T2H_OVERLAP_WGRAD=0 T2H_OVERLAP_CONV_WGRAD=0 T2H_PIPELINE_TILES=0
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 > $OUT/trace_bench.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 > /dev/null 2> $OUT/pmc_write.err
@@ -20,7 +20,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/probe_fetch -o p --output-form
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/probe_write -o p --output-format csv -- python3 $R/profiles/pmc_probe.py > /dev/null 2> $OUT/probe_write.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace_infer -o t --output-format csv -- python3 $R/bench.py --mode infer --batch 4 --hip-graph 1 --steps 12 --warmup 4 > $OUT/infer_bench.json 2> $OUT/trace_infer.err
 cd $R
-unset T2H_OVERLAP_WGRAD T2H_OVERLAP_CONV_WGRAD
+unset T2H_OVERLAP_WGRAD T2H_OVERLAP_CONV_WGRAD T2H_PIPELINE_TILES
 python3 profiles/collect_pmc.py --bench $OUT/pmc_fetch $OUT/pmc_write --probe $OUT/probe_fetch $OUT/probe_write --tag $TAG > $OUT/pmc_summary.txt 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python3 profiles/summarize_trace.py $(ls $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv 2>/dev/null | head -1) --steps 6 --top 70 --tag $TAG --json profiles/rocprof_kernels.json > $OUT/kernel_trace_steady_state.txt 2>&1

@@ -9,6 +9,7 @@ import os as _os
 # all ranks share cuda:0 here: one stream per process (see bench.py --share-gpu)
 _os.environ.setdefault("T2H_OVERLAP_WGRAD", "0")
 _os.environ.setdefault("T2H_OVERLAP_CONV_WGRAD", "0")
+_os.environ.setdefault("T2H_PIPELINE_TILES", "0")
 import json
 import os
 import sys
