@@ -735,13 +735,15 @@ def main():
                 out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps, "
                                           "overlaps off (kernels alone)")
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
-                out["roofline_scatter_reduce"] = [roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"])))
+                # (compact: peak and unit are those of `bound` -- 8000 GB/s for hbm, 157.3 TFLOP/s fp32 MFMA for mfma)
+                out["roofline_scatter_reduce"] = [{k: v for k, v in roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"]))).items()
+                                                   if k not in ("peak", "unit", "launches_per_step")}
                                                   for n in SCATTER_REDUCE_TAGS if n in named]
                 out["roofline_top_symbols"] = [{"kernel": s["kernel"][:60], "ms_per_step": s["ms_per_step"], "frac": s["frac"],
                                                 "bound": s["bound"]} for s in syms[:4]]          # (the stdout line stays < 4 KB: the full table is in the file)
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in tags), 3)
-                # > 1: the per-launch event pairs of the profile leg over-read the kernels (their sum exceeds the whole
-                # un-instrumented step), so `roofline.achieved` / `frac` are conservative by about this factor
+                # sum of the kernels' durations ALONE over the time of a timed step: > 1 is what the step's overlaps (side stream,
+                # tile pipeline) hide, plus whatever the per-launch event pairs of the profile leg over-read (2-3 %)
                 out["event_inflation"] = round(out["t2h_kernels_ms_per_step"] / ms_per_step, 4)
                 out["t2h_launches_per_step"] = round(sum(k["launches_per_step"] for k in tags), 1)
             try:
