@@ -317,14 +317,22 @@ def timing() -> bool:
     return _timeline is not None
 
 
+_fn_cache = {}
+
+
 def call(name: str, *args, nbytes: int = 0, flops: int = 0, tag: str = None):
     """Invoke ``name`` from the library, raising on a non-zero return code.  ``nbytes`` / ``flops`` = the
     ALGORITHMIC HBM bytes / floating-point operations of this launch, only used when a
     KernelTimeline is active."""
-    fn = getattr(load(), name)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
     tl = _timeline
     if tl is None:
         rc = fn(*args)
+        if rc != 0:
+            check(rc, name)
+        return
     else:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         lib = load()

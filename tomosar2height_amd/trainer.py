@@ -241,7 +241,8 @@ class Trainer:
         """One tile -- or a LIST of tiles of the same accumulation window as one micro-batch (``_losses_micro_batch``: same
         accumulated gradient as feeding them one by one, to fp32 re-association) --: forward, loss, backward.  Returns True
         when this call ended with an optimizer step."""
-        self.model.train()
+        if not self.model.training:                           # (Module.train() walks every submodule: 0.4 ms per call here)
+            self.model.train()
         n_tiles = len(data) if isinstance(data, (list, tuple)) else 1
         if n_tiles > 1 and (self.accumulated_steps + n_tiles > self.local_every):
             raise ValueError(f"a micro-batch of {n_tiles} tiles would cross the optimizer step boundary "
