@@ -577,7 +577,10 @@ def main():
         # is created by its first step, exactly like the kernels' first launches above
         trainer.optimizer_boundary()
     if args.hip_graph:
-        trainer.capture_graph(tiles[0])
+        if trainer.pipeline_tiles:
+            trainer.capture_pipeline_graphs(tiles[0])      # forward / backward graphs of the two tile streams
+        else:
+            trainer.capture_graph(tiles[0])
         run(2)
     # phase-align: the K-th timed tile must end an optimizer step, so the timed region contains the all-reduce + AdamW
     # work of ceil(K / local_every) optimizer steps (the driver's K = 20 would otherwise never reach the 64th tile)

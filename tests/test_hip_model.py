@@ -631,6 +631,43 @@ def test_pipelined_tiles_give_identical_gradients():
         assert torch.equal(wa[k], wb[k]), k
 
 
+def test_pipelined_tiles_as_hipgraphs_give_identical_gradients():
+    """``Trainer.capture_pipeline_graphs``: the tile pipeline with one forward and one backward hipGraph per tile stream.  Replays
+    run the kernels the eager pipeline launches, in the same order per buffer: accumulated gradients, loss accumulator and the
+    weights after an optimizer step are identical bit for bit to the eager pipeline; a tile of another shape falls back to eager."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    tiles = [{"inputs": synth_cloud(20000, seed=400 + i).to(_dev()),
+              "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(_dev())} for i in range(7)]
+    odd = {"inputs": synth_cloud(15000, seed=499).to(_dev()), "dsm": tiles[0]["dsm"]}
+
+    def run(graphs):
+        model = det_init_(TomoSAR2Height(cfg), seed=16).to(_dev())
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=1e-3), device=_dev(), optimize_every=5, use_cloud=True)
+        tr.pipeline_tiles = True
+        tr.overlap_wgrad = tr.overlap_conv_wgrad = False            # (the graphs keep the weight gradients on the tile's stream)
+        assert tr.train_step(tiles[0]) is False                     # eager: lays out the bucket
+        if graphs:
+            tr.capture_pipeline_graphs(tiles[1])
+        ended = [tr.train_step(t) for t in tiles[1:]] + [tr.train_step(odd)]
+        assert ended == [False, False, False, True, False, False, False]
+        tr.flush_gradients()
+        torch.cuda.synchronize()
+        return ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                {k: p.detach().clone() for k, p in model.named_parameters()}, float(tr.accumulated_loss), float(tr.last_avg_loss))
+
+    (ga, wa, la, lavg_a), (gb, wb, lb, lavg_b) = run(False), run(True)
+    assert la == lb and lavg_a == lavg_b
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+
+
 def test_tile_index_built_ahead_on_a_side_stream_gives_the_same_step():
     """``Trainer.prepare`` builds the next tile's index (cell sort, sampling adjoint, cell counts) on a side stream while the
     current step runs; the step on the prebuilt index is the step on the raw cloud, bit for bit (same kernels, same order)."""
