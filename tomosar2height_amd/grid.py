@@ -117,15 +117,16 @@ def conv3x3_supported(x: torch.Tensor, conv: torch.nn.Conv2d) -> bool:
             and x.dtype == torch.float32 and _pow2(x.shape[2]) and _pow2(x.shape[3]))
 
 
-# ---- the same convolutions on the bf16 matrix cores with an exact 3-way operand split (csrc/conv_bx3.hip) --------------------
-# T2H_CONV_PRECISION=fp32 keeps every 3x3 convolution on conv.hip's fp32 MFMA kernels (A/B; same tolerance either way: the
-# split is exact and the accumulation fp32 -- tests/test_hip_conv.py measures both against float64).  Planes of at least
-# T2H_BX3_MIN_PIXELS pixels (default: 256 x 256, where the kernels were measured 1.4-1.8x faster; profiles/conv_bf16x3_lab.hip).
-# 'bf16' (set by TomoSAR2Height.set_mlp_precision('bf16'), BASELINE configs[2]): the same kernels with the leading bf16 part of
-# both operands only -- one MFMA per product, tolerance of that MODE 2e-2 of the height scale (tests/test_full_size_vs_oracle.py).
-# 'f16x2': the same kernels on v_mfma_f32_32x32x16_f16 with a TWO-way fp16 split of both operands and one power-of-two scale per
-# staged block -- three MFMAs per product instead of six, fp32-grade unless an element lies more than 2^18 below the largest
-# element of its own staged block (csrc/conv_bx3.hip, "the fp16 two-way split"; include/t2h.h T2H_F16X2).
+# ---- the same convolutions on the 16-bit matrix cores with split operands (csrc/conv_bx3.hip) ---------------------------------
+# T2H_CONV_PRECISION selects the arithmetic of the 3x3 / transposed convolutions and of the wide grid-side products on planes of at
+# least T2H_BX3_MIN_PIXELS pixels (default 32 x 32; smaller ones stay on conv.hip):
+#   'f16x2' (default)  v_mfma_f32_32x32x16_f16 with a TWO-way fp16 split of both operands and one power-of-two scale per staged
+#                      block -- three MFMAs per product, fp32-grade unless an element lies more than 2^18 below the largest element
+#                      of its own staged block (csrc/conv_bx3.hip, "the fp16 two-way split"; include/t2h.h T2H_F16X2)
+#   'bf16x3'           the exact three-way bf16 split: six MFMAs per product (the r04b form)
+#   'fp32'             conv.hip's fp32 MFMA kernels (A/B; same tolerance: tests/test_hip_conv.py measures all three against float64)
+#   'bf16'             (set by TomoSAR2Height.set_mlp_precision('bf16'), BASELINE configs[2]) the leading bf16 part of both operands
+#                      only: one MFMA per product, tolerance of that MODE 2e-2 of the height scale (tests/test_full_size_vs_oracle.py)
 CONV_PRECISION = os.environ.get("T2H_CONV_PRECISION", "f16x2")
 BX3_MIN_PIXELS = int(os.environ.get("T2H_BX3_MIN_PIXELS", str(32 * 32)))
 _CONV_PRECISIONS = ("fp32", "bf16x3", "f16x2", "bf16")
@@ -135,8 +136,7 @@ _DEFAULT_CONV_PRECISION = CONV_PRECISION
 
 
 def set_conv_precision(name: str = None):
-    """'bf16x3' (exact split: fp32-grade), 'fp32' (conv.hip's fp32 MFMA) or 'bf16' (operands rounded to bf16: configs[2]);
-    None restores the process default (T2H_CONV_PRECISION)."""
+    """'f16x2', 'bf16x3', 'fp32' or 'bf16' (see above); None restores the process default (T2H_CONV_PRECISION)."""
     global CONV_PRECISION
     name = _DEFAULT_CONV_PRECISION if name is None else name
     if name not in _CONV_PRECISIONS:
