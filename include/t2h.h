@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 13
+#define T2H_ABI_VERSION 14
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -110,6 +110,19 @@ int t2h_pool_max_fwd(const float *feat, int ldf, const int32_t *off0, int B, int
                      int ldp, uint8_t *winner, t2h_stream_t stream);
 int t2h_pool_max_bwd(const float *gpooled, int ldg, const uint8_t *winner, const int32_t *off0, int B, int nbits,
                      int C, int accumulate, float *gfeat, int ldo, t2h_stream_t stream);
+/* The OPERATOR itself, in the reference's own layout, for callers of the operators rather than of the modules
+ * (SURVEY 8b "operator-level seam"):
+ *     out, arg = torch_scatter.scatter_max(src [B, C, N], index [B, 1, N], dim_size = R * R)              pointnet.py:95
+ * feat: the points' features POINT-major in the CALLER's order, [B * N, ld] (src is a permuted view of such a tensor at
+ * the reference's call site); perm / off0: from t2h_tile_build on the cell centres of `index` (equal-N batches).
+ * val [B, C, 4^nbits] fp32, arg [B, C, 4^nbits] int64, cell p = ix + R iy as coordinate2index numbers them.  Cells no
+ * point falls into: value 0, arg = N.  Ties: the first point in the caller's order (pytorch-scatter's CPU rule; NaN and
+ * -inf never win).  Backward (pytorch-scatter: the gradient of `out` goes to `arg` only): gsrc [B, N, C] point-major is
+ * zeroed and gsrc[b, arg[b, c, p], c] = gval[b, c, p] for every touched cell -- no atomics, a point lies in one cell. */
+int t2h_scatter_max_fwd(const float *feat, int ld, const int32_t *perm, const int32_t *off0, int B, int N, int nbits, int C,
+                        float *val, int64_t *arg, t2h_stream_t stream);
+int t2h_scatter_max_bwd(const float *gval, const int64_t *arg, int B, int C, int N, int64_t cells, float *gsrc,
+                        t2h_stream_t stream);
 /* scatter_type='mean' (pointnet.py:55-56: self.scatter = scatter_mean; no shipped config selects it): out[n] = mean of
  * feat over the rows of n's finest-level cell -- torch_scatter.scatter_mean (sum in point order, one division by the
  * count) followed by the gather of pointnet.py:98.  The operator is its own adjoint: the backward is the same call on the

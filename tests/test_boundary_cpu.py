@@ -177,6 +177,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_trunk_block_fwd": (n, 3, n, n, n, 32, n, n, n, n, n, n, n, n, n, 100, n, n, n, n, 32, n, n, n),
         "t2h_trunk_block_bwd": (n, 32, n, 32, n, n, n, n, n, n, n, n, 32, n, 32, n, 3, n, n, n, n, n, 100, n, n, 0, n),
         "t2h_trunk_block_reduce": (n, 100, 0, 0, n, n, n, n, n, n, n, 0, n),
+        "t2h_scatter_max_fwd": (n, 32, n, n, 1, 100, 4, 32, n, n, n),
+        "t2h_scatter_max_bwd": (n, n, 1, 32, 100, 256, n, n),
         "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }

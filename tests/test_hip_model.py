@@ -631,6 +631,83 @@ def test_pipelined_tiles_give_identical_gradients():
         assert torch.equal(wa[k], wb[k]), k
 
 
+@pytest.mark.parametrize("feed", ["fresh", "prepared", "producer"])
+def test_pipelined_tiles_whose_inputs_the_caller_drops_at_once(feed):
+    """The tile pipeline reads a tile's inputs on ITS streams until the end of its backward -- one ``train_step`` call after
+    the caller may have dropped them.  Here every tile is a FRESH device allocation (copied from the host / built ahead by
+    ``Trainer.prepare`` on a side stream / produced by ``producer.TileSource`` with prefetch on a side stream), dropped right
+    after ``train_step`` returns, and the caller's (and the producer's) stream then re-allocates blocks of the same sizes and
+    fills them with NaN.  The trainer holds the inputs until their backward has completed (``Trainer._hold_inputs``): gradients,
+    losses and weights equal the sequential run's bit for bit -- a recycled block would show up as NaN."""
+    import numpy as np_
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    dev = _dev()
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    n_tiles = 7
+    host = [{"inputs": synth_cloud(20000, seed=600 + i),
+             "dsm": torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30} for i in range(n_tiles)]
+    if feed == "producer":
+        from tomosar2height_amd.producer import RasterPatcher, TileProducer
+        from tomosar2height_amd.synthetic import berlin_chunk
+        ch = berlin_chunk(seed=5, tiles_per_side=2, n_points=20000)
+        chunk = (TileProducer(ch["points"].to(dev), z_bound=ch["z_bound"]), RasterPatcher(ch["dsm"].to(dev), ch["left"], ch["top"]))
+        anchors = np_.floor(np_.random.RandomState(3).uniform(0, 512.0, (n_tiles, 2))) + np_.array([ch["left"], ch["bottom"]])
+
+    def churn(shapes, streams):
+        for st in streams:
+            with torch.cuda.stream(st):
+                junk = [torch.full(shp, float("nan"), device=dev) for shp in shapes for _ in range(2)]
+                del junk
+
+    def run(pipelined):
+        model = det_init_(TomoSAR2Height(cfg), seed=17).to(dev)
+        model.set_channels_last(True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=1e-3), device=dev, optimize_every=4, use_cloud=True)
+        tr.pipeline_tiles = pipelined
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        source = None
+        if feed == "producer":
+            from tomosar2height_amd.producer import TileSource
+            source = TileSource(*chunk, flip_augm=True, rotate_augm=True, rng=np_.random.RandomState(9), stream=side)
+            ahead = source.get(anchors[0], defer_wait=True)
+        elif feed == "prepared":
+            ahead = tr.prepare({k: v.to(dev) for k, v in host[0].items()}, side)
+        ended = []
+        for i in range(n_tiles):
+            if feed == "fresh":
+                data = {k: v.to(dev) for k, v in host[i].items()}
+            else:
+                data = ahead                                      # produced / indexed while the previous step ran
+                if i + 1 < n_tiles:
+                    ahead = (source.get(anchors[i + 1], defer_wait=True) if source is not None
+                             else tr.prepare({k: v.to(dev) for k, v in host[i + 1].items()}, side))
+                if source is not None:
+                    source.wait(data)
+            n_i = data["inputs"].n_points if hasattr(data["inputs"], "n_points") else data["inputs"].shape[1]
+            ended.append(tr.train_step(data))
+            del data                                              # the caller's last reference
+            churn([(1, n_i, 3), (n_i, 3), (n_i,), (1, 512, 512), (65537,)], [main, side])
+        assert ended == [False, False, False, True, False, False, False]
+        tr.flush_gradients()
+        torch.cuda.synchronize()
+        assert all(ev.query() for ev, _ in tr._held)
+        return ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                {k: p.detach().clone() for k, p in model.named_parameters()}, float(tr.accumulated_loss), float(tr.last_avg_loss))
+
+    (ga, wa, la, lavg_a), (gb, wb, lb, lavg_b) = run(False), run(True)
+    assert np.isfinite(la) and np.isfinite(lavg_a)
+    assert la == lb and lavg_a == lavg_b
+    for k in ga:
+        assert torch.isfinite(gb[k]).all(), k
+        assert torch.equal(ga[k], gb[k]), k
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+
+
 def test_pipelined_tiles_as_hipgraphs_give_identical_gradients():
     """``Trainer.capture_pipeline_graphs``: the tile pipeline with one forward and one backward hipGraph per tile stream.  Replays
     run the kernels the eager pipeline launches, in the same order per buffer: accumulated gradients, loss accumulator and the

@@ -1,0 +1,272 @@
+"""-m gpu: the OPERATOR-level seam of SURVEY.md 8b.  The reference's own module graph -- here its restatement
+``oracle.torch_ref`` (pinned bit for bit to the imported reference by tests/test_oracle_golden.py), moved to the device
+UNCHANGED -- runs with only the operator calls replaced by ``tomosar2height_amd.ops``:
+
+    coordinate2index   utils/coordinate.py:12-28                   -> ops.coordinate2index
+    scatter_max        pointnet.py:95 (torch_scatter)              -> ops.scatter_max     (differentiable: grad -> arg)
+    scatter_mean       pointnet.py:109; alto.py:85,194             -> ops.scatter_mean
+    F.grid_sample      alto.py:95,204                              -> ops.grid_sample
+    F.interpolate      pixel.py:107                                -> ops.interpolate
+
+and is compared with the same graph on the CPU (the oracle) and with the fixtures generated from the reference itself.
+The linear layers / convolutions of that graph stay torch's (that IS the reference's graph on a GPU); the packaged
+modules (test_hip_model.py) are the path that replaces them too.  Tolerances: heights 1e-4 relative (north_star); gradients
+at the mask-flip resolution used everywhere else (1e-2 max-normalised, 3e-3 L2; fixtures of the reduced net 2e-4)."""
+import contextlib
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from detinit import det_init_, synth_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+@contextlib.contextmanager
+def hip_operators():
+    """``oracle.torch_ref`` with its five operator names bound to the HIP drop-ins (and nothing else changed)."""
+    import torch.nn.functional as F
+    from oracle import torch_ref
+    from tomosar2height_amd import ops
+
+    shim = types.SimpleNamespace(**{k: getattr(F, k) for k in dir(F) if not k.startswith("__")})
+    shim.grid_sample = ops.grid_sample
+    shim.interpolate = ops.interpolate
+    saved = {k: getattr(torch_ref, k) for k in ("scatter_max", "scatter_mean", "coordinate2index", "F")}
+    torch_ref.scatter_max, torch_ref.scatter_mean = ops.scatter_max, ops.scatter_mean
+    torch_ref.coordinate2index, torch_ref.F = ops.coordinate2index, shim
+    try:
+        yield torch_ref
+    finally:
+        for k, v in saved.items():
+            setattr(torch_ref, k, v)
+        ops.check_indices()
+
+
+# ------------------------------------------------------------------------------------------------ the operators themselves
+@pytest.mark.parametrize("reso", [4, 16])
+def test_pool_local_on_the_hip_scatter_max_matches_the_reference_fixture(reso):
+    """pointnet.py:92-99 verbatim -- scatter_max(...)[0].gather(2, index.expand(...)) -- forward AND gradient against the
+    reference's own fixture (engineered ties, an all-equal cell)."""
+    from tomosar2height_amd import ops
+    g = load_golden("pool_local")
+    feat = torch.from_numpy(g[f"feat_r{reso}"]).to(_dev()).requires_grad_(True)
+    index = torch.from_numpy(g[f"index_r{reso}"]).to(_dev())
+    assert torch.equal(ops.coordinate2index(torch.from_numpy(g[f"xy_r{reso}"]).to(_dev()), reso), index)
+    fea, arg = ops.scatter_max(feat.permute(0, 2, 1), index, dim_size=reso ** 2)
+    assert fea.requires_grad and not arg.requires_grad and arg.dtype == torch.int64
+    out = fea.gather(dim=2, index=index.expand(-1, feat.size(2), -1)).permute(0, 2, 1)
+    assert np.array_equal(out.detach().cpu().numpy(), g[f"out_r{reso}"])
+    out.backward(torch.from_numpy(g[f"gout_r{reso}"]).to(_dev()))
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), g[f"gfeat_r{reso}"], rtol=1e-6, atol=1e-6)
+    ops.check_indices()
+
+
+@pytest.mark.parametrize("b,n,c,reso", [(2, 700, 8, 16), (1, 5000, 32, 64), (3, 257, 5, 2), (1, 131072, 32, 256)])
+def test_scatter_max_values_args_and_gradient_against_the_restated_torch_scatter(b, n, c, reso):
+    """(out, arg) bit for bit and the routed gradient exactly, against oracle/scatter_ref.py on the CPU: quantised values
+    (many ties: first point wins), a -inf entry (never wins), empty cells (0, arg = N), a channel count off the float4 path,
+    a plane smaller than a workgroup's 8 x 8 block, and the benchmark's size."""
+    from oracle import scatter_ref
+    from tomosar2height_amd import ops
+    gen = torch.Generator().manual_seed(100 + n)
+    cloud = synth_cloud(n, seed=n, batch=b)
+    feat = (torch.randn(b, n, c, generator=gen) * 4).round() / 4
+    feat[0, 5, min(1, c - 1)] = float("-inf")
+    idx = ((cloud[..., 0] * reso).long() + reso * (cloud[..., 1] * reso).long()).unsqueeze(1)
+    gval = (torch.randn(b, c, reso * reso, generator=gen) * 8).round() / 8
+    src_ref = feat.clone().requires_grad_(True)
+    want_v, want_a = scatter_ref.scatter_max(src_ref.permute(0, 2, 1), idx, dim_size=reso * reso)
+    (want_v * gval).sum().backward()
+
+    src = feat.to(_dev()).requires_grad_(True)
+    index = idx.to(_dev())
+    val, arg = ops.scatter_max(src.permute(0, 2, 1), index, dim_size=reso * reso)
+    (val * gval.to(_dev())).sum().backward()
+    assert torch.equal(arg.cpu(), want_a)
+    assert np.array_equal(val.detach().cpu().numpy(), want_v.detach().numpy())
+    assert np.array_equal(src.grad.cpu().numpy(), src_ref.grad.numpy())
+    # a channel-major contiguous src (not the permuted view the reference passes) goes through one copy, same results
+    val2, arg2 = ops.scatter_max(feat.permute(0, 2, 1).contiguous().to(_dev()), index, dim_size=reso * reso)
+    assert torch.equal(arg2, arg) and torch.equal(val2, val.detach())
+    # NaN never wins the strict '>' (pytorch-scatter's CPU loop, restated in plain C by oracle/t2h_oracle.c)
+    from oracle import c_oracle
+    feat[0, 3, 0] = float("nan")
+    feat[0, 4, :] = float("nan")
+    want_v, want_a = c_oracle.scatter_max(feat.numpy(), idx.numpy(), reso * reso)
+    val3, arg3 = ops.scatter_max(feat.to(_dev()).permute(0, 2, 1), index, dim_size=reso * reso)
+    assert np.array_equal(val3.cpu().numpy(), want_v) and np.array_equal(arg3.cpu().numpy(), want_a)
+    ops.check_indices()
+
+
+def test_operator_seam_does_not_synchronise_and_reports_bad_indices_later():
+    """No call of the seam waits for the device (torch's sync debug mode would raise); an index outside [0, dim_size) is
+    clamped on the device and reported by a later call / ``check_indices()`` as ValueError (torch_scatter: index error)."""
+    from tomosar2height_amd import ops
+    n, c, reso = 4096, 16, 32
+    cloud = synth_cloud(n, seed=3).to(_dev())
+    feat = torch.randn(1, n, c, device=_dev(), requires_grad=True)
+    plane = torch.randn(1, c, reso, reso, device=_dev(), requires_grad=True)
+    gout = torch.randn(1, c, n, 1, device=_dev())
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        index = ops.coordinate2index(cloud[..., :2], reso)
+        fea, _ = ops.scatter_max(feat.permute(0, 2, 1), index, dim_size=reso * reso)
+        back = fea.gather(2, index.expand(-1, c, -1))
+        mean = ops.scatter_mean(feat.permute(0, 2, 1), index, out=feat.new_zeros(1, c, reso * reso))
+        samp = ops.grid_sample(plane, 2.0 * cloud[:, :, None, :2] - 1.0, padding_mode="border", align_corners=True,
+                               mode="bilinear")
+        up = ops.interpolate(plane, size=64, mode="bilinear", align_corners=True)
+        (back.sum() + mean.sum() + up.sum()).backward()
+        samp.backward(gout)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    ops.check_indices()
+    assert feat.grad is not None and plane.grad is not None
+    # the index tensor's tile is built once and found again (same tensor object, same version)
+    assert ops._tile_from_index(index, reso * reso) is ops._tile_from_index(index, reso * reso)
+    bad = index.clone()
+    bad[0, 0, 7] = reso * reso
+    ops.scatter_mean(feat.detach().permute(0, 2, 1), bad, dim_size=reso * reso)
+    with pytest.raises(ValueError, match="outside"):
+        ops.check_indices()
+    ops.check_indices()                                           # reported once
+
+
+def test_grid_sample_with_the_reference_signature():
+    """alto.py:90-95: vgrid = 2 * xy - 1 -> F.grid_sample(c, vgrid, padding_mode='border', align_corners=True,
+    mode='bilinear') -> [B, C, N, 1] against ATen on the CPU (same taps and weights; the four-term sum is evaluated
+    without fused multiply-adds here, ATen's build may contract: a few ulp), the plane gradient within fp32 summation-order
+    noise, and the vgrid -> xy recovery exact: the same bits as sampling at the xy that produced the grid."""
+    import torch.nn.functional as F
+    from tomosar2height_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    for (b, c, r, n) in [(2, 12, 16, 3000), (1, 64, 128, 20000)]:
+        xy = synth_cloud(n, seed=r, batch=b)[..., :2].contiguous()
+        xy[0, :4] = torch.tensor([[2.0 ** -20, 2.0 ** -20], [1 - 2.0 ** -20, 0.5], [0.25, 0.75], [0.1, 1 - 2.0 ** -20]])
+        plane = torch.randn(b, c, r, r, generator=gen)
+        gout = torch.randn(b, c, n, 1, generator=gen)
+        vgrid = 2.0 * xy[:, :, None].float() - 1.0
+        p_ref = plane.clone().requires_grad_(True)
+        want = F.grid_sample(p_ref, vgrid, padding_mode="border", align_corners=True, mode="bilinear")
+        want.backward(gout)
+        p = plane.to(_dev()).requires_grad_(True)
+        got = ops.grid_sample(p, vgrid.to(_dev()), padding_mode="border", align_corners=True, mode="bilinear")
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+        direct = ops.grid_sample_points(p.detach(), xy.to(_dev()))
+        assert torch.equal(direct, got.detach().squeeze(-1))
+        got.backward(gout.to(_dev()))
+        assert _rel(p.grad.cpu().numpy(), p_ref.grad.numpy()) <= 2e-6
+    with pytest.raises(NotImplementedError):
+        ops.grid_sample(p, vgrid.to(_dev()), mode="nearest")
+
+
+# ------------------------------------------------------------------------------------------------ reference-shaped graphs
+def test_reference_shaped_pointnet_on_hip_operators_matches_the_reference_fixture():
+    """The restated LocalPoolPointnet + ALTO U-Net (reduced: r = 16, depth 3, 8 channels), on the device, operators swapped,
+    against the output plane and EVERY parameter gradient the reference itself produced (fixture 6 of SURVEY 8c)."""
+    g = load_golden("local_pool_pointnet_reduced")
+    with hip_operators() as torch_ref:
+        enc = torch_ref.LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                                          unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8),
+                                          plane_resolution=16)
+        enc.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}, strict=True)
+        enc.to(_dev())
+        out = enc(torch.from_numpy(g["cloud"]).to(_dev()))["xy"]
+        out.backward(torch.from_numpy(g["gout"]).to(_dev()))
+    assert _rel(out.detach().cpu().numpy(), g["out"]) <= 1e-4
+    assert [k for k, v in enc.named_parameters() if v.grad is None] == g["none_grad"].tolist()
+    for k, v in enc.named_parameters():
+        if v.grad is not None:
+            assert _rel(v.grad.cpu().numpy(), g["g." + k]) <= 2e-4, k
+
+
+def _compare_with_cpu_oracle(cfg, cloud, seed, what):
+    """Heights and every parameter gradient (smooth linear loss, see test_model_vs_torch_oracle_all_grads) of the
+    reference-shaped graph on the HIP operators against the same graph on the CPU."""
+    from oracle import torch_ref as cpu_ref
+    w = torch.randn(512, 512, generator=torch.Generator().manual_seed(1))
+    ref = det_init_(cpu_ref.TomoSAR2Height(cfg), seed=seed)
+    pa_ref, _ = ref(input_cloud=cloud)
+    (pa_ref.squeeze() * w).mean().backward()
+    with hip_operators() as torch_ref:
+        model = det_init_(torch_ref.TomoSAR2Height(cfg), seed=seed).to(_dev())
+        pa, pb = model(input_cloud=cloud.to(_dev()))
+        (pa.squeeze() * w.to(_dev())).mean().backward()
+        torch.cuda.synchronize()
+    err = _rel(pa.detach().cpu().numpy(), pa_ref.detach().numpy())
+    print(f"[{what}] reference-shaped graph on HIP operators: heights max rel err vs CPU oracle {err:.2e}")
+    assert err <= 1e-4
+    worst = (0.0, 0.0, "")
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is None:
+            continue
+        got, want = p.grad.cpu().double(), q.grad.double()
+        mx = _rel(got.numpy(), want.numpy())
+        l2 = ((got - want).norm() / (want.norm() + 1e-30)).item()
+        worst = max(worst, (mx, l2, k))
+        assert mx <= 1e-2, f"{k}: max-normalised gradient error {mx:.2e}"
+        assert l2 <= 3e-3, f"{k}: L2 relative gradient error {l2:.2e}"
+    print(f"[{what}] worst gradient: {worst[0]:.2e} max-normalised, {worst[1]:.2e} L2 ({worst[2]})")
+    return model
+
+
+def test_reference_shaped_full_model_on_hip_operators_matches_the_reference_fixture():
+    """Full-size Berlin network at N = 4096 (fixture 8 of SURVEY 8c): heights against the REFERENCE's own output, loss and
+    gradient norms under the trainer's L1 loss (trainer.py:61-70) -- the bounds test_full_model_golden holds the packaged
+    modules to."""
+    from tomosar2height_amd.config import berlin_config
+    g = load_golden("full_model_berlin_n4096")
+    cfg = berlin_config()
+    cloud = torch.from_numpy(g["cloud"])
+    dsm = torch.from_numpy(g["dsm_lo"]).repeat_interleave(8, -2).repeat_interleave(8, -1)
+    with hip_operators() as torch_ref:
+        model = det_init_(torch_ref.TomoSAR2Height(cfg), seed=8).to(_dev())
+        assert list(model.state_dict()) == g["state_keys"].tolist()
+        loss = torch_ref.train_loss(model, cloud.to(_dev()), None, dsm.to(_dev()))
+        loss.backward()
+        with torch.no_grad():
+            pa, _ = model(input_cloud=cloud.to(_dev()))
+    assert _rel(pa[0, :, :, 0].cpu().numpy(), g["height"]) <= 1e-4
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-4)
+    grads = dict(model.named_parameters())
+    assert [k for k, v in grads.items() if v.grad is None] == g["none_grad"].tolist()
+    for k, nrm in zip(g["grad_names"].tolist(), g["grad_norm"]):      # L1's sign flips: norms to 2e-2, as test_full_model_golden
+        got = grads[k].grad.double().norm().item()
+        assert abs(got - nrm) <= 2e-2 * nrm + 1e-9, f"{k}: grad norm {got} vs {nrm}"
+
+
+def test_reference_shaped_full_model_on_hip_operators_all_gradients():
+    """Every height and every parameter gradient against the CPU oracle on the skewed tile of
+    test_hip_model.py::test_model_vs_torch_oracle_all_grads (N = 20 000, 3000 points in ONE finest cell), at that test's
+    bounds (the resolution ReLU / arg-max mask flips leave: 1e-2 max-normalised, 3e-3 L2)."""
+    from tomosar2height_amd.config import berlin_config
+    cloud = synth_cloud(20000, seed=77)
+    cloud[0, :3000, :2] = cloud[0, 0, :2]
+    _compare_with_cpu_oracle(berlin_config(), cloud, seed=21, what="berlin N=20000, skewed")
+
+
+def test_reference_shaped_full_model_on_hip_operators_at_the_benchmarked_size():
+    """N = 131 072 (bench.py's tile): the operator kernels at the size-keyed selections the benchmark runs (the sort, the
+    scatter over 65 536 cells, the sample adjoint by walks / transposed matrix), inside the reference's own graph."""
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import DEFAULT_POINTS, berlin_tile
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tile = berlin_tile(seed=1000, n_points=DEFAULT_POINTS)
+    assert tile["inputs"].shape == (1, 131072, 3)
+    _compare_with_cpu_oracle(berlin_config(), tile["inputs"], seed=31, what="berlin N=131072")

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -32,6 +32,8 @@ SIGNATURES = {
     "t2h_pool_max_fwd": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "t2h_pool_max_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "t2h_pool_mean": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "t2h_scatter_max_fwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "t2h_scatter_max_bwd": (_i, [_vp, _vp, _i, _i, _i, _i64, _vp, _vp]),
     "t2h_pool_rows_fwd": (_i, [_vp, _i, _vp, _vp, _i64, _i, _vp, _i, _vp, _vp]),
     "t2h_pool_rows_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp, _i, _vp]),
     "t2h_segmean_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -11,7 +11,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from .. import mlp, ops
+from .. import _lib, mlp, ops
 from ..block import ResnetBlockFC
 from ..tile import TileIndex
 from .alto import UNet as Alto
@@ -43,6 +43,11 @@ class LocalPoolPointnet(nn.Module):
         # total (out_of_domain_total) is read by Trainer at optimizer-step boundaries and by DSMGenerator per mosaic
         self.check_domain = False
         self.register_buffer("domain_status", torch.zeros(2, dtype=torch.int32), persistent=False)
+        # one status pair per STREAM that builds tile indices: t2h_tile_build zeroes status[0] in stream order and counts into it
+        # with atomics, so two tiles building concurrently (the trainer's tile pipeline: forward i + 1 beside backward i, each on
+        # its own stream) must not share the pair -- one tile's reset would race the other's atomics.  ``domain_status`` serves
+        # the first stream seen; the running totals (status[1]) of all of them are summed by out_of_domain_total()
+        self._status_by_stream = {}
 
     def set_channels_last(self, flag: bool):
         """Keep the grid side in channels_last memory so planes need no NCHW<->NHWC copies."""
@@ -53,10 +58,25 @@ class LocalPoolPointnet(nn.Module):
     def out_of_domain_total(self, reset: bool = True) -> int:
         """Points with x or y outside [0, 1) (or NaN) over all forwards since the last reset (synchronises).  Such
         points were clamped into the border cells; the reference would index out of range (coordinate.py:12-28)."""
-        n = int(self.domain_status[1].item())
+        extra = [st for st in self._status_by_stream.values() if st is not self.domain_status
+                 and st.device == self.domain_status.device]
+        if extra:                                           # (the caller's stream has joined the tile streams: Trainer.flush_pipeline)
+            n = int(torch.stack([self.domain_status] + extra)[:, 1].sum().item())
+        else:
+            n = int(self.domain_status[1].item())
         if reset and n:
             self.domain_status.zero_()
+            for st in extra:
+                st.zero_()
         return n
+
+    def _status_for(self, raw_stream: int) -> torch.Tensor:
+        hit = self._status_by_stream.get(raw_stream)
+        if hit is None or hit.device != self.domain_status.device:
+            taken = any(st is self.domain_status for st in self._status_by_stream.values())
+            hit = torch.zeros_like(self.domain_status) if taken else self.domain_status
+            self._status_by_stream[raw_stream] = hit
+        return hit
 
     def point_features(self, tile: TileIndex) -> torch.Tensor:
         """pointnet.py:72-82 on sorted rows: fc_pos, 5 ResNet blocks with 4 local max- (or mean-) pools, fc_c."""
@@ -64,7 +84,8 @@ class LocalPoolPointnet(nn.Module):
 
     def prepare(self, inputs: torch.Tensor, stream=None) -> TileIndex:
         """Build the index of a tile ahead of its step, on ``stream`` (see ``TileIndex.prebuild``)."""
-        return TileIndex.prebuild(inputs, self.reso_plane, status=self.domain_status, stream=stream)
+        status = self._status_for(stream.cuda_stream if stream is not None else _lib.stream())
+        return TileIndex.prebuild(inputs, self.reso_plane, status=status, stream=stream)
 
     def forward(self, inputs: torch.Tensor) -> Dict[str, torch.Tensor]:
         """inputs ``[B, N, 3]`` in [0,1) -> ``{'xy': [B, feature_dim, R, R]}``.  ``inputs`` may also be the tile's index built
@@ -74,7 +95,7 @@ class LocalPoolPointnet(nn.Module):
                 raise ValueError(f"prebuilt TileIndex has resolution {inputs.R}, the encoder {self.reso_plane}")
             tile = inputs.wait_ready()
         else:
-            tile = TileIndex(inputs, self.reso_plane, status=self.domain_status)
+            tile = TileIndex(inputs, self.reso_plane, status=self._status_for(_lib.stream()))
         if self.check_domain:
             tile.check_domain()
         net = self.point_features(tile)

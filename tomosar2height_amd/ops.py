@@ -324,13 +324,52 @@ def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
     return out[:, None, :]
 
 
-# The next three mirror the reference's operator calls with their ORIGINAL signatures (original point order, raw
-# int64 cell index).  They are a compatibility seam for code that calls the operators directly: the tile index is
-# rebuilt from the index tensor (cell centres stand in for the coordinates), rows are permuted into sorted order,
-# and the same HIP kernels run.  The packaged modules never take this route (they produce features in sorted order).
+# The rest mirrors the reference's OPERATOR calls with their original signatures (original point order, raw int64 cell
+# index, channel-major [B, C, N] features): SURVEY.md 8b "operator-level seam".  It is what a caller gets who keeps the
+# reference's own module graph and swaps only the operators; every one of them is differentiable exactly where the
+# reference's is.  The tile index is built from the index tensor (cell centres stand in for the coordinates) ONCE per index
+# tensor -- the reference computes an index with coordinate2index and hands it to several scatter calls (pointnet.py:70,
+# 76-77, 88) -- and the same HIP kernels run.  No call here synchronises with the device: an index outside
+# [0, dim_size) is counted on the device, clamped into a border cell, and reported by a LATER call of this seam (or by
+# ``check_indices()``) as ValueError -- the asynchronous form of the index error torch_scatter raises.  The packaged
+# modules never take this route (they keep features in sorted order).
+_index_tiles = {}          # id(index tensor) -> (weakref, version, cells, TileIndex)
+_pending_index_checks = []  # (event, pinned status copy, description)
+
+
+def _poll_index_checks(wait: bool = False):
+    keep = []
+    bad = None
+    for ev, host, what in _pending_index_checks:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            if int(host[0]) and bad is None:
+                bad = (int(host[0]), what)
+        else:
+            keep.append((ev, host, what))
+    _pending_index_checks[:] = keep
+    if bad is not None:
+        raise ValueError(f"{bad[1]}: {bad[0]} index value(s) outside [0, dim_size) (clamped into border cells on the device; "
+                         "torch_scatter raises an index error for these)")
+
+
+def check_indices():
+    """Wait for the index-range checks of all operator-seam calls issued so far and raise ValueError if one failed."""
+    _poll_index_checks(wait=True)
+
+
 def _tile_from_index(index: torch.Tensor, dim_size: int) -> TileIndex:
+    import weakref
+    _poll_index_checks()
     if index.dim() != 3 or index.shape[1] != 1:
         raise ValueError("index must be [B, 1, N] (what coordinate2index returns)")
+    if index.dtype != torch.int64:
+        raise TypeError(f"index must be int64, got {index.dtype}")
+    _lib.require_device(index, what="scatter index")
+    hit = _index_tiles.get(id(index))
+    if hit is not None and hit[0]() is index and hit[1] == index._version and hit[2] == int(dim_size):
+        return hit[3]
     reso = int(round(dim_size ** 0.5))
     if reso * reso != dim_size:
         raise ValueError(f"dim_size={dim_size} is not a square plane")
@@ -338,59 +377,154 @@ def _tile_from_index(index: torch.Tensor, dim_size: int) -> TileIndex:
     ix, iy = (idx % reso).float(), torch.div(idx, reso, rounding_mode="floor").float()
     centres = torch.stack([(ix + 0.5) / reso, (iy + 0.5) / reso, torch.zeros_like(ix)], dim=2)
     tile = TileIndex(centres.contiguous(), reso)
-    tile.check_domain()        # index outside [0, dim_size) -> ValueError (torch_scatter raises an index error)
+    # index outside [0, dim_size): status[0] counts them; copied to pinned memory in stream order and looked at later
+    host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+    host.copy_(tile.status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending_index_checks.append((ev, host, f"scatter index [B={index.shape[0]}, N={index.shape[2]}] into {dim_size} cells"))
+    key = id(index)
+    _index_tiles[key] = (weakref.ref(index, lambda _r, k=key: _index_tiles.pop(k, None)), index._version, int(dim_size), tile)
     return tile
+
+
+def _point_major(src: torch.Tensor, what: str) -> torch.Tensor:
+    """src [B, C, N] -> contiguous [B, N, C] fp32 on the device; free when src is the permuted view of a point-major tensor
+    (what the reference passes: pointnet.py:95,109)."""
+    if src.dim() != 3:
+        raise ValueError(f"{what}: src must be [B, C, N], got {tuple(src.shape)}")
+    pm = _f32(src, what).permute(0, 2, 1)
+    pm = pm if pm.is_contiguous() else pm.contiguous()
+    _lib.require_device(pm, what=what)
+    return pm
 
 
 def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out: torch.Tensor = None,
                  dim_size: int = None) -> torch.Tensor:
     """``torch_scatter.scatter_mean(src[B,C,N], index[B,1,N], out=zeros[B,C,R*R])`` (pointnet.py:109; alto.py:85,194).
-    ``out`` must be all zero as at every reference call site; it is filled and returned."""
+    ``out`` must be all zero as at every reference call site; it is filled and returned.  Differentiable w.r.t. ``src``
+    (grad[b,c,n] = grad_out[b,c,cell(n)] / count(cell(n)))."""
     if dim not in (-1, 2):
         raise NotImplementedError("only the last-dim form the reference uses is built")
     cells = out.shape[-1] if out is not None else int(dim_size)
     tile = _tile_from_index(index, cells)
-    feat = tile.sort_rows(src.permute(0, 2, 1).contiguous())
+    feat = tile.sort_rows(_point_major(src, "scatter_mean"))
     plane = rasterise_mean(tile, feat, tile.R)                       # [B, C, R, R]
     flat = plane.reshape(plane.shape[0], plane.shape[1], cells)
     if out is not None:
-        out.copy_(flat)
+        out.copy_(flat)            # in place like torch_scatter (autograd follows the copy: `out` becomes differentiable)
         return out
     return flat
 
 
+class _ScatterMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, cells: int):
+        pm = _point_major(src, "scatter_max")
+        b, n, c = pm.shape
+        tile = _tile_from_index(index, cells)
+        if tile.B != b or tile.N != n:
+            raise ValueError(f"scatter_max: src {tuple(src.shape)} does not match index {tuple(index.shape)}")
+        val = torch.empty(b, c, cells, dtype=torch.float32, device=pm.device)
+        arg = torch.empty(b, c, cells, dtype=torch.int64, device=pm.device)
+        _lib.call("t2h_scatter_max_fwd", _lib.ptr(pm), c, _lib.ptr(tile.perm), _lib.ptr(tile.off0), b, n, tile.nbits, c,
+                  _lib.ptr(val), _lib.ptr(arg), _lib.stream(), nbytes=4 * c * b * n + 8 * b * n + 12 * c * b * cells)
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        ctx.n = n
+        return val, arg
+
+    @staticmethod
+    def backward(ctx, gval, _garg):
+        (arg,) = ctx.saved_tensors
+        b, c, cells = arg.shape
+        gval = gval.contiguous()
+        _lib.require_device(gval, what="scatter_max backward")
+        gsrc = torch.empty(b, ctx.n, c, dtype=torch.float32, device=gval.device)
+        _lib.call("t2h_scatter_max_bwd", _lib.ptr(gval), _lib.ptr(arg), b, c, ctx.n, cells, _lib.ptr(gsrc), _lib.stream(),
+                  nbytes=12 * c * b * cells + 4 * c * b * ctx.n)
+        return gsrc.permute(0, 2, 1), None, None
+
+
 def scatter_max(src: torch.Tensor, index: torch.Tensor, dim: int = -1, out=None, dim_size: int = None):
     """``torch_scatter.scatter_max(src[B,C,N], index[B,1,N], dim_size=R*R) -> (out[B,C,R*R], arg[B,C,R*R])``
-    (pointnet.py:95).  Untouched cells: value 0, arg = N.  Ties: first point wins.  Forward only."""
+    (pointnet.py:95).  Untouched cells: value 0, arg = N.  Ties: first point wins.  Differentiable w.r.t. ``src``: the
+    gradient of ``out`` goes to the arg-max point only (pytorch-scatter's backward); ``arg`` is not differentiable."""
     if dim not in (-1, 2) or out is not None:
         raise NotImplementedError("only scatter_max(src, index, dim_size=...) over the last dim is built")
-    b, c, n = src.shape
-    tile = _tile_from_index(index, int(dim_size))
-    feat = tile.sort_rows(src.permute(0, 2, 1).contiguous())
-    pooled = torch.empty_like(feat)
-    winner = torch.empty(b * n, _lib.load().t2h_pool_winner_stride(c), dtype=torch.uint8, device=src.device)
-    _lib.call("t2h_pool_max_fwd", _lib.ptr(feat), c, _lib.ptr(tile.off0), tile.B, tile.nbits, c, _lib.ptr(pooled), c,
-              _lib.ptr(winner), _lib.stream(), nbytes=8 * c * b * n + 4 * b * n)
-    # expand the winner bitmask to one flag per (point, channel), then scatter values / original indices to cells
-    vec = 4 if c % 4 == 0 else 1
-    shifts = torch.arange(vec, device=src.device, dtype=torch.uint8)
-    flags = ((winner[:, :, None] >> shifts) & 1).reshape(b * n, -1)[:, :c].bool()          # sorted order
-    rows, chans = flags.nonzero(as_tuple=True)
-    cell_of = index[:, 0, :].reshape(-1)[(tile.perm.long() + torch.arange(b, device=src.device).repeat_interleave(n) * n)]
-    batch_of = rows // n
-    val = torch.zeros(b, c, int(dim_size), dtype=src.dtype, device=src.device)
-    arg = torch.full((b, c, int(dim_size)), n, dtype=torch.int64, device=src.device)
-    val[batch_of, chans, cell_of[rows]] = pooled[rows, chans]
-    arg[batch_of, chans, cell_of[rows]] = tile.perm.long()[rows]
-    return val, arg
+    if dim_size is None:
+        raise NotImplementedError("scatter_max: pass dim_size (the reference always does, pointnet.py:95): inferring it "
+                                  "from index.max() would synchronise with the device")
+    return _ScatterMax.apply(src, index, int(dim_size))
+
+
+class _GridSamplePoints(torch.autograd.Function):
+    """Bilinear / border / align_corners sample at N points given in the caller's order.  The forward is a plain gather
+    (no sort); only the backward -- ATen's is 4 C atomics per point -- sorts the points once to run the atomic-free
+    segmented adjoint."""
+
+    @staticmethod
+    def forward(ctx, plane, xy):
+        _f32(plane, "grid_sample")
+        b, c, r, r2 = plane.shape
+        if r != r2 or xy.shape[0] != b:
+            raise ValueError(f"grid_sample: expected plane [B, C, r, r] and points [B, N, 2], got {tuple(plane.shape)}, "
+                             f"{tuple(xy.shape)}")
+        ctx.was_cl = _is_channels_last(plane)
+        p = to_nhwc(plane)
+        _lib.require_device(p, xy, what="grid_sample")
+        n = xy.shape[1]
+        pts = torch.cat([xy[..., :2], torch.zeros_like(xy[..., :1])], dim=2).contiguous()
+        out = torch.empty(b * n, c, dtype=torch.float32, device=p.device)
+        _lib.call("t2h_sample_fwd", _lib.ptr(p), _lib.ptr(pts), 3, b, n, r, c, _lib.ptr(out), _lib.stream(),
+                  nbytes=4 * c * b * n + 8 * b * n + 4 * p.numel())
+        ctx.save_for_backward(pts)
+        ctx.shape = (b, c, r, n)
+        return out.view(b, n, c).permute(0, 2, 1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pts,) = ctx.saved_tensors
+        b, c, r, n = ctx.shape
+        tile = TileIndex(pts.clamp(0.0, 1.0 - 2.0 ** -24), r)        # binning needs [0,1); sampling uses the raw xy
+        tile.pts.copy_(tile.sort_rows(pts))
+        g = tile.sort_rows(gout.permute(0, 2, 1))
+        gplane = _sample_bwd(tile, g, r, c, None)
+        return from_nhwc(gplane, ctx.was_cl), None
 
 
 def grid_sample_points(plane: torch.Tensor, xy: torch.Tensor) -> torch.Tensor:
     """``F.grid_sample(plane, 2*xy[:, :, None]-1, padding_mode='border', align_corners=True).squeeze(-1)``
     (alto.py:90-95): plane [B,C,r,r], xy [B,N,2+] -> [B,C,N].  Differentiable w.r.t. the plane."""
-    b, c, r, _ = plane.shape
-    pts = torch.cat([xy[..., :2], torch.zeros_like(xy[..., :1])], dim=2).contiguous()
-    tile = TileIndex(pts.clamp(0.0, 1.0 - 2.0 ** -24), r)            # binning needs [0,1); sampling uses the raw xy
-    tile.pts.copy_(tile.sort_rows(pts))
-    out_sorted = sample_plane(tile, plane)
-    return tile.unsort_rows(out_sorted).permute(0, 2, 1)
+    return _GridSamplePoints.apply(plane, _f32(xy, "grid_sample_points"))
+
+
+def grid_sample(input: torch.Tensor, grid: torch.Tensor, mode: str = "bilinear", padding_mode: str = "border",
+                align_corners: bool = True) -> torch.Tensor:
+    """``F.grid_sample(c[B,C,r,r], vgrid[B,N,1,2], padding_mode='border', align_corners=True, mode='bilinear') ->
+    [B,C,N,1]`` with the reference's own signature (alto.py:95,204).  ``vgrid = 2*xy - 1``: the kernels take xy, which is
+    recovered as (vgrid + 1) / 2 in float64 -- exactly the coordinate whose ``2*xy - 1`` rounds to the given vgrid whenever
+    vgrid was produced that way (every reference call), so taps and weights are ATen's bit for bit on such grids; an
+    arbitrary grid is evaluated within 2^-25 of its coordinate.  Differentiable w.r.t. ``input`` only (the reference's
+    points do not require grad)."""
+    if mode != "bilinear" or padding_mode != "border" or not align_corners:
+        raise NotImplementedError("grid_sample: only mode='bilinear', padding_mode='border', align_corners=True (the "
+                                  "reference's call, alto.py:95) is built")
+    if grid.dim() != 4 or grid.shape[2] != 1 or grid.shape[3] != 2:
+        raise NotImplementedError("grid_sample: the grid must be [B, N, 1, 2] (one sampling location per point)")
+    if grid.requires_grad:
+        raise NotImplementedError("grid_sample: no gradient w.r.t. the grid is built (the reference's points are data)")
+    xy = ((grid[:, :, 0, :].double() + 1.0) * 0.5).float()
+    return _GridSamplePoints.apply(input, xy).unsqueeze(-1)
+
+
+def interpolate(input: torch.Tensor, size=None, scale_factor=None, mode: str = "bilinear",
+                align_corners: bool = True) -> torch.Tensor:
+    """``F.interpolate(x, size=S, mode='bilinear', align_corners=True)`` with the reference's signature (pixel.py:107)."""
+    if mode != "bilinear" or not align_corners or scale_factor is not None or size is None:
+        raise NotImplementedError("interpolate: only size=S, mode='bilinear', align_corners=True (pixel.py:107) is built")
+    if isinstance(size, (tuple, list)):
+        if len(size) != 2 or size[0] != size[1]:
+            raise NotImplementedError("interpolate: square outputs only")
+        size = size[0]
+    return upsample_bilinear(input, int(size))

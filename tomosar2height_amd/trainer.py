@@ -108,6 +108,7 @@ class Trainer:
         self._pipe_graphs = None        # capture_pipeline_graphs: forward / backward hipGraphs of the two tile streams
         self._bwd_done = None           # event: end of the last issued backward (the next one accumulates into the same buffers)
         self._tile_parity = 0
+        self._held = []                 # (event at the end of a tile's backward, that tile's ``data``): see _hold_inputs
 
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
         # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
@@ -294,7 +295,10 @@ class Trainer:
         """One tile -- or a LIST of tiles of the same accumulation window as one micro-batch (``_losses_micro_batch``: same
         accumulated gradient as feeding them one by one, to fp32 re-association) --: forward, loss, backward.  Returns True
         when this call ended with an optimizer step."""
-        if not self.model.training:                           # (Module.train() walks every submodule: 0.4 ms per call here)
+        # trainer.py:59 calls model.train() every step.  Module.train() walks every submodule (0.4 ms per call here), so the
+        # root flag is looked at per tile and the whole tree once per accumulation window: a caller that put a SUBMODULE into
+        # eval mode while the root stayed in training mode is brought back at the next window, like the reference does
+        if not self.model.training or (self.accumulated_steps == 0 and self._any_submodule_in_eval()):
             self.model.train()
         n_tiles = len(data) if isinstance(data, (list, tuple)) else 1
         if n_tiles > 1 and (self.accumulated_steps + n_tiles > self.local_every):
@@ -333,6 +337,12 @@ class Trainer:
 
         self.optimizer_boundary()
         return True
+
+    def _any_submodule_in_eval(self) -> bool:
+        mods = getattr(self, "_modules_flat", None)
+        if mods is None:
+            mods = self._modules_flat = list(self.model.modules())
+        return any(not m.training for m in mods)
 
     def _backward(self, loss):
         """``loss.backward()`` of one tile (or micro-batch) with the weight gradients on the side streams."""
@@ -392,7 +402,7 @@ class Trainer:
                     loss_l1, loss_ce = self._losses(data, 0.0001)
                 loss = loss_l1 + loss_ce
         self._issue_pending_backward()
-        self._pending = (loss, loss_l1, loss_ce, st, self._weights_version(), gset)
+        self._pending = (loss, loss_l1, loss_ce, st, self._weights_version(), gset, data)
         self.accumulated_steps += 1
         if self.accumulated_steps < self.local_every:
             return False
@@ -402,7 +412,7 @@ class Trainer:
     def _issue_pending_backward(self):
         if self._pending is None:
             return
-        loss, loss_l1, loss_ce, st, version, gset = self._pending
+        loss, loss_l1, loss_ce, st, version, gset, data = self._pending
         self._pending = None
         if version != self._weights_version():
             self._reset_accumulators()
@@ -422,6 +432,20 @@ class Trainer:
             self.accumulated_loss_dict["loss_ce"] += loss_ce.detach()
             self.accumulated_loss_dict["loss_l1"] += loss_l1.detach()
             self._bwd_done = st.record_event(torch.cuda.Event(enable_timing=True))
+        self._hold_inputs(self._bwd_done, data)
+
+    def _hold_inputs(self, done, data):
+        """The caller's tensors of a pipelined tile -- cloud or prebuilt TileIndex, target, image -- were allocated on the
+        CALLER's stream (or a producer's), but are read by the tile's stream and the weight-gradient side streams until the
+        end of its backward, one ``train_step`` call after the caller may have dropped them.  The caching allocator would hand
+        such a block back to its own stream at once (that stream has no pending use of it) and the next tile's producer would
+        overwrite it under the queued kernels.  So the trainer keeps ``data`` referenced until the event at the end of that
+        tile's backward -- recorded after the side streams have joined -- HAS COMPLETED (host-side query: valid for whatever
+        stream owns the allocation).  A few tiles' inputs (MBs) at most."""
+        held = self._held
+        while held and held[0][0].query():
+            held.pop(0)
+        held.append((done, data))
 
     def _weights_version(self) -> int:
         """Version counter of one trained parameter (every optimizer, FlatAdamW included, bumps all of them together)."""
@@ -508,6 +532,9 @@ class Trainer:
         self._reset_accumulators()
 
     def _reset_accumulators(self):
+        if self._pending is not None:                      # (error path: a forward whose backward will never be issued)
+            st, data = self._pending[3], self._pending[6]
+            self._hold_inputs(st.record_event(torch.cuda.Event()), data)
         self._pending = None
         if self._tile_streams is not None:                 # (nothing of the tile pipeline may still be accumulating)
             cur = torch.cuda.current_stream()
