@@ -192,6 +192,16 @@ int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim,
 int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                               int level, int sum_level, int C, float *sums_nhwc, int ld_sums, float *pooled_nhwc, int ld_pooled,
                               void *sign_bits, t2h_stream_t stream);
+/* ... with a dispatch order: `cell_order` (may be NULL) from t2h_cell_order_build for the same tile and level -- the level's
+ * cells, then its 2 x 2 blocks of cells, each list by FALLING row count ([cells + cells / 4] int32, t2h_cell_order_len).  The
+ * on-chip walks give each cell (or block) its own workgroup whose duration grows with the cell's rows; started longest-first the
+ * dense cells no longer decide how long the chip idles at the end of the launch.  Scheduling only: results are bit-identical
+ * with and without an order.  (No reference counterpart: torch_scatter / grid_sample have no such structure to balance.) */
+size_t t2h_cell_order_len(int B, int nbits, int level);
+int t2h_cell_order_build(const int32_t *off0, int B, int nbits, int level, int32_t *order, t2h_stream_t stream);
+int t2h_sample_relu_cellsums_ordered(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
+                                     int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums, float *pooled_nhwc,
+                                     int ld_pooled, void *sign_bits, const int32_t *cell_order, t2h_stream_t stream);
 /* t2h_segsum_bwd_multi folded into the sample adjoint's per-cell partial kernel: gplane [B, r, r, C] =
  * S^T ( (mask > 0) * sum_q gplanes_q[cell_q(.)] ) without the [N, C] hidden gradient ever being written.  Only where the level
  * takes the per-cell partials (t2h_sample_bwd_workspace_bytes > 0); same workspace.  `mask`: the hidden activations [N, C]
@@ -203,6 +213,12 @@ int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int *levels
                              const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim, const int32_t *off0, int B, int N,
                              int nbits, int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                              t2h_stream_t stream);
+/* ... with the dispatch order of t2h_cell_order_build (`cell_order`, may be NULL; used by the row-walk form): see
+ * t2h_sample_relu_cellsums_ordered.  Bit-identical results with and without. */
+int t2h_sample_bwd_from_sums_ordered(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
+                                     const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim,
+                                     const int32_t *off0, int B, int N, int nbits, int level, int C, float *gplane_nhwc,
+                                     void *workspace, size_t workspace_bytes, const int32_t *cell_order, t2h_stream_t stream);
 /* The same with `addend` [B*N, C] (may be NULL) added to the result: the point features of a level feed both the
  * rasterisation and the next level's fc_c (alto.py:123-130), so their gradient is a sum of two -- formed here instead of
  * by an extra elementwise pass (gfeat may alias addend). */

@@ -237,3 +237,61 @@ def test_on_chip_hidden_activations_equal_the_two_kernel_form(c, r, sum_level, d
     else:                                         # ... unless it takes the per-(cell, split) partials there: same sums, re-associated
         assert torch.equal(got[:, :off], want[:, :off]) and torch.equal(got[:, off + c:], want[:, off + c:])
         assert ((got - want).abs().max() / want.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.parametrize("c,r,sum_level,batch", [(1024, 32, 0, 1), (512, 64, 0, 1), (256, 128, 0, 1), (256, 64, 1, 2), (256, 128, 1, 2)])
+def test_cell_order_is_longest_first_and_changes_no_bit(c, r, sum_level, batch):
+    """t2h_cell_order_build: the level's cells, then its 2 x 2 blocks of cells, each a permutation by FALLING row count; the
+    on-chip walks launched with it (dense cells' workgroups first) give the bits of the launch without it -- forward (per-cell
+    sums, pooled sums, sign words), backward (dQ) -- and both forms of the r05 forward (a cell shared by four waves / a
+    2 x 2 block of cells per workgroup) give the bits of the r04 kernel."""
+    import os
+    from tomosar2height_amd import _lib, deferred
+    tile = _tile(n=150000 if r == 128 else 90000, batch=batch)
+    lv = tile.level(r)
+    cells = tile.B * r * r
+    order = tile.cell_order(lv)
+    assert order.numel() == _lib.load().t2h_cell_order_len(tile.B, tile.nbits, lv) == cells + cells // 4
+    for lst, shift in ((order[:cells], lv), (order[cells:], lv + 1)):
+        n = lst.numel()
+        assert torch.equal(lst.sort().values, torch.arange(n, device=_dev(), dtype=torch.int32))
+        bounds = tile.off0[::4 ** shift]
+        rows = (bounds[1:] - bounds[:-1])[lst.long()]
+        quantum = max(1, (tile.n_points // n + 63) // 64)         # the sort's key: rows / quantum, capped at 2047
+        key = (rows // quantum).clamp(max=2047)
+        assert bool((key[1:] <= key[:-1]).all()) and int(rows.sum()) == tile.n_points
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(tile.B, r, r, c, generator=g).to(_dev())
+    rs = 256 >> sum_level
+
+    def forward(order_arg, variant):
+        os.environ["T2H_CELLSUMS_V2"] = variant
+        try:
+            sums = torch.full((tile.B * rs * rs, c), 3.0, device=_dev())
+            pooled = torch.full((tile.B * (rs // 2) ** 2, c), 5.0, device=_dev())
+            bits = torch.zeros(tile.n_points * (c // 256) * 4, dtype=torch.int64, device=_dev())
+            _lib.call("t2h_sample_relu_cellsums_ordered", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+                      tile.N, tile.nbits, lv, sum_level, c, _lib.ptr(sums), c, _lib.ptr(pooled) if sum_level < lv else None, c,
+                      _lib.ptr(bits), None if order_arg is None else _lib.ptr(order_arg), _lib.stream())
+            return sums, pooled, bits
+        finally:
+            os.environ.pop("T2H_CELLSUMS_V2", None)
+
+    ref = forward(None, "0")                                     # the r04 kernel (one wave per chunk, its own neighbourhood)
+    for variant in ("1", "2"):                                   # r05: shared by four waves / 2 x 2 blocks of cells
+        for o in (None, order):
+            got = forward(o, variant)
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), (variant, o is not None)
+    planes = [(torch.randn(tile.B * (256 >> l) ** 2, c, generator=g).to(_dev()), l) for l in range(lv + 1)]
+    arr, lvs, lds = deferred._plane_args(planes)
+    ws_bytes = _lib.load().t2h_sample_bwd_workspace_bytes(tile.B, tile.N, tile.nbits, lv, c)
+    assert ws_bytes > 0
+    ws = _lib.workspace(ws_bytes, _dev())
+    outs = []
+    for o in (None, order, order):
+        dq = torch.full((tile.B * r * r, c), float("nan"), device=_dev())
+        _lib.call("t2h_sample_bwd_from_sums_ordered", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(ref[2]), 1,
+                  _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, lv, c, _lib.ptr(dq), _lib.ptr(ws),
+                  ws_bytes, None if o is None else _lib.ptr(o), _lib.stream())
+        outs.append(dq)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]) and bool(torch.isfinite(outs[0]).all())

@@ -739,6 +739,163 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
     }
 }
 
+// ---- r05: the same pass with the neighbourhood SHARED by the workgroup's four waves ----------------------------------------
+// sample_relu_cellsums_kernel gives every wave its own 9 KB neighbourhood (one wave per 256-channel chunk): 36 KB of LDS per
+// workgroup = 4 waves per SIMD, a 9 KB L2 -> LDS round trip in front of every wave's ~16 rows, ~75 vector instructions per row
+// (the compiler pairs (v00.x nw, v01.x ne) for its packed multiplies and shuffles registers to do so).  Here a workgroup is
+//   K = 0: ONE sampling cell x ONE 256-channel chunk: the 3 x 3 neighbourhood staged once (9 KB), each wave a quarter of the
+//          workgroup's children (blockIdx.z splits them further);
+//   K = 1: a 2 x 2 BLOCK of sampling cells, one per wave, sharing its 4 x 4 neighbourhood (16 KB) -- levels with few rows
+//          per cell, where a cell has too few children to share out (r = 128: 4 children, 8 rows);
+// so 8 workgroups = 32 waves fit a CU (<= 64 VGPRs) and the staging traffic drops 4x / 2.25x.  Per row: the channel pairs
+// (x, y), (z, w) go through v_pk_mul_f32 / v_pk_add_f32 with the tap weight broadcast from an SGPR -- the SAME products and
+// the same order of additions per element as sample_fwd_kernel (bit-identical), in 24 instead of ~55 vector instructions -- and
+// the four ballots of a row are parked in lane (row mod 64) of eight registers (v_writelane) and leave as one coalesced 2 KB
+// store per 64 rows instead of two lane-0 stores per row.  The next 64 rows' coordinates are requested while the current 64 run.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// lane `i` (wave-uniform) of the eight registers = the four wave-uniform 64-bit words; the other lanes keep their values.
+// (gfx9 encodings read one SGPR per vector instruction: the lane select goes through M0)
+__device__ inline void park8(unsigned (&acc)[8], unsigned long long w0, unsigned long long w1, unsigned long long w2,
+                             unsigned long long w3, int i) {
+    asm("s_mov_b32 m0, %8\n\t"
+        "v_writelane_b32 %0, %9, m0\n\tv_writelane_b32 %1, %10, m0\n\tv_writelane_b32 %2, %11, m0\n\tv_writelane_b32 %3, %12, m0\n\t"
+        "v_writelane_b32 %4, %13, m0\n\tv_writelane_b32 %5, %14, m0\n\tv_writelane_b32 %6, %15, m0\n\tv_writelane_b32 %7, %16, m0"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "s"(__builtin_amdgcn_readfirstlane(i)), "s"((unsigned)w0), "s"((unsigned)(w0 >> 32)), "s"((unsigned)w1),
+          "s"((unsigned)(w1 >> 32)), "s"((unsigned)w2), "s"((unsigned)(w2 >> 32)), "s"((unsigned)w3), "s"((unsigned)(w3 >> 32))
+        : "m0");
+}
+
+template <int K, bool POOL>
+__global__ __launch_bounds__(256, 2) void sample_relu_cellsums_v2_kernel(const float *__restrict__ plane,
+                                                                        const float *__restrict__ pts, int dim,
+                                                                        const int32_t *__restrict__ off0, int nbits, int level,
+                                                                        int sum_level, int C, float *__restrict__ sums,
+                                                                        int ld_sums, unsigned long long *__restrict__ bits,
+                                                                        int npts_m1, float *__restrict__ sums2, int ld_sums2,
+                                                                        const int32_t *__restrict__ order, int gz) {
+    constexpr int SIDE = 3 + K, NS = SIDE * SIDE;
+    __shared__ float4 T[NS][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid, the cell slowest: blockIdx.x = (cell rank * gz + z) * chunks + chunk -- workgroups start in blockIdx order, so
+    // all parts of a cell start together and the cells in the order of their rank
+    const int chunks = C >> 8;
+    const int chunk = (int)(blockIdx.x % (unsigned)chunks), c0 = chunk * 256 + lane * 4;
+    const int zpart = (int)((blockIdx.x / (unsigned)chunks) % (unsigned)gz);
+    const unsigned rank = blockIdx.x / (unsigned)(chunks * gz);
+    const int rbits = nbits - level, r = 1 << rbits, sbits = rbits - K;
+    // Morton index (batch-major) of the cell at level + K; `order`: the cells by falling row count (t2h_cell_order_build), so
+    // that the dispatcher starts the dense cells first and the light ones fill the gaps (longest-first scheduling)
+    const int64_t wg = order ? (int64_t)order[rank] : (int64_t)rank;
+    const int b = (int)(wg >> (2 * sbits));
+    const uint32_t smk = (uint32_t)(wg & (((int64_t)1 << (2 * sbits)) - 1));
+    const int d = level - sum_level, nchild = 1 << (2 * d), rs = 1 << (nbits - sum_level);
+    const uint32_t mk = K == 0 ? smk : ((smk << 2) | (uint32_t)wave);   // this wave's sampling cell
+    const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
+    const int per_wave = K == 0 ? nchild / (gz * 4) : nchild;
+    const int child_lo = K == 0 ? (zpart * 4 + wave) * per_wave : 0, child_hi = child_lo + per_wave;
+    const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
+    // the first 64 child boundaries and the rows' coordinates are on the wave's critical path: requested BEFORE the staging loads
+    int bnd_lo, bnd_hi;
+    {
+        const int ci = child_lo + lane;
+        bnd_lo = ci <= child_hi ? off0[obase + ((size_t)ci << (2 * sum_level))] : 0;
+        bnd_hi = ci + 1 <= child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
+    }
+    const int wx0 = K == 0 ? cx - 1 : 2 * (int)compact1by1(smk) - 1, wy0 = K == 0 ? cy - 1 : 2 * (int)compact1by1(smk >> 1) - 1;
+    for (int e = tid; e < NS * 64; e += 256) {
+        const int sl = e >> 6, py = wy0 + sl / SIDE, px = wx0 + sl % SIDE;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)py < (unsigned)r && (unsigned)px < (unsigned)r)
+            v = *reinterpret_cast<const float4 *>(plane + (((size_t)b * r + py) * r + px) * C + chunk * 256 + (e & 63) * 4);
+        T[sl][e & 63] = v;
+    }
+    const int row_first = __builtin_amdgcn_readfirstlane(bnd_lo);       // this wave's rows: [row_first, row_end), contiguous
+    const int row_end = off0[obase + ((size_t)child_hi << (2 * sum_level))];
+    float2 pxy = *reinterpret_cast<const float2 *>(pts + (size_t)min(row_first + lane, npts_m1) * dim);
+    __syncthreads();
+    const float4 *Tl = &T[0][lane];
+
+    int nb0 = __builtin_amdgcn_readfirstlane(row_first - 64), slot_l = 0;  // taps of rows nb0 .. nb0 + 63, lane-parallel
+    float nw_l = 0.f, ne_l = 0.f, sw_l = 0.f, se_l = 0.f;
+    unsigned bl[8] = {0, 0, 0, 0, 0, 0, 0, 0};                           // the ballots of row nb0 + lane
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f), p01 = pe;              // pooled-output state of the current quad of children
+    auto flush_bits = [&]() {
+        if (bits && nb0 >= row_first && nb0 + lane < row_end) {
+            uint4 *dst = reinterpret_cast<uint4 *>(bits + ((size_t)chunk * ((size_t)npts_m1 + 1) + (size_t)(nb0 + lane)) * 4);
+            dst[0] = make_uint4(bl[0], bl[1], bl[2], bl[3]);
+            dst[1] = make_uint4(bl[4], bl[5], bl[6], bl[7]);
+        }
+    };
+    for (int cb = child_lo; cb < child_hi; cb += 64) {                  // children in batches of 64: their row boundaries
+        if (cb != child_lo) {
+            const int ci = cb + lane;
+            bnd_lo = ci <= child_hi ? off0[obase + ((size_t)ci << (2 * sum_level))] : 0;
+            bnd_hi = ci + 1 <= child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * sum_level))] : 0;
+        }
+        const int nc = min(64, child_hi - cb);
+        for (int c = 0; c < nc; ++c) {
+            const int s = __builtin_amdgcn_readlane(bnd_lo, c), e = __builtin_amdgcn_readlane(bnd_hi, c);
+            f32x2 sum01 = {0.f, 0.f}, sum23 = {0.f, 0.f};
+            int n = s;
+            while (n < e) {
+                if (n >= nb0 + 64) {
+                    flush_bits();
+                    nb0 = __builtin_amdgcn_readfirstlane(nb0 + 64);
+                    const Taps tp = make_taps(pxy.x, pxy.y, r);
+                    if (nb0 + 64 < row_end)                               // the next 64 rows' coordinates, under this batch's rows
+                        pxy = *reinterpret_cast<const float2 *>(pts + (size_t)min(nb0 + 64 + lane, npts_m1) * dim);
+                    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                    nw_l = __fmul_rn(tp.wx0, tp.wy0);
+                    ne_l = x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.f;
+                    sw_l = y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.f;
+                    se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
+                    // slot of the north-west tap in the staged window (a tap outside the plane has weight 0 and reads the
+                    // staged zero -- the sample kernel skips it: the same value)
+                    slot_l = (min(max(tp.y0 - cy + 1, 0), 1) + (K ? (wave >> 1) : 0)) * SIDE +
+                             min(max(tp.x0 - cx + 1, 0), 1) + (K ? (wave & 1) : 0);
+                }
+                const int i0 = n - nb0, cnt = min(e - n, 64 - i0);        // rows of this child inside the current batch
+                auto row = [&](int i) {
+                    const float nw = readlane_f(nw_l, i), ne = readlane_f(ne_l, i), sw = readlane_f(sw_l, i), se = readlane_f(se_l, i);
+                    const float4 *t00 = Tl + __builtin_amdgcn_readlane(slot_l, i) * 64;
+                    const float4 v00 = t00[0], v01 = t00[64], v10 = t00[SIDE * 64], v11 = t00[(SIDE + 1) * 64];
+                    f32x2 a01 = f32x2{v00.x, v00.y} * nw, a23 = f32x2{v00.z, v00.w} * nw;
+                    a01 = a01 + f32x2{v01.x, v01.y} * ne; a23 = a23 + f32x2{v01.z, v01.w} * ne;
+                    a01 = a01 + f32x2{v10.x, v10.y} * sw; a23 = a23 + f32x2{v10.z, v10.w} * sw;
+                    a01 = a01 + f32x2{v11.x, v11.y} * se; a23 = a23 + f32x2{v11.z, v11.w} * se;
+                    a01.x = fmaxf(a01.x, 0.f); a01.y = fmaxf(a01.y, 0.f); a23.x = fmaxf(a23.x, 0.f); a23.y = fmaxf(a23.y, 0.f);
+                    const unsigned long long w0 = __ballot(a01.x > 0.f), w1 = __ballot(a01.y > 0.f);
+                    const unsigned long long w2 = __ballot(a23.x > 0.f), w3 = __ballot(a23.y > 0.f);
+                    park8(bl, w0, w1, w2, w3, i);
+                    sum01 = sum01 + a01; sum23 = sum23 + a23;             // summed in row order
+                };
+                for (int j = 0; j < cnt; ++j) row(i0 + j);
+                n += cnt;
+            }
+            const float4 sum = make_float4(sum01.x, sum01.y, sum23.x, sum23.y);
+            const uint32_t cm = (uint32_t)(cb + c);                      // child's Morton code inside the cell
+            const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
+            *reinterpret_cast<float4 *>(sums + (((size_t)b * rs + fy) * rs + fx) * ld_sums + c0) = sum;
+            if (POOL) {
+                // the 2 x 2 pooled sums one level up, formed from the four children while they are in registers (children are
+                // visited in Morton order = the order (c0 + c1) + (c2 + c3) of plane_sumpool2x2_kernel: same bits)
+                const unsigned k4 = cm & 3u;
+                if (k4 == 0u) pe = sum;
+                else if (k4 == 1u) p01 = make_float4(pe.x + sum.x, pe.y + sum.y, pe.z + sum.z, pe.w + sum.w);
+                else if (k4 == 2u) pe = sum;
+                else {
+                    const float4 o = make_float4(p01.x + (pe.x + sum.x), p01.y + (pe.y + sum.y), p01.z + (pe.z + sum.z),
+                                                 p01.w + (pe.w + sum.w));
+                    const int rs2 = rs >> 1;
+                    *reinterpret_cast<float4 *>(sums2 + (((size_t)b * rs2 + (fy >> 1)) * rs2 + (fx >> 1)) * ld_sums2 + c0) = o;
+                }
+            }
+        }
+    }
+    flush_bits();
+}
+
 // Deterministic backward: one group per pixel; a point of cell (cx,cy) only touches pixels
 // {cx-1..cx+1} x {cy-1..cy+1} (px = x*(r-1) lies in (cx-1, cx+1)), so pixel (px,py) gathers from the
 // 3x3 cells around it.  Cells are visited row-major, points in sorted order: a fixed summation order.
@@ -1394,13 +1551,18 @@ template <int K>
 __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__restrict__ pts, int dim,
                                                             const int32_t *__restrict__ off0, int nbits, int level, int wl,
                                                             int C, float *__restrict__ partial, MultiPlanes mp,
-                                                            const unsigned long long *__restrict__ bits, int npts_m1) {
+                                                            const unsigned long long *__restrict__ bits, int npts_m1,
+                                                            const int32_t *__restrict__ order) {
     constexpr int SIDE = 3 + K, NS = SIDE * SIDE;
-    __shared__ float4 NB[NS][64];
+    __shared__ float4 NB[4 * 9][64];                                   // [wave][3 x 3 slot]: 36 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.y, c0 = chunk * 256 + lane * 4, cpc = C >> 8;
+    // 1-D grid, the cell slowest (blockIdx.x = rank * chunks + chunk): the chunks of a cell start together, the cells in the
+    // order of their rank -- `order` (t2h_cell_order_build): by falling row count, longest first
+    const int cpc = C >> 8;
+    const int chunk = (int)(blockIdx.x % (unsigned)cpc), c0 = chunk * 256 + lane * 4;
+    const unsigned rank = blockIdx.x / (unsigned)cpc;
     const int rbits = nbits - level, r = 1 << rbits, sbits = rbits - K;
-    const int64_t wg = blockIdx.x;                                    // Morton index (batch-major) of the cell at level + K
+    const int64_t wg = order ? (int64_t)order[rank] : (int64_t)rank;  // Morton index (batch-major) of the cell at level + K
     const int b = (int)(wg >> (2 * sbits));
     const uint32_t smk = (uint32_t)(wg & (((int64_t)1 << (2 * sbits)) - 1));
     const int d = level - wl, nchild = 1 << (2 * d);
@@ -1408,25 +1570,33 @@ __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__res
     const int child_lo = K == 0 ? wave * (nchild >> 2) : 0, child_hi = K == 0 ? child_lo + (nchild >> 2) : nchild;
     const int cx = (int)compact1by1(mk), cy = (int)compact1by1(mk >> 1);
     const size_t obase = ((size_t)b << (2 * nbits)) + ((size_t)mk << (2 * level));
-    for (int e = tid; e < NS * 64; e += 256) NB[e >> 6][e & 63] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    float4 acc[9];
+    f32x2 acc[9][2];                             // (x, y) and (z, w) halves: v_pk_fma_f32 with the slot weight broadcast
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 9; ++q) { acc[q][0] = f32x2{0.f, 0.f}; acc[q][1] = f32x2{0.f, 0.f}; }
     // the plane rows of a child, requested (raw) ahead of their use; a coarser plane's row is shared by 4, 16, .. consecutive
-    // children and requested only when it changes
+    // children and requested only when it changes.  Which row a child reads in each plane is computed for 64 children at once
+    // (lane = child) and handed to the child loop by readlane: scalar compares and branches per child instead of ~30 vector
+    // instructions of Morton arithmetic
     float4 raw[kWalkPlanes];
     int held[kWalkPlanes];
+    int prow_l[kWalkPlanes];
 #pragma unroll
-    for (int q = 0; q < kWalkPlanes; ++q) held[q] = -1;
-    auto request = [&](int child) {
+    for (int q = 0; q < kWalkPlanes; ++q) { held[q] = -1; prow_l[q] = 0; raw[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    auto plane_rows = [&](int child) {                                  // lane-parallel: the rows of child `child` (this lane's)
         const uint32_t cm = (uint32_t)child;
         const int fx = (cx << d) + (int)compact1by1(cm), fy = (cy << d) + (int)compact1by1(cm >> 1);
 #pragma unroll
         for (int q = 0; q < kWalkPlanes; ++q)
             if (q < mp.n) {
                 const int sh = mp.level[q] - wl, rq = 1 << (nbits - mp.level[q]);
-                const int row = (b * rq + (fy >> sh)) * rq + (fx >> sh);
+                prow_l[q] = (b * rq + (fy >> sh)) * rq + (fx >> sh);
+            }
+    };
+    auto request = [&](int c) {                                         // c: the child's lane in the current batch (uniform)
+#pragma unroll
+        for (int q = 0; q < kWalkPlanes; ++q)
+            if (q < mp.n) {
+                const int row = __builtin_amdgcn_readlane(prow_l[q], c);
                 if (row != held[q]) {
                     held[q] = row;
                     raw[q] = *reinterpret_cast<const float4 *>(mp.g[q] + (size_t)row * mp.ld[q] + c0);
@@ -1434,9 +1604,13 @@ __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__res
             }
     };
     int nb0 = 0;
-    float w9_l[9];                               // lane i: the nine slot weights of row nb0 + i (five of them 0)
-#pragma unroll
-    for (int q = 0; q < 9; ++q) w9_l[q] = 0.f;
+    // lane i: the four tap weights of row nb0 + i; cm[k]: the rows of the batch whose north-west tap sits at position k = 2 dy + dx
+    // of the cell's 3 x 3 neighbourhood.  A row's four products go to four accumulators that depend on k only, so the rows of a
+    // child are taken class by class -- four straight-line loops over lane masks, 8 packed FMAs and 4 v_readlane per row -- where
+    // r04 multiplied all nine accumulators by nine weights, five of them zero (18 packed FMAs, 9 v_readlane).  Per accumulator
+    // the rows still arrive child by child in a fixed order: deterministic; the order inside a child is (class, row).
+    float nw_l = 0.f, ne_l = 0.f, sw_l = 0.f, se_l = 0.f;
+    unsigned long long cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
     unsigned long long w0_l = 0, w1_l = 0, w2_l = 0, w3_l = 0;
     bool have = false;
     for (int cb = child_lo; cb < child_hi; cb += 64) {
@@ -1444,7 +1618,8 @@ __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__res
         const int bnd_lo = ci < child_hi ? off0[obase + ((size_t)ci << (2 * wl))] : 0;
         const int bnd_hi = ci < child_hi ? off0[obase + ((size_t)(ci + 1) << (2 * wl))] : 0;
         unsigned long long todo = __ballot(bnd_hi > bnd_lo);             // the non-empty children of this batch
-        if (todo) request(cb + (int)__builtin_ctzll(todo));
+        plane_rows(ci);
+        if (todo) request((int)__builtin_ctzll(todo));
         while (todo) {
             const int c = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
@@ -1453,59 +1628,62 @@ __global__ __launch_bounds__(256) void sample_bwd_walk_kernel(const float *__res
 #pragma unroll
             for (int q = 1; q < kWalkPlanes; ++q)
                 if (q < mp.n) { G.x = __fadd_rn(G.x, raw[q].x); G.y = __fadd_rn(G.y, raw[q].y); G.z = __fadd_rn(G.z, raw[q].z); G.w = __fadd_rn(G.w, raw[q].w); }
-            if (todo) request(cb + (int)__builtin_ctzll(todo));          // the next child's rows, under this child's work
+            if (todo) request((int)__builtin_ctzll(todo));               // the next child's rows, under this child's work
             int n = s;
             while (n < e) {
                 if (!have || n >= nb0 + 64) {
                     nb0 = n; have = true;
                     const int nn = min(n + lane, npts_m1);
                     const Taps tp = make_taps(pts[(size_t)nn * dim + 0], pts[(size_t)nn * dim + 1], r);
-                    const int dx = tp.x0 - cx + 1, dy = tp.y0 - cy + 1;        // slot column / row of the north-west tap: 0 or 1
-#pragma unroll
-                    for (int sy = 0; sy < 3; ++sy) {
-                        const float wy = (sy == dy) ? tp.wy0 : ((sy == dy + 1) ? tp.wy1 : 0.0f);
-#pragma unroll
-                        for (int sx = 0; sx < 3; ++sx) {
-                            const float wx = (sx == dx) ? tp.wx0 : ((sx == dx + 1) ? tp.wx1 : 0.0f);
-                            w9_l[sy * 3 + sx] = __fmul_rn(wx, wy);
-                        }
-                    }
+                    nw_l = __fmul_rn(tp.wx0, tp.wy0); ne_l = __fmul_rn(tp.wx1, tp.wy0);
+                    sw_l = __fmul_rn(tp.wx0, tp.wy1); se_l = __fmul_rn(tp.wx1, tp.wy1);
+                    const int cls = min(max(tp.y0 - cy + 1, 0), 1) * 2 + min(max(tp.x0 - cx + 1, 0), 1);
+                    cm0 = __ballot(cls == 0); cm1 = __ballot(cls == 1); cm2 = __ballot(cls == 2); cm3 = __ballot(cls == 3);
                     const ulonglong2 *bw = reinterpret_cast<const ulonglong2 *>(bits + ((size_t)chunk * ((size_t)npts_m1 + 1) + nn) * 4);
                     const ulonglong2 b01 = bw[0], b23 = bw[1];
                     w0_l = b01.x; w1_l = b01.y; w2_l = b23.x; w3_l = b23.y;
                 }
                 const int i0 = n - nb0, cnt = min(e - n, 64 - i0);
-                for (int j = 0; j < cnt; ++j) {
-                    const int i = i0 + j;
-                    float4 g;
-                    g.x = keep_if(readlane_u64(w0_l, i), G.x); g.y = keep_if(readlane_u64(w1_l, i), G.y);
-                    g.z = keep_if(readlane_u64(w2_l, i), G.z); g.w = keep_if(readlane_u64(w3_l, i), G.w);
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) fma4(acc[q], readlane_f(w9_l[q], i), g);
+                const unsigned long long range = (cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull)) << i0;
+#define T2H_TAP(Q, W) acc[Q][0] = __builtin_elementwise_fma(f32x2{W, W}, g01, acc[Q][0]); \
+                      acc[Q][1] = __builtin_elementwise_fma(f32x2{W, W}, g23, acc[Q][1])
+#define T2H_CLASS(MASK, QA, QB, QC, QD)                                                                                      \
+                for (unsigned long long mk = (MASK) & range; mk; mk &= mk - 1) {                                               \
+                    const int i = (int)__builtin_ctzll(mk);                                                                    \
+                    const f32x2 g01 = {keep_if(readlane_u64(w0_l, i), G.x), keep_if(readlane_u64(w1_l, i), G.y)};               \
+                    const f32x2 g23 = {keep_if(readlane_u64(w2_l, i), G.z), keep_if(readlane_u64(w3_l, i), G.w)};               \
+                    const float nw = readlane_f(nw_l, i), ne = readlane_f(ne_l, i), sw = readlane_f(sw_l, i), se = readlane_f(se_l, i); \
+                    T2H_TAP(QA, nw); T2H_TAP(QB, ne); T2H_TAP(QC, sw); T2H_TAP(QD, se);                                           \
                 }
+                T2H_CLASS(cm0, 0, 1, 3, 4)
+                T2H_CLASS(cm1, 1, 2, 4, 5)
+                T2H_CLASS(cm2, 3, 4, 6, 7)
+                T2H_CLASS(cm3, 4, 5, 7, 8)
+#undef T2H_CLASS
+#undef T2H_TAP
                 n += cnt;
             }
         }
     }
-    // the four waves add their neighbourhoods in wave order
-    const int qx = K ? (wave & 1) : 0, qy = K ? (wave >> 1) : 0;
-#pragma unroll 1
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wave == w) {
+    // every wave leaves its 3 x 3 neighbourhood in its own LDS slab; after ONE barrier the workgroup adds the four slabs per
+    // element in wave order, starting from 0 -- the sums (and bits) of the r04 kernel, whose waves took turns behind a barrier each
 #pragma unroll
-            for (int sl = 0; sl < 9; ++sl) {
-                float4 &t = NB[(sl / 3 + qy) * SIDE + sl % 3 + qx][lane];
-                float4 v = t;
-                v.x += acc[sl].x; v.y += acc[sl].y; v.z += acc[sl].z; v.w += acc[sl].w;
-                t = v;
-            }
-        }
-    }
+    for (int sl = 0; sl < 9; ++sl) NB[wave * 9 + sl][lane] = make_float4(acc[sl][0].x, acc[sl][0].y, acc[sl][1].x, acc[sl][1].y);
     __syncthreads();
     float *pbase = partial + (size_t)wg * NS * C + chunk * 256;
-    for (int e = tid; e < NS * 64; e += 256)
-        *reinterpret_cast<float4 *>(pbase + (size_t)(e >> 6) * C + (e & 63) * 4) = NB[e >> 6][e & 63];
+    for (int e = tid; e < NS * 64; e += 256) {
+        const int ws = e >> 6, l = e & 63, wy = ws / SIDE, wx = ws % SIDE;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int ly = wy - (K ? (w >> 1) : 0), lx = wx - (K ? (w & 1) : 0);
+            if ((unsigned)ly < 3u && (unsigned)lx < 3u) {
+                const float4 u = NB[w * 9 + ly * 3 + lx][l];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(pbase + (size_t)ws * C + l * 4) = v;
+    }
 }
 
 // stage 2 for K = 1: pixel (px, py) takes its slot from the (up to) four 2 x 2 cell blocks whose 4 x 4 windows hold it
@@ -1600,6 +1778,51 @@ using namespace t2h;
     do {                                  \
         if ((C) % 4 == 0) { CALL4; } else { CALL1; } \
     } while (0)
+
+// ---- longest-first dispatch order of a level's cells (t2h_cell_order_build) -------------------------------------------------
+// The on-chip walks give every sampling cell (or 2 x 2 block of cells) its own workgroup, whose duration grows with the cell's
+// row count; workgroups start in blockIdx order, so where a dense cluster sits in the Morton order decides how long the chip
+// idles at the end of the launch (Berlin-shaped tile, r = 32: 128 rows per cell on average, 951 in the densest -- 40 of 147 us).
+// A counting sort of the cells by falling row count (keys: rows / quantum, capped at kOrderKeys - 1; ONE workgroup per list:
+// LDS histogram, scan, scatter) lets the dispatcher start the dense cells first.  Which cell a workgroup takes never changes a result bit:
+// every output element is still written by exactly one wave, with the same operations in the same order.  (Cells of equal
+// count land in the order their atomics arrive: scheduling only.)
+constexpr int kOrderKeys = 2048;
+__global__ __launch_bounds__(1024) void cell_order_kernel(const int32_t *__restrict__ off0, int64_t cells, int shift0,
+                                                         int32_t *__restrict__ order) {
+    __shared__ int hist[kOrderKeys];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x;
+    // list 0: the cells themselves; list 1: their 2 x 2 blocks (one level up)
+    const int shift = shift0 + 2 * (int)blockIdx.x;
+    const int64_t n = cells >> (2 * (int)blockIdx.x);
+    int32_t *out = order + (blockIdx.x ? cells : 0);
+    for (int k = tid; k < kOrderKeys; k += 1024) hist[k] = 0;
+    // key = rows / quantum, capped: the quantum maps the list's AVERAGE row count to <= 64, so the 2048 keys reach 32 x the average
+    const int quantum = (int)max((int64_t)1, ((int64_t)off0[n << shift] / max(n, (int64_t)1) + 63) / 64);
+    __syncthreads();
+    for (int64_t c = tid; c < n; c += 1024) {
+        const int rows = off0[(c + 1) << shift] - off0[c << shift];
+        atomicAdd(&hist[kOrderKeys - 1 - min(rows / quantum, kOrderKeys - 1)], 1);      // bucket 0 = the densest
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 buckets: two per thread, wave scan, then the 16 wave totals
+    const int a = hist[2 * tid], bsum = a + hist[2 * tid + 1];
+    int incl = bsum;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((tid & 63) >= o) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    const int excl = base + incl - bsum;
+    __syncthreads();
+    hist[2 * tid] = excl; hist[2 * tid + 1] = excl + a;
+    __syncthreads();
+    for (int64_t c = tid; c < n; c += 1024) {
+        const int rows = off0[(c + 1) << shift] - off0[c << shift];
+        out[atomicAdd(&hist[kOrderKeys - 1 - min(rows / quantum, kOrderKeys - 1)], 1)] = (int32_t)c;
+    }
+}
 
 static int check_level(const char *what, int B, int nbits, int level, int C) {
     if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level > nbits || C < 1)
@@ -1889,6 +2112,21 @@ T2H_API int t2h_sample_fwd(const float *plane_nhwc, const float *pts, int dim, i
     return check_launch("sample_fwd");
 }
 
+T2H_API size_t t2h_cell_order_len(int B, int nbits, int level) {
+    if (B < 1 || nbits < 1 || nbits > T2H_MAX_NBITS || level < 0 || level >= nbits) return 0;
+    const size_t cells = (size_t)B << (2 * (nbits - level));
+    return cells + (cells >> 2);
+}
+
+T2H_API int t2h_cell_order_build(const int32_t *off0, int B, int nbits, int level, int32_t *order, t2h_stream_t stream) {
+    if (!off0 || !order) return fail(T2H_ERR_ARG, "cell_order_build: null pointer");
+    if (t2h_cell_order_len(B, nbits, level) == 0) return fail(T2H_ERR_ARG, "cell_order_build: needs 0 <= level < nbits");
+    const int64_t cells = (int64_t)B << (2 * (nbits - level));
+    note_kernel("t2h::cell_order_kernel");
+    hipLaunchKernelGGL(cell_order_kernel, dim3(2), dim3(1024), 0, as_stream(stream), off0, cells, 2 * level, order);
+    return check_launch("cell_order_build");
+}
+
 T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
                                      int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums, void *sign_bits,
                                      t2h_stream_t stream) {
@@ -1899,6 +2137,14 @@ T2H_API int t2h_sample_relu_cellsums(const float *plane_nhwc, const float *pts, 
 T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
                                       int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums,
                                       float *pooled_nhwc, int ld_pooled, void *sign_bits, t2h_stream_t stream) {
+    return t2h_sample_relu_cellsums_ordered(plane_nhwc, pts, dim, off0, B, N, nbits, level, sum_level, C, sums_nhwc, ld_sums,
+                                            pooled_nhwc, ld_pooled, sign_bits, nullptr, stream);
+}
+
+T2H_API int t2h_sample_relu_cellsums_ordered(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
+                                             int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums,
+                                             float *pooled_nhwc, int ld_pooled, void *sign_bits, const int32_t *cell_order,
+                                             t2h_stream_t stream) {
     if (!plane_nhwc || !pts || !off0 || !sums_nhwc) return fail(T2H_ERR_ARG, "sample_relu_cellsums: null pointer");
     if (pooled_nhwc && (sum_level >= level || ld_pooled < C || ld_pooled % 4 != 0 || ((uintptr_t)pooled_nhwc & 15)))
         return fail(T2H_ERR_ARG, "sample_relu_cellsums: the pooled sums need sum_level < level and 16-byte aligned rows of >= C floats");
@@ -1913,6 +2159,27 @@ T2H_API int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts,
     int groups = 1;                                                   // split the children until ~8192 workgroups exist (4096: +10 us at r = 64; 16384: +18 us at r = 32)
     const int nchild = 1 << (2 * (level - sum_level));
     static const int min_wgs = [] { const char* e = getenv("T2H_ON_CHIP_MIN_WGS"); return e ? atoi(e) : 8192; }();
+    // r05: the workgroup shares one staged neighbourhood (sample_relu_cellsums_v2_kernel); T2H_CELLSUMS_V2=0: the r04 kernel (A/B)
+    const char *e_v2 = getenv("T2H_CELLSUMS_V2"), *e_wgs = getenv("T2H_CELLSUMS_V2_WGS");        // (read per call: the probes flip them)
+    const int v2 = e_v2 ? atoi(e_v2) : 1, v2_wgs = e_wgs ? atoi(e_wgs) : 8192;
+    if (v2 && nbits - level >= 1) {
+        const int npts_m1 = (int)(rows_of(B, N) - 1);
+        unsigned long long *bw = static_cast<unsigned long long *>(sign_bits);
+        const int quad = pooled_nhwc ? 4 : 1;                         // children a wave must hold (whole quads for the pooled sums)
+        note_kernel("t2h::sample_relu_cellsums_v2_kernel");
+        const bool k0 = v2 != 2 && nchild >= 4 * quad;              // K = 0: the four waves share out the cell's children
+        // cell_order: [cells] the level's cells, then [cells / 4] its 2 x 2 blocks, each by falling row count
+        const int32_t *order_k0 = cell_order, *order_k1 = cell_order ? cell_order + cells : nullptr;
+        int gz = 1;
+        if (k0) while (nchild / (4 * gz * 2) >= quad && cells * chunks * gz < v2_wgs) gz *= 2;
+        const dim3 grid((unsigned)((k0 ? cells : (cells >> 2)) * chunks * gz));           // K = 1: a 2 x 2 block of cells per workgroup
+#define T2H_V2_LAUNCH(KK, PP) hipLaunchKernelGGL((sample_relu_cellsums_v2_kernel<KK, PP>), grid, dim3(256), 0, as_stream(stream), \
+            plane_nhwc, pts, dim, off0, nbits, level, sum_level, C, sums_nhwc, ld_sums, bw, npts_m1, pooled_nhwc, ld_pooled, k0 ? order_k0 : order_k1, gz)
+        if (k0) { if (pooled_nhwc) T2H_V2_LAUNCH(0, true); else T2H_V2_LAUNCH(0, false); }
+        else { if (pooled_nhwc) T2H_V2_LAUNCH(1, true); else T2H_V2_LAUNCH(1, false); }
+#undef T2H_V2_LAUNCH
+        return check_launch("sample_relu_cellsums(v2)");
+    }
     // (with pooled sums a workgroup's share of the children must hold whole quads)
     while (groups < (pooled_nhwc ? nchild / 4 : nchild) && cells * ((chunks + 3) / 4) * groups < min_wgs) groups *= 2;
     hipLaunchKernelGGL(sample_relu_cellsums_kernel, dim3((unsigned)cells, (chunks + 3) / 4, groups), dim3(64 * waves),
@@ -1926,6 +2193,15 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
                                      const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim, const int32_t *off0, int B, int N, int nbits,
                                      int level, int C, float *gplane_nhwc, void *workspace, size_t workspace_bytes,
                                      t2h_stream_t stream) {
+    return t2h_sample_bwd_from_sums_ordered(gplanes_nhwc, levels, lds, n_planes, cell, mask, mask_is_bits, pts, dim, off0, B, N, nbits,
+                                            level, C, gplane_nhwc, workspace, workspace_bytes, nullptr, stream);
+}
+
+T2H_API int t2h_sample_bwd_from_sums_ordered(const float *const *gplanes_nhwc, const int *levels, const int *lds, int n_planes,
+                                             const int32_t *cell, const void *mask, int mask_is_bits, const float *pts, int dim,
+                                             const int32_t *off0, int B, int N, int nbits, int level, int C, float *gplane_nhwc,
+                                             void *workspace, size_t workspace_bytes, const int32_t *cell_order,
+                                             t2h_stream_t stream) {
     if (!gplanes_nhwc || !levels || !lds || !cell || !mask || !pts || !off0 || !gplane_nhwc)
         return fail(T2H_ERR_ARG, "sample_bwd_from_sums: null pointer");
     if (n_planes < 1 || n_planes > kMaxMultiPlanes)
@@ -1980,14 +2256,15 @@ T2H_API int t2h_sample_bwd_from_sums(const float *const *gplanes_nhwc, const int
         const unsigned long long *bw = static_cast<const unsigned long long *>(mask);
         const int npts_m1 = (int)(rows_of(B, N) - 1);
         GroupCfg g = group_cfg<4>(C);
+        const int32_t *order_k0 = cell_order, *order_k1 = cell_order ? cell_order + groups : nullptr;
         if (blocks) {
-            hipLaunchKernelGGL(sample_bwd_walk_kernel<1>, dim3((unsigned)(groups >> 2), C / 256), dim3(256), 0, as_stream(stream), pts,
-                               dim, off0, nbits, level, wl, C, partial, mp, bw, npts_m1);
+            hipLaunchKernelGGL(sample_bwd_walk_kernel<1>, dim3((unsigned)((groups >> 2) * (C / 256))), dim3(256), 0, as_stream(stream), pts,
+                               dim, off0, nbits, level, wl, C, partial, mp, bw, npts_m1, order_k1);
             hipLaunchKernelGGL(sample_bwd_gather4_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream), partial,
                                B, nbits - level, C, g.lg, gplane_nhwc);
         } else {
-            hipLaunchKernelGGL(sample_bwd_walk_kernel<0>, dim3((unsigned)groups, C / 256), dim3(256), 0, as_stream(stream), pts, dim,
-                               off0, nbits, level, wl, C, partial, mp, bw, npts_m1);
+            hipLaunchKernelGGL(sample_bwd_walk_kernel<0>, dim3((unsigned)(groups * (C / 256))), dim3(256), 0, as_stream(stream), pts, dim,
+                               off0, nbits, level, wl, C, partial, mp, bw, npts_m1, order_k0);
             hipLaunchKernelGGL(sample_bwd_gather9_kernel, dim3(grid_for(groups, g.lg)), dim3(kThreads), 0, as_stream(stream), partial,
                                B, nbits - level, C, g.lg, 1, nullptr, gplane_nhwc);
         }

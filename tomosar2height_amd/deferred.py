@@ -34,6 +34,7 @@ FUSED_SAMPLE_BWD = os.environ.get("T2H_FUSED_SAMPLE_BWD", "1") != "0"      # A/B
 CELLS_MFMA = os.environ.get("T2H_CELLS_MFMA", "1") != "0"                  # (mirrors the library's switch: the bit mask needs it)
 SIGN_BITS = os.environ.get("T2H_SIGN_BITS", "1") != "0"                    # A/B: 0 = keep the hidden activations for the mask
 ON_CHIP_HIDDEN = os.environ.get("T2H_ON_CHIP_HIDDEN", "1") != "0"          # A/B: 0 = sample kernel + per-cell sum kernel
+CELL_ORDER = os.environ.get("T2H_CELL_ORDER", "1") != "0"                  # A/B: 0 = the on-chip walks start their cells in Morton order
 ON_CHIP_MIN_PTS_PER_CELL = float(os.environ.get("T2H_ON_CHIP_MIN_PTS", "8"))   # the walk is sequential inside a cell
 
 
@@ -175,10 +176,11 @@ class _DeferredLevel(torch.autograd.Function):
             second = None
             if len(levels) > 1 and levels[1] == levels[0] + 1 and levels[0] < tile.level(r):
                 second = state._matrix(state.S, levels[1])[:, lo:hi]
-            _lib.call("t2h_sample_relu_cellsums2", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
+            order = tile.cell_order(tile.level(r)) if CELL_ORDER else None
+            _lib.call("t2h_sample_relu_cellsums_ordered", _lib.ptr(q_rows), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B,
                       tile.N, tile.nbits, tile.level(r), levels[0], c2, finest.data_ptr(), finest.stride(0),
                       None if second is None else second.data_ptr(), 0 if second is None else second.stride(0),
-                      None if bits is None else _lib.ptr(bits), _lib.stream(),
+                      None if bits is None else _lib.ptr(bits), None if order is None else _lib.ptr(order), _lib.stream(),
                       nbytes=4 * q_rows.numel() + 12 * tile.n_points + 4 * c2 * finest.shape[0]
                       + (0 if bits is None else (c2 // 8) * tile.n_points) + (0 if second is None else 4 * c2 * second.shape[0]),
                       tag=_lib.timing() and f"t2h_sample_relu_cellsums[C={c2},r={r}]")
@@ -440,9 +442,10 @@ class Deferred:
             arr, lvs, lds = _plane_args(planes)
             ws = _lib.workspace(ws_bytes, h.device)
             dq = torch.empty(tile.B * r * r, c2, dtype=torch.float32, device=h.device)
-            _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(h),
+            order = tile.cell_order(level) if (CELL_ORDER and mask_is_bits) else None
+            _lib.call("t2h_sample_bwd_from_sums_ordered", arr, lvs, lds, len(planes), _lib.ptr(tile.cell), _lib.ptr(h),
                       1 if mask_is_bits else 0, _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits,
-                      level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, _lib.stream(),
+                      level, c2, _lib.ptr(dq), _lib.ptr(ws), ws_bytes, None if order is None else _lib.ptr(order), _lib.stream(),
                       nbytes=(c2 // 8 if mask_is_bits else 4 * c2) * tile.n_points + 12 * tile.n_points + 4 * dq.numel()
                       + sum(4 * c2 * p.shape[0] for p, _ in planes), tag=_lib.timing() and f"t2h_sample_bwd_from_sums[C={c2},r={r}]")
             return dq

@@ -125,6 +125,22 @@ class TileIndex:
             hit = self._adjoint[level] = (offsets, entries)
         return hit
 
+    def cell_order(self, level: int):
+        """Dispatch order of the on-chip walks at ALTO level ``level`` (``t2h_cell_order_build``): the level's cells, then its
+        2 x 2 blocks of cells, each by falling row count -- the dense cells' workgroups start first.  Built on first use and kept
+        for the tile's lifetime (the forward and the backward walk of the level share it).  Scheduling only: results do not depend
+        on it.  ``None`` where the level has no such list (the coarsest possible level, a 1 x 1 plane)."""
+        hit = self._adjoint.get(("order", level), False)
+        if hit is False:
+            n = int(_lib.load().t2h_cell_order_len(self.B, self.nbits, level))
+            hit = None
+            if n > 0 and self.n_points > 0:
+                hit = torch.empty(n, dtype=torch.int32, device=self.device)
+                _lib.call("t2h_cell_order_build", _lib.ptr(self.off0), self.B, self.nbits, level, _lib.ptr(hit), _lib.stream(),
+                          nbytes=8 * n + 8 * (n - n // 5))
+            self._adjoint[("order", level)] = hit
+        return hit
+
     @property
     def n_points(self) -> int:
         return -self.N if self.N < 0 else self.B * self.N
@@ -148,6 +164,8 @@ class TileIndex:
                 tile.sample_adjoint(0)
             for lv in range(min(4, tile.nbits)):
                 deferred.counts(tile, lv)
+                if lv >= 1 and deferred.CELL_ORDER:
+                    tile.cell_order(lv)
             tile.ready = torch.cuda.Event()
             tile.ready.record(stream)
         cloud.record_stream(stream)
@@ -157,8 +175,11 @@ class TileIndex:
 
     def _tensors(self):
         out = [self.pts, self.perm, self.cell, self.off0]
-        for offsets, entries in self._adjoint.values():
-            out += [offsets, entries]
+        for key, val in self._adjoint.items():
+            if isinstance(key, tuple):                       # ("order", level): one tensor or None
+                out += [val] if val is not None else []
+            else:
+                out += list(val)
         out += list(self.__dict__.get("_cell_counts", {}).values())
         return out
 
