@@ -111,6 +111,13 @@ def parse():
     ap.add_argument("--sustain-s", type=float, default=6.0,
                     help="after the timed region: this many seconds of back-to-back tile-steps (one HIP event per step, nothing "
                          "else) -> sustained_ms_per_step and first / last quartile step time; never part of `value`.  0 = off")
+    ap.add_argument("--pin-cores", type=int, default=1,
+                    help="N > 1: bind every rank to its own CPU cores (NUMA-local to its GPU where sysfs tells) before the GPU is "
+                         "initialised; 0 = leave the affinity alone")
+    ap.add_argument("--exact-split-steps", type=int, default=16,
+                    help="tile-steps of a SECOND short timed leg with the 3x3 / transposed convolutions on the exact three-way bf16 "
+                         "split (six MFMAs per product: fp32 arithmetic bit for bit up to summation order) instead of the default "
+                         "two-way fp16 split with block scales; reported as `exact_split`, never part of `value` (0: skip)")
     ap.add_argument("--from-producer", action="store_true",
                     help="every tile of every leg is cropped / normalised / augmented / raster-patched on the device by "
                          "producer.TileSource from a synthetic chunk resident in HBM (dataset.py:201-330) inside the loop, "
@@ -424,6 +431,63 @@ def self_launch(args):
     return rc if rc != 0 or line is not None else 1
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus():
+    """CPUs local to each GPU, in HIP device order, WITHOUT touching the GPU (sysfs only): the KFD topology lists the GPUs
+    (nodes with SIMDs) in the order the runtime enumerates them and gives each one's PCI address, whose sysfs entry names the
+    NUMA-local CPUs.  None when the topology is not readable (containers without /sys/class/kfd)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        out = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            out.append(_parse_cpulist(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read()))
+        return out or None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def pin_rank(local_rank: int, local_world: int, shared_gpu: bool = False):
+    """Bind this rank to its own CPU cores BEFORE anything initialises the GPU (the HIP runtime's helper threads inherit the
+    mask).  A rank of the B = 1 step needs about two cores (Python issue thread + autograd's device thread + HIP runtime:
+    `sustained.host_cpu_ms_per_step` ~ 13 ms per 6.7 ms step), and a rank whose threads migrate or share a core with a neighbour
+    becomes the straggler every other rank waits for at the all-reduce: the known risk of the 8-GPU line.
+    Cores: those NUMA-local to the rank's GPU (sysfs), shared out among the ranks whose GPUs have the same local set; without a
+    readable topology an equal slice of the process's current mask.  Returns the sorted core list (also left in T2H_RANK_CPUS)."""
+    avail = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(avail) < local_world:
+        return avail
+    topo = None if shared_gpu else gpu_local_cpus()
+    mine = None
+    if topo is not None and local_rank < len(topo) and local_world <= len(topo):
+        local = sorted(topo[local_rank] & set(avail))
+        peers = [r for r in range(local_world) if topo[r] == topo[local_rank]]
+        per = len(local) // max(len(peers), 1)
+        if per >= 1:
+            i = peers.index(local_rank)
+            mine = local[i * per:(i + 1) * per]
+    if not mine:
+        per = len(avail) // local_world
+        mine = avail[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    os.environ["T2H_RANK_CPUS"] = ",".join(map(str, mine))
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", len(mine))))))
+    return mine
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -433,6 +497,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    # first thing, before any GPU call (torch.cuda.is_available() below initialises the runtime): this rank's own cores
+    rank_cpus = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), shared_gpu=args.share_gpu) if args.pin_cores else None
+    if rank_cpus is not None and world > 1:
+        torch.set_num_threads(max(1, min(len(rank_cpus), torch.get_num_threads())))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU path to benchmark)")
     if args.share_gpu:
@@ -641,6 +709,33 @@ def main():
         fence()
         sustained["host_issue_ms_empty_queue"] = round(1e3 * statistics.median(lone), 3)
 
+    # ---- leg 1c: the same step with the convolutions in the EXACT split arithmetic (never part of `value`): what `dtype: f32`
+    # costs when no block-floating-point caveat is accepted (DESIGN 4.1a vs 4.1b)
+    exact_split = None
+    if args.exact_split_steps > 0 and args.mode == "train" and not args.hip_graph and grid.CONV_PRECISION == "f16x2":
+        trainer.flush_pipeline()
+        grid.set_conv_precision("bf16x3")
+        try:
+            run(6)                                            # (first use prepares the three-way split weights)
+            fence()
+            te = time.perf_counter()
+            run(args.exact_split_steps)
+            fence()
+            es = time.perf_counter() - te
+            if world > 1:
+                tmax = torch.tensor([es], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                es = float(tmax.item())
+            exact_split = {"value": round(world * args.exact_split_steps / es, 3), "ms_per_step": round(1e3 * es / args.exact_split_steps, 3),
+                           "steps": args.exact_split_steps,
+                           "arithmetic": "3x3 / transposed convolutions and wide grid-side products: exact 3-way bf16 operand split, "
+                                         "6 MFMAs per product, fp32 accumulate (T2H_CONV_PRECISION=bf16x3)"}
+        finally:
+            trainer.flush_pipeline()
+            grid.set_conv_precision(None)
+            run(2)                                            # back on the default arithmetic before the next leg
+            fence()
+
     # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
     timeline = None
     if args.profile_steps > 0 and not args.hip_graph:
@@ -671,8 +766,18 @@ def main():
     if args.check_dp == 1 or (args.check_dp < 0 and world > 1):
         try:
             dp = check_dp(args, world, rank, dev, group, model, make_trainer)
+            if args.backend == "nccl" and world > 1 and dp.get("rccl_ranks") != world:
+                raise AssertionError(f"--backend nccl with {world} ranks, but the gradient all-reduce ran on {dp.get('rccl_ranks')} RCCL ranks")
         except Exception as e:          # the headline line must survive a failing diagnostic (every rank fails alike or the
             dp = {"error": f"{type(e).__name__}: {e}"[:300]}      # collective inside raises on all of them)
+    per_rank = None
+    if world > 1:
+        # what every rank's HOST did (the scaling risk of the line: DESIGN section 6): its cores and its CPU time per tile-step
+        mine = {"rank": rank, "cpus": os.environ.get("T2H_RANK_CPUS", ""),
+                "host_cpu_ms_per_step": None if sustained is None else sustained["host_cpu_ms_per_step"],
+                "host_issue_ms_per_step": None if sustained is None else sustained["host_issue_ms_per_step"]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=group)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -757,6 +862,8 @@ def main():
                 out["config"]["kernel_table"] = args.kernel_table
             except OSError as e:
                 out["config"]["kernel_table"] = f"not written: {e}"
+        if exact_split is not None:
+            out["exact_split"] = exact_split
         if sustained is not None:
             out["sustained"] = sustained
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
@@ -768,6 +875,14 @@ def main():
             out["config"]["workload"] += ", tiles from the device tile producer (dataset.py:201-330)"
         if dp is not None:
             out["check_dp"] = dp
+        if per_rank is not None:
+            sets = [set(r["cpus"].split(",")) - {""} for r in per_rank]
+            out["ranks"] = {"host_cpu_ms_per_step": [r["host_cpu_ms_per_step"] for r in per_rank],
+                            "host_issue_ms_per_step": [r["host_issue_ms_per_step"] for r in per_rank],
+                            "cores_per_rank": [len(c) for c in sets],
+                            "affinity_disjoint": bool(all(sets)) and all(not (sets[i] & sets[j]) for i in range(world)
+                                                                         for j in range(i + 1, world)),
+                            "cpus": [r["cpus"] if len(r["cpus"]) <= 24 else r["cpus"][:21] + "..." for r in per_rank]}
         if world == 1 and not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)          # last: the GPU legs above run back to back
         print(json.dumps(out), flush=True)

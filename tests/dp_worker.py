@@ -65,6 +65,12 @@ def _step(model, dev, tiles, group, every):
     return grabbed["g"], params, float(tr.last_avg_loss), tr
 
 
+def _per_element(p_dp, p_1, g_dp, g_1):
+    clear = (g_1.abs() > 1e2 * (g_dp - g_1).abs()) & (g_1.abs() > 1e-6)
+    return {"clear_fraction": float(clear.float().mean().item()),
+            "param_max_abs_clear": float(((p_dp - p_1).abs() * clear).max().item())}
+
+
 def run_dp(out_path):
     """W ranks, HIP model, gloo over tensors on the shared GPU: bucket == single-process bucket up to fp32 re-association,
     replicas bit-identical after the step, never-used parameters outside the bucket."""
@@ -100,6 +106,9 @@ def run_dp(out_path):
                                                 1e2 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max())).max().item()),
            "significant_fraction": float((tr1.grad_in_param_order.abs() >
                                           1e2 * (tr.grad_in_param_order - tr1.grad_in_param_order).abs().max()).float().mean().item()),
+           # r05: the same PER ELEMENT -- a weight whose own gradient stands 100 x clear of its own re-association
+           # difference (and of AdamW's eps) must take the same step in both runs; most weights qualify
+           **_per_element(p_dp, p_1, tr.grad_in_param_order, tr1.grad_in_param_order),
            "loss_dp": loss_dp, "loss_single": loss_1, "none_grad": none_grad, "live": live,
            "bucket": int(tr.bucket.flat.numel()), "bucket_single": int(tr1.bucket.flat.numel()),
            "bucket_views_aligned": all(p.grad.data_ptr() % 16 == 0 for p in model.parameters() if p.grad is not None)}

@@ -56,13 +56,38 @@ def test_benchmarked_configuration_matches_the_oracle_at_full_size(use_image):
 
     # gradient resolution: see test_model_vs_torch_oracle_all_grads (ReLU / max-pool / arg-max masks flip under 1e-7
     # activation differences; the oracle itself moved to the device deviates from its CPU run by up to 6e-3 max-normalised)
-    rows = []
+    # float64 run of the same oracle (cloud+image only): the yardstick for tensors whose fp32-vs-fp32 distance exceeds 3e-3 --
+    # how far torch's OWN fp32 run is from the float64 gradient is the mask-flip noise of fp32 arithmetic at this size, a
+    # figure that does not depend on our kernels
+    g64 = {}
+    if use_image:
+        import copy
+        ref64 = copy.deepcopy(ref).double()
+        for q in ref64.parameters():
+            q.grad = None
+        import torch.nn.functional as F64
+
+        def sample64(xy, plane):                     # torch_ref.sample_bilinear without its cast of the grid to fp32 (alto.py:93)
+            out = F64.grid_sample(plane, 2.0 * xy[:, :, None] - 1.0, padding_mode="border", align_corners=True, mode="bilinear")
+            return out.squeeze(-1).transpose(1, 2)
+        keep = torch_ref.sample_bilinear
+        torch_ref.sample_bilinear = sample64
+        try:
+            pa64, _ = ref64(input_cloud=cloud.double(), input_image=image.double())
+            (pa64.squeeze() * w.double()).mean().backward()
+        finally:
+            torch_ref.sample_bilinear = keep
+        g64 = {k: q.grad for k, q in ref64.named_parameters() if q.grad is not None}
+    rows, vs64 = [], {}
     for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         assert (p.grad is None) == (q.grad is None), k
         if p.grad is None:
             continue
         got, want = p.grad.cpu().double(), q.grad.double()
         rows.append((_rel(got.numpy(), want.numpy()), ((got - want).norm() / (want.norm() + 1e-30)).item(), k))
+        if k in g64:
+            n64 = g64[k].norm() + 1e-30
+            vs64[k] = (((got - g64[k]).norm() / n64).item(), ((want - g64[k]).norm() / n64).item())
     rows.sort(reverse=True)
     print(f"[full size, image={use_image}] heights {err:.2e}; gradients (max-normalised, L2, name), worst first:")
     for mx, l2, k in rows[:8]:
@@ -72,16 +97,26 @@ def test_benchmarked_configuration_matches_the_oracle_at_full_size(use_image):
     # weight gradient, i.e. moves that row by ~1/sqrt(1024) = 3 % (measured: image_encoder.up_convs.0.conv2.weight 1.1e-2 with
     # L2 2.3e-3, everything else < 6.1e-3).  The image U-Net's three deepest levels therefore get 3e-2 in the max norm; the L2
     # criterion (3e-3) holds everywhere, and the mask-pinned checks of test_hip_masks.py / test_hip_conv.py pin the arithmetic.
-    # r04: the image U-Net's L2 bound is 5e-3 (measured 3.8e-3 on image_encoder.down_convs.2.conv1.weight once every 3x3
-    # convolution ran on the split-bf16 matrix-core kernels -- another summation order, so another set of units within 1e-7 of zero
-    # flips); that this is mask-flip noise and not arithmetic is pinned by test_hip_masks.py::test_image_unet_*_with_the_same_masks:
-    # the same levels, same kernels, against float64 with the forward's own masks: every output and gradient <= 2e-6.
+    # The L2 bound is 3e-3 for every tensor (r04 had loosened the image U-Net's to 5e-3 when its convolutions moved to the split
+    # matrix-core kernels -- another summation order, another set of units within 1e-7 of zero flips; measured 3.8e-3 on one tensor).
+    # r05: a tensor over 3e-3 must instead be as close to the FLOAT64 gradient as torch's own fp32 run of the same graph is (within
+    # 25 %): the distance between two fp32 runs is then mask-flip noise by the oracle's own measure, not our arithmetic.  (That it
+    # is not arithmetic is also pinned by test_hip_masks.py::test_image_unet_*_with_the_same_masks: same kernels against float64
+    # with the forward's own masks, every output and gradient <= 2e-6.)
     small_planes = ("image_encoder.down_convs.4.", "image_encoder.down_convs.5.", "image_encoder.up_convs.0.")
     for mx, l2, k in rows:
         lim_mx = 3e-2 if k.startswith(small_planes) else 1e-2
-        lim_l2 = 5e-3 if k.startswith("image_encoder.") else 3e-3
         assert mx <= lim_mx, f"{k}: max-normalised gradient error {mx:.2e} > {lim_mx:g}"
-        assert l2 <= lim_l2, f"{k}: L2 relative gradient error {l2:.2e} > {lim_l2:g}"
+        if l2 > 3e-3:
+            assert k in vs64, f"{k}: L2 relative gradient error {l2:.2e} > 3e-3"
+            ours, torchs = vs64[k]
+            print(f"    {k}: L2 vs the fp32 oracle {l2:.2e} > 3e-3; vs float64: ours {ours:.2e}, torch fp32 {torchs:.2e}")
+            assert ours <= 1.25 * torchs, (f"{k}: L2 error vs the float64 gradient {ours:.2e} exceeds 1.25 x that of torch's own "
+                                           f"fp32 run ({torchs:.2e})")
+    if vs64:
+        worst = max(vs64.items(), key=lambda kv: kv[1][0] / (kv[1][1] + 1e-30))
+        print(f"[full size, image] L2 distance to the float64 gradient, worst ratio ours / torch-fp32: {worst[0]}: "
+              f"{worst[1][0]:.2e} / {worst[1][1]:.2e}")
 
 
 # ------------------------------------------------------------------------------------------------ r04: every reported line
@@ -262,3 +297,74 @@ def test_munich_hipgraph_inference_matches_the_oracle_at_full_size(munich_full_s
     with torch.no_grad():
         pa, pb = model(input_cloud=cloud, input_image=image)
     assert torch.equal(pa, pa_s) and torch.equal(pb, pb_s)
+
+
+def test_block_scales_of_the_split_convolutions_on_the_benchmarked_tile():
+    """``dtype: "f32"`` on the bench line with the 3x3 convolutions on the fp16 two-way split: an element keeps
+    fp32-grade RELATIVE accuracy while it is within 2^18 of the largest magnitude of its own staged block (beyond that it is
+    kept to 2^-40 of the block maximum: block floating point).  This instruments every 3x3 convolution call -- forward, data
+    gradient, weight gradient -- of one training step on bench.py's tile (N = 131072) and measures, per call and operand, the
+    fraction of non-zero elements that lie more than 2^18 below their block's maximum (blocks taken LARGER than the kernels'
+    staged ones: (rows + halo) x 34 pixels x 32 channels, so the measured fraction is an upper bound).  Asserted: under 1e-3 of
+    the non-zero elements of every operand of every call (the 1e-3 quantile sits inside the fp32-grade range) -- and what such
+    elements could add to a block's sum at all stays below 2^-18 of the block's largest term each."""
+    import torch.nn.functional as F
+    from tomosar2height_amd import TomoSAR2Height, grid
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.synthetic import DEFAULT_POINTS, berlin_tile
+    dev = torch.device("cuda:0")
+    assert grid.CONV_PRECISION == "f16x2"
+    model = det_init_(TomoSAR2Height(berlin_config()), seed=31).to(dev)
+    model.set_channels_last(True)
+    tile = berlin_tile(seed=1000, n_points=DEFAULT_POINTS)
+    rows = []
+
+    def degraded(t, what):
+        """t [B, C, H, W] (any strides): (fraction of non-zero elements > 2^18 below their block maximum, non-zero count)"""
+        a = t.detach().abs().float()
+        b, c, h, w = a.shape
+        if c % 32:
+            return
+        cm = a.reshape(b, c // 32, 32, h, w).amax(2)                                 # 32-channel chunks
+        th = 8 if h >= 8 else h
+        bm = F.max_pool2d(cm, kernel_size=(th + 2, 34), stride=(th, 32), padding=(1, 1))      # halo tile maxima
+        bm = bm.repeat_interleave(th, 2)[:, :, :h].repeat_interleave(32, 3)[:, :, :, :w]
+        bm = bm.repeat_interleave(32, 1)
+        nz = a > 0
+        bad = nz & (a * 2.0 ** 18 < bm)
+        n = int(nz.sum())
+        rows.append((int(bad.sum()) / max(n, 1), n, what, tuple(t.shape)))
+
+    orig = (grid.conv3x3_fwd_, grid.conv3x3_dgrad_, grid.conv3x3_wgrad_)
+
+    def fwd(x, w, bias, y, **kw):
+        if grid.bx3_applicable(x.shape[0], x.shape[2], x.shape[3], x.shape[1], w.shape[0]):
+            degraded(x, "fwd x")
+        return orig[0](x, w, bias, y, **kw)
+
+    def dgrad(gy, w, dx, **kw):
+        if grid.bx3_applicable(gy.shape[0], gy.shape[2], gy.shape[3], w.shape[1], gy.shape[1]):
+            degraded(gy, "dgrad dy")
+        return orig[1](gy, w, dx, **kw)
+
+    def wgrad(gy, x, dw, db, **kw):
+        if grid.bx3_applicable(gy.shape[0], gy.shape[2], gy.shape[3], x.shape[1], gy.shape[1]):
+            degraded(gy, "wgrad dy")
+            degraded(x, "wgrad x")
+        return orig[2](gy, x, dw, db, **kw)
+
+    grid.conv3x3_fwd_, grid.conv3x3_dgrad_, grid.conv3x3_wgrad_ = fwd, dgrad, wgrad
+    try:
+        pa, _ = model(input_cloud=tile["inputs"].to(dev))
+        torch.nn.functional.l1_loss(pa.squeeze(), tile["dsm"].squeeze().to(dev)).backward()
+        torch.cuda.synchronize()
+    finally:
+        grid.conv3x3_fwd_, grid.conv3x3_dgrad_, grid.conv3x3_wgrad_ = orig
+    assert len(rows) >= 60, f"only {len(rows)} split-convolution operands seen"
+    rows.sort(reverse=True)
+    print(f"[block scales] {len(rows)} operands of the split 3x3 convolutions; worst fractions of non-zero elements more than "
+          "2^18 below their block maximum:")
+    for frac, n, what, shape in rows[:8]:
+        print(f"    {frac:.2e} of {n:9d} non-zero   {what:9s} {shape}")
+    for frac, n, what, shape in rows:
+        assert frac <= 1e-3, f"{what} {shape}: {frac:.2e} of the non-zero elements are beyond the fp32-grade range of their block"
