@@ -145,7 +145,7 @@ def test_pixelwise_decoder_golden(mode, foot, img):
     g = load_golden("pixelwise_decoder")
     tag = f"{mode}_f{int(foot)}_i{int(img)}"
     import tomosar2height_amd as t2h
-    t2h.allow_library_fallback(mode == "fc").set()     # the per-pixel FC head has a 1-column Linear (rocBLAS in its backward)
+    before = sum(t2h.fallback_counts().values())       # r05: the per-pixel FC head's 1-column Linear runs on the head kernels too
     dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode=mode, use_footprint=foot), seed=7)
     assert list(dec.state_dict()) == g[f"keys_{tag}"].tolist()
     dec.to(_dev())
@@ -166,6 +166,20 @@ def test_pixelwise_decoder_golden(mode, foot, img):
     got, want = planes["xy"].grad.cpu().double(), torch.from_numpy(g[f"gxy_{tag}"]).double()
     _close(got.numpy(), want.numpy(), rel=1e-2, what="gxy")
     assert ((got - want).norm() / want.norm()).item() <= 3e-3
+    assert sum(t2h.fallback_counts().values()) == before, "a vendor-library fallback ran"
+    if mode == "fc":      # Linear(32, 1) head: weight / bias gradients against float64 on the device (the fixture holds gxy only)
+        head = dec.fc_decoder
+        rows = torch.randn(4096, 32, generator=torch.Generator().manual_seed(3)).to(_dev()).requires_grad_(True)
+        up = torch.randn(4096, 1, generator=torch.Generator().manual_seed(4)).to(_dev())
+        for p in head.parameters():
+            p.grad = None
+        head(rows).backward(up)
+        r64 = rows.detach().double().requires_grad_(True)
+        w64, b64 = head.fc_out.weight.detach().double().requires_grad_(True), head.fc_out.bias.detach().double().requires_grad_(True)
+        (torch.relu(r64) @ w64.t() + b64).backward(up.double())
+        _close(rows.grad.cpu().numpy(), r64.grad.cpu().numpy(), rel=2e-6, what="fc head dx")
+        _close(head.fc_out.weight.grad.cpu().numpy(), w64.grad.cpu().numpy(), rel=2e-6, what="fc head dw")
+        _close(head.fc_out.bias.grad.cpu().numpy(), b64.grad.cpu().numpy(), rel=2e-6, what="fc head db")
 
 
 def _full_model(tag):

@@ -56,8 +56,9 @@ class FCDecoder(nn.Module):
     def forward(self, x):
         for layer in self.blocks:
             x = layer(x)
-        x = F.leaky_relu(x) if self.leaky else F.relu(x)
-        return mlp.linear(x, self.fc_out.weight, self.fc_out.bias)
+        if self.leaky:
+            return mlp.linear(F.leaky_relu(x), self.fc_out.weight, self.fc_out.bias)
+        return mlp.linear(x, self.fc_out.weight, self.fc_out.bias, relu_in=True)          # fc_out(act(x)), the ReLU in the loader
 
 
 class PixelwiseDecoder(nn.Module):
@@ -68,7 +69,11 @@ class PixelwiseDecoder(nn.Module):
                  use_footprint=False, **kwargs):
         super().__init__()
         if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built")
+            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
+                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
+                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
+                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
+                                      "no kernel here")
         if mode not in ("conv", "fc"):
             raise ValueError("Invalid mode. Use 'conv' or 'fc'.")
         self.mode, self.use_footprint = mode, bool(use_footprint)

@@ -107,7 +107,11 @@ class DownConv(_PointGridLevel):
     def __init__(self, in_channels, out_channels, i, pooling, depth, sample_mode="bilinear"):
         super().__init__()
         if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built")
+            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
+                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
+                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
+                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
+                                      "no kernel here")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.pooling, self.downsample, self.depth = pooling, i, depth
         self.conv1 = conv3x3(in_channels, out_channels)
@@ -139,7 +143,11 @@ class UpConv(_PointGridLevel):
                  sample_mode="bilinear"):
         super().__init__()
         if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built")
+            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
+                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
+                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
+                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
+                                      "no kernel here")
         self.in_channels, self.out_channels = in_channels, out_channels
         self.merge_mode, self.up_mode, self.depth = merge_mode, up_mode, depth
         self.is_last = i == depth - 2

@@ -288,6 +288,11 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
+        if w.shape[0] == 1 and w.shape[1] % 4 == 0 and x.is_contiguous():
+            # one output column (fc_out of the per-pixel FC decoder, pixel.py:51,56: Linear(32, 1) over 512 x 512 pixel rows): a
+            # rank-1 product per row -- the concat-free head's kernels with ONE input (t2h_head1x1_bwd: dx = g w masked by the
+            # ReLU, dw = sum_p g[p] a[p, :], db = sum_p g[p], deterministic two-stage sums) instead of a library GEMM
+            return _linear1_backward(ctx, x, w, bias, gy)
         dx = None
         if ctx.needs_input_grad[0]:
             if w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0:
@@ -299,6 +304,28 @@ class _Linear(torch.autograd.Function):
                     dx = dx * (x > 0)
         dw, db = _wgrad(gy, x, w, bias, relu_in=ctx.relu_in)
         return dx, dw, db, None
+
+
+def _linear1_backward(ctx, x, w, bias, gy):
+    import ctypes
+    m, k = x.shape
+    a = x
+    if ctx.relu_in:                                    # the head kernels take the ReLU OUTPUT: a = x * (x > 0), one pass
+        a = torch.empty_like(x)
+        _lib.call("t2h_relu_mask", _lib.ptr(x), _lib.ptr(x), _lib.ptr(a), x.numel(), _lib.stream(), nbytes=12 * x.numel())
+    dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+    dw = torch.empty(k, dtype=torch.float32, device=x.device)
+    db = torch.empty(1, dtype=torch.float32, device=x.device) if bias is not None else None
+    ws_bytes = _lib.ws_bytes("t2h_head1x1_bwd_workspace_bytes", m, k)
+    ws = _lib.workspace(ws_bytes, x.device)
+    xarr = (ctypes.c_void_p * 1)(a.data_ptr())
+    dxarr = (ctypes.c_void_p * 1)(dx.data_ptr() if dx is not None else None)
+    carr = (ctypes.c_int * 1)(k)
+    _lib.call("t2h_head1x1_bwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(dxarr, ctypes.c_void_p),
+              ctypes.cast(carr, ctypes.c_void_p), 1, _lib.ptr(w.reshape(-1).contiguous()), _lib.ptr(gy), m,
+              (1 << 8) if ctx.relu_in else 0, _lib.ptr(dw), None if db is None else _lib.ptr(db), _lib.ptr(ws), ws_bytes,
+              _lib.stream(), nbytes=4 * (3 * k + 1) * m)
+    return dx, dw.reshape(w.shape), db, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu_in: bool = False) -> torch.Tensor:
