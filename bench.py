@@ -820,6 +820,13 @@ def main():
         if args.mlp_precision != "fp32":
             from tomosar2height_amd import mlp
             out["config"]["trunk_precision"] = mlp.trunk_precision()
+        if args.mlp_precision == "bf16":
+            # BASELINE configs[2] ("bf16 MLP GEMMs on MFMA") is kept as an ARITHMETIC, retired as a speed mode: the default line
+            # already runs its convolutions and wide grid-side products on the 16-bit matrix cores (fp16 two-way split), what this
+            # mode still changes are the per-point GEMMs of three levels, whose A operand is produced per tile in fp32 -- measured
+            # 99.0 vs 101.0 tiles/s (r04) against the fp32-result line of the same configuration: no gain to report
+            out["config"]["mode_note"] = ("configs[2] arithmetic (operands rounded to bf16, fp32 accumulate); not a speed mode: the "
+                                          "default fp32-result line already runs the 16-bit matrix cores (DESIGN.md section 5)")
         if timeline is not None:
             tags, syms = kernel_tables(timeline, args.profile_steps)
             traffic, traffic_src = pmc_traffic() if (args.points == 131072 and not args.from_producer) else ({}, None)
