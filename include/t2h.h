@@ -199,6 +199,9 @@ int t2h_sample_relu_cellsums2(const float *plane_nhwc, const float *pts, int dim
  * with and without an order.  (No reference counterpart: torch_scatter / grid_sample have no such structure to balance.) */
 size_t t2h_cell_order_len(int B, int nbits, int level);
 int t2h_cell_order_build(const int32_t *off0, int B, int nbits, int level, int32_t *order, t2h_stream_t stream);
+/* ... for levels level_lo .. level_hi in ONE launch; `order` holds their lists back to back (t2h_cell_order_len each). */
+int t2h_cell_order_build_range(const int32_t *off0, int B, int nbits, int level_lo, int level_hi, int32_t *order,
+                               t2h_stream_t stream);
 int t2h_sample_relu_cellsums_ordered(const float *plane_nhwc, const float *pts, int dim, const int32_t *off0, int B, int N,
                                      int nbits, int level, int sum_level, int C, float *sums_nhwc, int ld_sums, float *pooled_nhwc,
                                      int ld_pooled, void *sign_bits, const int32_t *cell_order, t2h_stream_t stream);

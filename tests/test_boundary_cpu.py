@@ -122,6 +122,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_sample_bwd_from_sums_ordered": (n, n, n, 1, n, n, 0, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n, n),
         "t2h_sample_relu_cellsums_ordered": (n, n, 3, n, 1, 10, 8, 2, 0, 256, n, 256, n, 256, n, n, n),
         "t2h_cell_order_build": (n, 1, 8, 2, n, n),
+        "t2h_cell_order_build_range": (n, 1, 8, 1, 3, n, n),
         "t2h_sample_fwd": (n, n, 3, 1, 10, 32, 32, n, n),
         "t2h_sample_fwd_relu": (n, n, 3, 1, 10, 32, 32, n, n, n),
         "t2h_sample_bwd": (n, n, 3, n, 1, 10, 8, 0, 32, n, n, 0, n),

@@ -51,6 +51,7 @@ SIGNATURES = {
     "t2h_sample_relu_cellsums2": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "t2h_cell_order_len": (_sz, [_i, _i, _i]),
     "t2h_cell_order_build": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "t2h_cell_order_build_range": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "t2h_sample_relu_cellsums_ordered": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "t2h_sample_bwd_from_sums": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "t2h_sample_bwd_from_sums_ordered": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),

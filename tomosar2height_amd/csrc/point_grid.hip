@@ -1788,23 +1788,36 @@ using namespace t2h;
 // every output element is still written by exactly one wave, with the same operations in the same order.  (Cells of equal
 // count land in the order their atomics arrive: scheduling only.)
 constexpr int kOrderKeys = 2048;
-__global__ __launch_bounds__(1024) void cell_order_kernel(const int32_t *__restrict__ off0, int64_t cells, int shift0,
+constexpr int kOrderRegs = 16;                  // cells per thread kept in registers between the two passes (16384 cells per list)
+// blockIdx.x = 2 * (level - level_lo) + list: list 0 = the level's cells, list 1 = their 2 x 2 blocks (one level up).  `order`
+// holds the lists of levels level_lo .. back to back: [cells_l][cells_l / 4] per level (t2h_cell_order_len each)
+__global__ __launch_bounds__(1024) void cell_order_kernel(const int32_t *__restrict__ off0, int B, int nbits, int level_lo,
                                                          int32_t *__restrict__ order) {
     __shared__ int hist[kOrderKeys];
     __shared__ int wsum[16];
     const int tid = threadIdx.x;
-    // list 0: the cells themselves; list 1: their 2 x 2 blocks (one level up)
-    const int shift = shift0 + 2 * (int)blockIdx.x;
-    const int64_t n = cells >> (2 * (int)blockIdx.x);
-    int32_t *out = order + (blockIdx.x ? cells : 0);
+    const int level = level_lo + ((int)blockIdx.x >> 1), list = (int)blockIdx.x & 1;
+    int32_t *out = order;
+    for (int l = level_lo; l < level; ++l) { const int64_t c = (int64_t)B << (2 * (nbits - l)); out += c + (c >> 2); }
+    const int64_t cells = (int64_t)B << (2 * (nbits - level));
+    const int shift = 2 * level + 2 * list;
+    const int64_t n = cells >> (2 * list);
+    if (list) out += cells;
     for (int k = tid; k < kOrderKeys; k += 1024) hist[k] = 0;
     // key = rows / quantum, capped: the quantum maps the list's AVERAGE row count to <= 64, so the 2048 keys reach 32 x the average
     const int quantum = (int)max((int64_t)1, ((int64_t)off0[n << shift] / max(n, (int64_t)1) + 63) / 64);
-    __syncthreads();
-    for (int64_t c = tid; c < n; c += 1024) {
-        const int rows = off0[(c + 1) << shift] - off0[c << shift];
-        atomicAdd(&hist[kOrderKeys - 1 - min(rows / quantum, kOrderKeys - 1)], 1);      // bucket 0 = the densest
+    int key[kOrderRegs];
+#pragma unroll
+    for (int k = 0; k < kOrderRegs; ++k) {
+        const int64_t c = tid + (int64_t)k * 1024;
+        key[k] = c < n ? kOrderKeys - 1 - min((off0[(c + 1) << shift] - off0[c << shift]) / quantum, kOrderKeys - 1) : -1;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOrderRegs; ++k)
+        if (key[k] >= 0) atomicAdd(&hist[key[k]], 1);                       // bucket 0 = the densest
+    for (int64_t c = tid + (int64_t)kOrderRegs * 1024; c < n; c += 1024)   // (lists beyond 16384 cells: batches of tiles)
+        atomicAdd(&hist[kOrderKeys - 1 - min((off0[(c + 1) << shift] - off0[c << shift]) / quantum, kOrderKeys - 1)], 1);
     __syncthreads();
     // exclusive scan of the 2048 buckets: two per thread, wave scan, then the 16 wave totals
     const int a = hist[2 * tid], bsum = a + hist[2 * tid + 1];
@@ -1818,10 +1831,11 @@ __global__ __launch_bounds__(1024) void cell_order_kernel(const int32_t *__restr
     __syncthreads();
     hist[2 * tid] = excl; hist[2 * tid + 1] = excl + a;
     __syncthreads();
-    for (int64_t c = tid; c < n; c += 1024) {
-        const int rows = off0[(c + 1) << shift] - off0[c << shift];
-        out[atomicAdd(&hist[kOrderKeys - 1 - min(rows / quantum, kOrderKeys - 1)], 1)] = (int32_t)c;
-    }
+#pragma unroll
+    for (int k = 0; k < kOrderRegs; ++k)
+        if (key[k] >= 0) out[atomicAdd(&hist[key[k]], 1)] = (int32_t)(tid + k * 1024);
+    for (int64_t c = tid + (int64_t)kOrderRegs * 1024; c < n; c += 1024)
+        out[atomicAdd(&hist[kOrderKeys - 1 - min((off0[(c + 1) << shift] - off0[c << shift]) / quantum, kOrderKeys - 1)], 1)] = (int32_t)c;
 }
 
 static int check_level(const char *what, int B, int nbits, int level, int C) {
@@ -2119,11 +2133,17 @@ T2H_API size_t t2h_cell_order_len(int B, int nbits, int level) {
 }
 
 T2H_API int t2h_cell_order_build(const int32_t *off0, int B, int nbits, int level, int32_t *order, t2h_stream_t stream) {
+    return t2h_cell_order_build_range(off0, B, nbits, level, level, order, stream);
+}
+
+T2H_API int t2h_cell_order_build_range(const int32_t *off0, int B, int nbits, int level_lo, int level_hi, int32_t *order,
+                                       t2h_stream_t stream) {
     if (!off0 || !order) return fail(T2H_ERR_ARG, "cell_order_build: null pointer");
-    if (t2h_cell_order_len(B, nbits, level) == 0) return fail(T2H_ERR_ARG, "cell_order_build: needs 0 <= level < nbits");
-    const int64_t cells = (int64_t)B << (2 * (nbits - level));
+    if (level_lo > level_hi || t2h_cell_order_len(B, nbits, level_lo) == 0 || t2h_cell_order_len(B, nbits, level_hi) == 0)
+        return fail(T2H_ERR_ARG, "cell_order_build: needs 0 <= level_lo <= level_hi < nbits");
     note_kernel("t2h::cell_order_kernel");
-    hipLaunchKernelGGL(cell_order_kernel, dim3(2), dim3(1024), 0, as_stream(stream), off0, cells, 2 * level, order);
+    hipLaunchKernelGGL(cell_order_kernel, dim3(2 * (level_hi - level_lo + 1)), dim3(1024), 0, as_stream(stream), off0, B, nbits,
+                       level_lo, order);
     return check_launch("cell_order_build");
 }
 

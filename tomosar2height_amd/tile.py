@@ -132,13 +132,24 @@ class TileIndex:
         on it.  ``None`` where the level has no such list (the coarsest possible level, a 1 x 1 plane)."""
         hit = self._adjoint.get(("order", level), False)
         if hit is False:
-            n = int(_lib.load().t2h_cell_order_len(self.B, self.nbits, level))
-            hit = None
-            if n > 0 and self.n_points > 0:
-                hit = torch.empty(n, dtype=torch.int32, device=self.device)
-                _lib.call("t2h_cell_order_build", _lib.ptr(self.off0), self.B, self.nbits, level, _lib.ptr(hit), _lib.stream(),
-                          nbytes=8 * n + 8 * (n - n // 5))
-            self._adjoint[("order", level)] = hit
+            # all levels that can take an on-chip walk (1 .. 3) in ONE launch, the first time any of them is asked for
+            lib = _lib.load()
+            lo, hi = 1, min(3, self.nbits - 1)
+            if not (lo <= level <= hi):
+                lo = hi = level
+            lens = [int(lib.t2h_cell_order_len(self.B, self.nbits, lv)) for lv in range(lo, hi + 1)]
+            if min(lens) > 0 and self.n_points > 0:
+                buf = torch.empty(sum(lens), dtype=torch.int32, device=self.device)
+                _lib.call("t2h_cell_order_build_range", _lib.ptr(self.off0), self.B, self.nbits, lo, hi, _lib.ptr(buf),
+                          _lib.stream(), nbytes=16 * sum(lens))
+                at = 0
+                for lv, n in zip(range(lo, hi + 1), lens):
+                    self._adjoint[("order", lv)] = buf[at:at + n]
+                    at += n
+            else:
+                for lv in range(lo, hi + 1):
+                    self._adjoint[("order", lv)] = None
+            hit = self._adjoint[("order", level)]
         return hit
 
     @property
