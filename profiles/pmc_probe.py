@@ -47,16 +47,21 @@ q = torch.randn(32 * 32, 1024, device=dev)
 sums = torch.empty(256 * 256, 1024, device=dev)
 bits = torch.empty(M * 4 * 4, dtype=torch.int64, device=dev)
 lv32 = tile.level(32)
-for _ in range(REPS):
-    _lib.call("t2h_sample_relu_cellsums", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
-              tile.nbits, lv32, 0, 1024, sums.data_ptr(), sums.stride(0), _lib.ptr(bits), _lib.stream())
+order = torch.empty(_lib.load().t2h_cell_order_len(tile.B, tile.nbits, lv32), dtype=torch.int32, device=dev)
+for _ in range(REPS):                                         # r05: the level's longest-first dispatch order (cell_order_kernel)
+    _lib.call("t2h_cell_order_build", _lib.ptr(tile.off0), tile.B, tile.nbits, lv32, _lib.ptr(order), _lib.stream())
+pooled = torch.empty(128 * 128, 1024, device=dev)
+for _ in range(REPS):                                         # as deferred.py calls it: finest sums + the pooled ones, ordered
+    _lib.call("t2h_sample_relu_cellsums_ordered", _lib.ptr(q), _lib.ptr(tile.pts), tile.dim, _lib.ptr(tile.off0), tile.B, tile.N,
+              tile.nbits, lv32, 0, 1024, sums.data_ptr(), sums.stride(0), pooled.data_ptr(), pooled.stride(0), _lib.ptr(bits),
+              _lib.ptr(order), _lib.stream())
 arr, lvs, lds = deferred._plane_args(grads)
 ws_bytes = _lib.ws_bytes("t2h_sample_bwd_workspace_bytes", tile.B, tile.N, tile.nbits, lv32, 1024)
 ws = _lib.workspace(ws_bytes, dev)
 dq = torch.empty(32 * 32, 1024, device=dev)
 for _ in range(REPS):
-    _lib.call("t2h_sample_bwd_from_sums", arr, lvs, lds, len(grads), _lib.ptr(tile.cell), _lib.ptr(bits), 1, _lib.ptr(tile.pts),
+    _lib.call("t2h_sample_bwd_from_sums_ordered", arr, lvs, lds, len(grads), _lib.ptr(tile.cell), _lib.ptr(bits), 1, _lib.ptr(tile.pts),
               tile.dim, _lib.ptr(tile.off0), tile.B, tile.N, tile.nbits, lv32, 1024, _lib.ptr(dq), _lib.ptr(ws), ws_bytes,
-              _lib.stream())
+              _lib.ptr(order), _lib.stream())
 torch.cuda.synchronize()
 print("pmc_probe done")

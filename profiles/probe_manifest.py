@@ -11,7 +11,8 @@ PROBE_GROUPS = [
     [("t2h_segsum_fwd[C=1024,r=256]", ["segmean_fwd_kernel<4, false>"])],
     [("t2h_segsum_bwd_multi[C=1024,n=4]", ["segsum_bwd_multi_kernel"])],
     # r03, hidden activations on chip: sample + ReLU + per-cell sums + sign bits; the backward walk + its pixel gather
-    [("t2h_sample_relu_cellsums[C=1024,r=32]", ["sample_relu_cellsums_kernel"])],
+    [("t2h_cell_order_build[r=32]", ["cell_order_kernel"])],
+    [("t2h_sample_relu_cellsums[C=1024,r=32]", ["sample_relu_cellsums_v2_kernel"])],
     [("t2h_sample_bwd_from_sums[C=1024,r=32]", ["sample_bwd_walk_kernel", "sample_bwd_gather9_kernel"])],
 ]
 
