@@ -17,8 +17,8 @@ from tomosar2height_amd.synthetic import berlin_tile          # noqa: E402
 from tomosar2height_amd.tile import TileIndex                 # noqa: E402
 
 REPS = int(os.environ.get("REPS", "30"))
-FWD = [v for v in os.environ.get("FWD_VARIANTS", "0,1").split(",") if v]
-BWD = [v for v in os.environ.get("BWD_VARIANTS", "0,1").split(",") if v]
+FWD = [v for v in os.environ.get("FWD_VARIANTS", "0,1,1o").split(",") if v]     # 0 = r04 kernel, 1 = r05, o = + dispatch order
+BWD = [v for v in os.environ.get("BWD_VARIANTS", "1,1o").split(",") if v]      # (r05 kernel without / with the dispatch order)
 dev = torch.device("cuda:0")
 tile = TileIndex(berlin_tile(1000, clustered=os.environ.get("UNIFORM", "0") != "1")["inputs"].to(dev), 256)
 M = tile.n_points
@@ -51,9 +51,10 @@ for c2, r in ((1024, 32), (512, 64), (256, 128)):
     med, best = timed(lambda: _lib.call("t2h_cell_order_build", _lib.ptr(tile.off0), tile.B, tile.nbits, lv, _lib.ptr(order), _lib.stream()))
     cells = r * r
     rows = (tile.off0[::4 ** lv][1:] - tile.off0[::4 ** lv][:-1])[order[:cells].long()]
+    key = (rows // max(1, (M // cells + 63) // 64)).clamp(max=2047)         # the sort's key: rows / quantum, capped
     print(f"order r={r}: build {med:.1f} us; is a permutation: {bool((order[:cells].sort().values == torch.arange(cells, device=dev)).all())}, "
-          f"{bool((order[cells:].sort().values == torch.arange(cells // 4, device=dev)).all())}; rows falling: {bool((rows[1:] <= rows[:-1]).all())} "
-          f"({int(rows[0])} .. {int(rows[-1])})", flush=True)
+          f"{bool((order[cells:].sort().values == torch.arange(cells // 4, device=dev)).all())}; keys falling: {bool((key[1:] <= key[:-1]).all())} "
+          f"(rows {int(rows[0])} .. {int(rows[-1])})", flush=True)
     use_order = [False]
 
     def fwd():
