@@ -918,3 +918,46 @@ def test_optimizer_stepped_outside_the_trainer_is_noticed(fused):
         if p.grad is not None:
             scale = p.grad.abs().max().item() + 1e-20
             assert (got[k] - p.grad).abs().max().item() <= 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_out_of_domain_points_are_raised_at_the_optimizer_boundary_without_draining_the_queue(pipelined):
+    """``Trainer(check_domain=True)`` (default): a tile with points outside [0, 1)^2 -- the reference's scatter would index out of
+    range (coordinate.py:12-28) -- makes the optimizer boundary raise BEFORE the optimizer consumes the window, with the
+    accumulators reset; a clean window then trains normally.  r05: the count reaches the host through per-tile snapshots taken
+    right after each tile's index is built (pointnet.py), so the boundary waits for the last tile's ``tile_build`` only: the read
+    must not be a device-wide synchronisation (torch's sync debug mode would raise on ``.item()``), and the totals of BOTH tile
+    streams' status pairs count."""
+    from tomosar2height_amd import TomoSAR2Height
+    from tomosar2height_amd.config import berlin_config
+    from tomosar2height_amd.trainer import Trainer
+    cfg = berlin_config()
+    cfg.model.encoder_kwargs.unet_kwargs.depth = 4
+    model = det_init_(TomoSAR2Height(cfg), seed=19).to(_dev())
+    model.set_channels_last(True)
+    tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=1e-3), device=_dev(), optimize_every=4, use_cloud=True)
+    tr.pipeline_tiles = pipelined
+    dsm = (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(0)) * 30).to(_dev())
+    clouds = [synth_cloud(20000, seed=950 + i).to(_dev()) for i in range(12)]
+    for c in clouds[:4]:                                           # a clean window (the first tile lays out the bucket)
+        stepped = tr.train_step({"inputs": c, "dsm": dsm})
+    assert stepped
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    bad = [c.clone() for c in clouds[4:8]]
+    bad[1][0, :3, 0] = 1.5                                         # 3 points on one tile stream's tile ...
+    bad[2][0, :2, 1] = -0.25                                       # ... 2 on the other's
+    for c in bad[:3]:
+        assert tr.train_step({"inputs": c, "dsm": dsm}) is False
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")                        # the boundary's read may wait for events, not for the device
+    try:
+        with pytest.raises(ValueError, match=r"5 input point\(s\)"):
+            tr.train_step({"inputs": bad[3], "dsm": dsm})
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert tr.accumulated_steps == 0 and float(tr.bucket.flat.abs().sum()) == 0.0
+    for k, p in model.named_parameters():
+        assert torch.equal(p, before[k]), k                        # the optimizer has not consumed the bad window
+    for c in clouds[8:12]:
+        stepped = tr.train_step({"inputs": c, "dsm": dsm})
+    assert stepped and any(not torch.equal(p, before[k]) for k, p in model.named_parameters())

@@ -48,6 +48,13 @@ class LocalPoolPointnet(nn.Module):
         # its own stream) must not share the pair -- one tile's reset would race the other's atomics.  ``domain_status`` serves
         # the first stream seen; the running totals (status[1]) of all of them are summed by out_of_domain_total()
         self._status_by_stream = {}
+        # snapshot_domain (set by the Trainer): right after a tile's index is built its status pair's running total is copied to
+        # pinned host memory in stream order (8 bytes + an event).  out_of_domain_total() then waits for the LATEST snapshot of
+        # every pair -- i.e. for the last tile's tile_build, the first kernels of its forward -- instead of reading the device
+        # counters with .item(), which waits for everything queued: at an optimizer boundary that drained the tile pipeline and
+        # left the chip idle while the host issued the next forward (~3 ms per boundary)
+        self.snapshot_domain = False
+        self._domain_snaps = {}          # id(status tensor) -> [event, pinned int32[2], status tensor]
 
     def set_channels_last(self, flag: bool):
         """Keep the grid side in channels_last memory so planes need no NCHW<->NHWC copies."""
@@ -60,15 +67,40 @@ class LocalPoolPointnet(nn.Module):
         points were clamped into the border cells; the reference would index out of range (coordinate.py:12-28)."""
         extra = [st for st in self._status_by_stream.values() if st is not self.domain_status
                  and st.device == self.domain_status.device]
-        if extra:                                           # (the caller's stream has joined the tile streams: Trainer.flush_pipeline)
-            n = int(torch.stack([self.domain_status] + extra)[:, 1].sum().item())
+        pairs = [self.domain_status] + extra
+        used = self.__dict__.setdefault("_used_pairs", set())
+        snaps = [self._domain_snaps.get(id(st)) for st in pairs]
+        if self.snapshot_domain and all((sn is not None and sn[3]) or id(st) not in used for sn, st in zip(snaps, pairs)):
+            n = 0
+            for sn, st in zip(snaps, pairs):                # (a pair no tile has used since the reset holds 0)
+                if id(st) in used:
+                    sn[0].synchronize()
+                    n += int(sn[1][1])
+        elif extra:                                         # (the caller's stream has joined the tile streams: Trainer.flush_pipeline)
+            n = int(torch.stack(pairs)[:, 1].sum().item())
         else:
             n = int(self.domain_status[1].item())
+        if reset:
+            used.clear()
+            for sn in self._domain_snaps.values():
+                sn[3] = False
         if reset and n:
             self.domain_status.zero_()
             for st in extra:
                 st.zero_()
         return n
+
+    def _snapshot(self, status):
+        """Called by every forward right after its tile index exists (see ``snapshot_domain``)."""
+        self.__dict__.setdefault("_used_pairs", set()).add(id(status))
+        if not self.snapshot_domain:
+            return
+        ent = self._domain_snaps.get(id(status))
+        if ent is None:
+            ent = self._domain_snaps[id(status)] = [torch.cuda.Event(), torch.empty(2, dtype=torch.int32, pin_memory=True), status, False]
+        ent[1].copy_(status, non_blocking=True)
+        ent[0].record()
+        ent[3] = True
 
     def _status_for(self, raw_stream: int) -> torch.Tensor:
         hit = self._status_by_stream.get(raw_stream)
@@ -98,6 +130,7 @@ class LocalPoolPointnet(nn.Module):
             tile = TileIndex(inputs, self.reso_plane, status=self._status_for(_lib.stream()))
         if self.check_domain:
             tile.check_domain()
+        self._snapshot(tile.status)
         net = self.point_features(tile)
         if self.unet_type == "alto":      # net also feeds ALTO's first fc_c: one fused gradient sum (ops.rasterise_mean_thru)
             plane, net = ops.rasterise_mean_thru(tile, net, self.reso_plane, self.channels_last)      # pointnet.py:83

@@ -122,6 +122,10 @@ class Trainer:
             from . import deferred
             self.compose_cache = deferred.ComposeCache()
 
+        enc = getattr(model, "point_encoder", None)
+        if check_domain and enc is not None and hasattr(enc, "snapshot_domain"):
+            enc.snapshot_domain = True          # the boundary's out-of-domain read waits for the last tile's index only (pointnet.py)
+        self._flag_stream = None
         self.accumulated_steps = 0
         self.accumulated_loss = 0.0
         self.accumulated_loss_dict = {"loss_ce": 0.0, "loss_l1": 0.0}
@@ -191,6 +195,7 @@ class Trainer:
         the step is GPU-bound (measured: no gain); it pays for small tiles."""
         if self.bucket is None:
             raise RuntimeError("capture_graph: run one eager train_step first (the gradient bucket must exist)")
+        self._snapshots_off()
         dev = self.device
         static = {k: example[k].to(dev).clone() for k in ("inputs", "image", "dsm") if example.get(k) is not None}
         self.model.train()
@@ -229,6 +234,7 @@ class Trainer:
         stay on the tile's stream inside the graphs (graph branches measured slower than a linear graph on this stack)."""
         if self.bucket is None:
             raise RuntimeError("capture_pipeline_graphs: run one eager train_step first (the gradient bucket must exist)")
+        self._snapshots_off()
         self.flush_pipeline()
         dev = self.device
         main = torch.cuda.current_stream(dev)
@@ -263,6 +269,13 @@ class Trainer:
             self.compose_cache.restore(saved_cache)
         self._pipe_graphs = {"sets": sets, "shapes": {k: tuple(v.shape) for k, v in sets[0]["static"].items()}}
         return self._pipe_graphs
+
+    def _snapshots_off(self):
+        """hipGraph replays run no Python per tile: the out-of-domain totals are then read from the device at the boundary (the
+        snapshot's event record inside a capture could not be waited for from the host)."""
+        enc = getattr(self.model, "point_encoder", None)
+        if enc is not None and hasattr(enc, "snapshot_domain"):
+            enc.snapshot_domain = False
 
     def _pipe_graphs_match(self, data) -> bool:
         g = getattr(self, "_pipe_graphs", None)
@@ -496,10 +509,20 @@ class Trainer:
             # and learning rate of the last good step, with empty accumulators
             bad = self.model.out_of_domain_total()
             if self.world > 1:
-                # every rank must take the same branch (the all-reduce above has already happened on all of them)
-                flag = torch.tensor([float(bad)], device=self.bucket.flat.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
-                bad = int(flag.item())
+                # every rank must take the same branch (the all-reduce above has already happened on all of them).  On a stream
+                # of its own: the collective and the .item() then wait for nothing but each other, not for the tile streams
+                dev = self.bucket.flat.device
+                if dev.type == "cuda":
+                    if self._flag_stream is None:
+                        self._flag_stream = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(self._flag_stream):
+                        flag = torch.tensor([float(bad)], device=dev)
+                        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+                        bad = int(flag.item())
+                else:
+                    flag = torch.tensor([float(bad)], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+                    bad = int(flag.item())
             if bad:
                 self._reset_accumulators()
                 raise ValueError(f"{bad} input point(s) of the last {self.optimize_every} tile(s) had x or y outside [0, 1) "
