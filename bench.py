@@ -114,6 +114,10 @@ def parse():
     ap.add_argument("--pin-cores", type=int, default=1,
                     help="N > 1: bind every rank to its own CPU cores (NUMA-local to its GPU where sysfs tells) before the GPU is "
                          "initialised; 0 = leave the affinity alone")
+    ap.add_argument("--micro-batch-steps", type=int, default=32,
+                    help="tile-steps of a THIRD short timed leg with the accumulation window micro-batched: 4 tiles of different "
+                         "point counts per forward / backward (Trainer.train_step([tiles]): the same accumulated gradient to fp32 "
+                         "re-association); reported as `micro_batched`, never part of `value` (0: skip; only with --train-batch 1)")
     ap.add_argument("--exact-split-steps", type=int, default=16,
                     help="tile-steps of a SECOND short timed leg with the 3x3 / transposed convolutions on the exact three-way bf16 "
                          "split (six MFMAs per product: fp32 arithmetic bit for bit up to summation order) instead of the default "
@@ -137,7 +141,7 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json (rocprofv3 --pmc passes, profile {d.get('tag', '?')})"
+        return d.get("bytes_per_launch", {}), f"profiles/pmc_traffic.json ({d.get('tag', '?')})"
     except (OSError, ValueError):
         return {}, None
 
@@ -168,7 +172,7 @@ def rocprof_durations():
     try:
         with open(os.path.join(ROOT, "profiles", "rocprof_kernels.json")) as f:
             d = json.load(f)
-        return {k: v["avg_us"] for k, v in d.get("kernels", {}).items()}, f"profiles/rocprof_kernels.json (tag {d.get('tag', '?')})"
+        return {k: v["avg_us"] for k, v in d.get("kernels", {}).items()}, f"profiles/rocprof_kernels.json ({d.get('tag', '?')})"
     except (OSError, ValueError, KeyError):
         return {}, None
 
@@ -728,12 +732,50 @@ def main():
                 es = float(tmax.item())
             exact_split = {"value": round(world * args.exact_split_steps / es, 3), "ms_per_step": round(1e3 * es / args.exact_split_steps, 3),
                            "steps": args.exact_split_steps,
-                           "arithmetic": "3x3 / transposed convolutions and wide grid-side products: exact 3-way bf16 operand split, "
-                                         "6 MFMAs per product, fp32 accumulate (T2H_CONV_PRECISION=bf16x3)"}
+                           "arithmetic": "bf16x3: convolutions + wide grid-side products on the exact 3-way bf16 split, 6 MFMAs per product"}
         finally:
             trainer.flush_pipeline()
             grid.set_conv_precision(None)
             run(2)                                            # back on the default arithmetic before the next leg
+            fence()
+
+    # ---- leg 1d: the same accumulation window micro-batched (never part of `value`): 4 ragged tiles per forward / backward.  The
+    # reference runs its 64 tiles one at a time only because their point counts differ (tomosar2height.yaml:40); they are
+    # independent and their gradients are summed (trainer.py:69-89), so this is the same training step with a quarter of the
+    # launches per tile -- what takes the host out of a B = 1 step
+    micro_batched = None
+    if (args.micro_batch_steps > 0 and args.mode == "train" and args.train_batch == 1 and not args.hip_graph and source is None
+            and tile_stream is None and args.optimize_every % (4 * world) == 0):
+        trainer.flush_pipeline()
+        keep_tiles, keep_j = list(tiles), state.get("j", -1)
+        rag = (-0.10, 0.06, -0.04, 0.08)
+        pool = []
+        for i in range(8):
+            t = berlin_tile(seed=1000 * rank + 500 + i, n_points=int(round(args.points * (1.0 + rag[i % 4]))),
+                            clustered=not args.uniform_xy, with_image=args.use_image)
+            pool.append({k: t[k].to(dev) for k in (("inputs", "dsm", "image") if args.use_image else ("inputs", "dsm"))})
+        tiles[:] = pool
+        args.train_batch = 4
+        try:
+            n_mb = max(4, args.micro_batch_steps // 4 * 4)
+            trainer.accumulated_steps = trainer.accumulated_steps // 4 * 4        # (micro-batches never cross an optimizer boundary)
+            run(16)
+            fence()
+            tm = time.perf_counter()
+            run(n_mb)
+            fence()
+            em = time.perf_counter() - tm
+            if world > 1:
+                tmax = torch.tensor([em], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                em = float(tmax.item())
+            micro_batched = {"value": round(world * n_mb / em, 3), "ms_per_tile": round(1e3 * em / n_mb, 3), "tiles": n_mb,
+                             "tiles_per_forward": 4, "points": "ragged, -10..+8 % around --points"}
+        finally:
+            args.train_batch = 1
+            tiles[:] = keep_tiles
+            state["j"] = keep_j
+            run(2)
             fence()
 
     # ---- leg 2: per-launch HIP events (every rank runs it: the optimizer boundaries inside are collective)
@@ -808,8 +850,7 @@ def main():
                        "grid_convs": ({"bf16x3": "t2h csrc/conv_bx3.hip: every fp32 product from six bf16 MFMAs (exact 3-way operand "
                                                  "split, fp32 accumulate; error vs float64 = the fp32 MFMA kernels'), planes >= 32 wide; "
                                                  "csrc/conv.hip (fp32 MFMA) for the rest",
-                                       "f16x2": "t2h conv_bx3.hip: fp32 products from 3 fp16 MFMAs (2-way operand split, power-of-two "
-                                                "block scales, fp32 accumulate; error vs float64 at the fp32 kernels' level)",
+                                       "f16x2": "conv_bx3.hip: fp32 products from 3 fp16 MFMAs (2-way split, block scales; DESIGN 4.1b)",
                                        "bf16": "t2h csrc/conv_bx3.hip, operands rounded to bf16 (one MFMA per product, fp32 accumulate)",
                                        "fp32": "t2h implicit-GEMM on fp32 MFMA (csrc/conv.hip)"}[grid.CONV_PRECISION]
                                       if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen"),
@@ -847,8 +888,7 @@ def main():
                     out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
-                out["roofline"]["how"] = (f"HIP events around every launch of {args.profile_steps} untimed tile-steps, "
-                                          "overlaps off (kernels alone)")
+                out["roofline"]["how"] = f"HIP events per launch, {args.profile_steps} untimed steps, overlaps off"
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 # (compact: peak and unit are those of `bound` -- 8000 GB/s for hbm, 157.3 TFLOP/s fp32 MFMA for mfma)
                 out["roofline_scatter_reduce"] = [{k: v for k, v in roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"]))).items()
@@ -871,6 +911,8 @@ def main():
                 out["config"]["kernel_table"] = f"not written: {e}"
         if exact_split is not None:
             out["exact_split"] = exact_split
+        if micro_batched is not None:
+            out["micro_batched"] = micro_batched
         if sustained is not None:
             out["sustained"] = sustained
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
@@ -889,7 +931,7 @@ def main():
                             "cores_per_rank": [len(c) for c in sets],
                             "affinity_disjoint": bool(all(sets)) and all(not (sets[i] & sets[j]) for i in range(world)
                                                                          for j in range(i + 1, world)),
-                            "cpus": [r["cpus"] if len(r["cpus"]) <= 24 else r["cpus"][:21] + "..." for r in per_rank]}
+                            "first_cpu": [min((int(c) for c in st), default=-1) for st in sets]}
         if world == 1 and not args.skip_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)          # last: the GPU legs above run back to back
         print(json.dumps(out), flush=True)
