@@ -676,11 +676,11 @@ __global__ __launch_bounds__(256) void sample_relu_cellsums_kernel(const float *
                     nb0 = n; have = true;
                     const int nn = min(n + lane, npts_m1);                // rows past this cell belong to later cells: valid
                     const Taps tp = make_taps(pts[(size_t)nn * dim + 0], pts[(size_t)nn * dim + 1], r);
-                    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                    const float fx1 = (float)min(max(r - 1 - tp.x0, 0), 1), fy1 = (float)min(max(r - 1 - tp.y0, 0), 1);
                     nw_l = __fmul_rn(tp.wx0, tp.wy0);
-                    ne_l = x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.f;
-                    sw_l = y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.f;
-                    se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
+                    ne_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy0), fx1);      // (no compare -> mask -> select here: see the v2 kernel)
+                    sw_l = __fmul_rn(__fmul_rn(tp.wx0, tp.wy1), fy1);
+                    se_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy1), __fmul_rn(fx1, fy1));
                     slot_l = min(max(tp.y0 - cy + 1, 0), 1) * 3 + min(max(tp.x0 - cx + 1, 0), 1);     // 0 or 1 each by construction
                 }
                 const int i0 = n - nb0, cnt = min(e - n, 64 - i0);        // rows of this child inside the current batch
@@ -845,11 +845,19 @@ __global__ __launch_bounds__(256, 2) void sample_relu_cellsums_v2_kernel(const f
                     const Taps tp = make_taps(pxy.x, pxy.y, r);
                     if (nb0 + 64 < row_end)                               // the next 64 rows' coordinates, under this batch's rows
                         pxy = *reinterpret_cast<const float2 *>(pts + (size_t)min(nb0 + 64 + lane, npts_m1) * dim);
-                    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                    // 1.0 where the east / south tap lies inside the plane, else 0.0 -- by integer min / max and a product (p * 1 = p,
+                    // p * 0 = +0 for these non-negative finite p: the same bits as a select).  NOT `x1ok ? p : 0`: that compiles to
+                    // v_cmp -> SGPR pair -> s_and_b64 + v_cndmask, and with the split-convolution kernels (conv_bx3.hip) resident on
+                    // the same CU the select of a wave's FIRST 64 rows saw the mask with its last quarter (lanes 48..63) cleared --
+                    // 16 rows sampled without their east tap, a few cells' sums off by 1e-2 relative, 4-50 % of pipelined steps
+                    // (r05: profiles/r05_coresidency.txt; found by replaying one backward's calls beside this kernel on a second
+                    // stream; both this kernel and its r04 form, alone or beside any other kernel never).  The weights live for
+                    // 64 rows, so one lost quarter is amplified; tests/test_coresidency.py keeps watch
+                    const float fx1 = (float)min(max(r - 1 - tp.x0, 0), 1), fy1 = (float)min(max(r - 1 - tp.y0, 0), 1);
                     nw_l = __fmul_rn(tp.wx0, tp.wy0);
-                    ne_l = x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.f;
-                    sw_l = y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.f;
-                    se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
+                    ne_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy0), fx1);
+                    sw_l = __fmul_rn(__fmul_rn(tp.wx0, tp.wy1), fy1);
+                    se_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy1), __fmul_rn(fx1, fy1));
                     // slot of the north-west tap in the staged window (a tap outside the plane has weight 0 and reads the
                     // staged zero -- the sample kernel skips it: the same value)
                     slot_l = (min(max(tp.y0 - cy + 1, 0), 1) + (K ? (wave >> 1) : 0)) * SIDE +
