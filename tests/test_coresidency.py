@@ -137,20 +137,25 @@ def test_walks_beside_the_split_convolutions_are_bit_identical():
 
 
 @gpu
-@pytest.mark.parametrize("ahead", [False, True], ids=["lazy", "prepared"])
-def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead):
-    """8 four-tile windows through the tile pipeline (with tile indices built ahead on a side stream, or inside the step), each against
-    the same window with a device synchronise after every step: losses and all 147 gradients bit for bit, every time -- before the
-    fix above 4-50 % of the windows differed."""
+@pytest.mark.parametrize("ahead,points,image,windows", [(False, 40000, False, 8), (True, 40000, False, 8), (False, 131072, False, 4),
+                                                        (False, 40000, True, 4)],
+                         ids=["lazy", "prepared", "benchmark-size", "cloud+image"])
+def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, points, image, windows):
+    """Four-tile windows through the tile pipeline (tile indices built ahead on a side stream or inside the step; the benchmarked
+    N = 131 072; BASELINE configs[2] with the image U-Net), each against the same window with a device synchronise after every step:
+    losses and every gradient bit for bit, every time -- before the fix above 4-50 % of the windows differed."""
     det_init_, synth_cloud, TomoSAR2Height, berlin_config, Trainer = _setup()
     dev = torch.device("cuda:0")
-    tiles = _tiles(synth_cloud, dev, 4)
-    cfg = berlin_config()
+    tiles = _tiles(synth_cloud, dev, 4, points)
+    if image:
+        for i, t in enumerate(tiles):
+            t["image"] = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(40 + i)).to(dev)
+    cfg = berlin_config(use_image=image)
 
     def run(ahead, stepsync):
         model = det_init_(TomoSAR2Height(cfg), seed=15).to(dev)
         model.set_channels_last(True)
-        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True, use_image=image)
         side = torch.cuda.Stream() if ahead else None
         prep = (lambda t: tr.prepare(t, side)) if ahead else (lambda t: t)
         losses, inner = [], tr._losses
@@ -174,7 +179,7 @@ def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead):
 
     gold, gold_losses = run(False, True)
     differing = []
-    for it in range(8):
+    for it in range(windows):
         got, losses = run(ahead, False)
         n = sum(not torch.equal(got[k], gold[k]) for k in gold)
         if n or losses != gold_losses:
