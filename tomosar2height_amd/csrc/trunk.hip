@@ -655,7 +655,14 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
         // register q of the C/D layout holds row rb + ro(q), ro(q) = (q & 3) + 8 (q >> 2): one base, constant offsets
         const int rb = wrow0 + 4 * h;
 #define T2H_RO(q) (((q) & 3) + 8 * ((q) >> 2))
-#define T2H_ROW_OK(q) (rb + T2H_RO(q) < r1)
+        // "row q of this lane lies inside the cloud" (false only in the last workgroup), compared AFRESH at every use (`fresh` hides
+        // the row from common-subexpression elimination): left to itself the compiler computes the sixteen compares once per tile and
+        // parks them in SGPR pairs across ~1000 instructions, and a parked compare result is what the r05 co-residency fault eats
+        // (point_grid.hip's forward walk; profiles/r05_coresidency.txt).  Also 24 VGPRs cheaper here.  Not in the FIRST variant: it
+        // is at the register limit and spills with any of the three rewrites tried; it remains the one call the dense replay of
+        // profiles/coresidency_audit.py still catches (1 of ~70 launches beside the split convolutions), with or without these masks
+        auto fresh = [](int v) { if constexpr (!FIRST) asm volatile("" : "+v"(v)); return v; };
+#define T2H_ROW_OK(q) (fresh(rb) + T2H_RO(q) < r1)
         // hr in the C/D layout, requested before the g stage: its barriers keep the compiler from hoisting the loads itself
         float hr_cd[16];
 #pragma unroll
