@@ -332,8 +332,9 @@ int t2h_upsample_bilinear_bwd(const float *gout, int B, int C, int h, int w, int
  *   t2h_head1x1_fwd/bwd out[p] = bias + sum_i <w_i, x_i[p,:]> over up to 4 inputs: torch.cat([x,x1,x2,x3]) + the 1x1
  *                       conv4 of ConvDecoder (pixel.py:31) without materialising the 288-channel concat; backward gives
  *                       dx_i = [dx_i +] g[p] w_i, dw (Ctot floats, concatenated order) and dbias.  out_channels = 1.
- *                       dx_flags: bit 0 = accumulate into dx_i; bit 8+i = multiply dx_i by (x_i > 0), i.e. hand the
- *                       producer of a ReLU output x_i a gradient that already passed its ReLU backward.
+ *                       dx_flags: bit 0 = accumulate into dx_i; bit 1 = add to what dw / dbias hold (the trainer's gradient
+ *                       bucket) instead of overwriting; bit 8+i = multiply dx_i by (x_i > 0), i.e. hand the producer of a ReLU
+ *                       output x_i a gradient that already passed its ReLU backward.
  *   t2h_upsample_bilinear_nhwc_fwd/bwd   F.interpolate(bilinear, align_corners=True) on NHWC planes (pixel.py:107,110) */
 int t2h_bias_relu_fwd(float *y, const float *bias, int64_t P, int C, int relu, t2h_stream_t stream);
 size_t t2h_bias_relu_bwd_workspace_bytes(int64_t P, int C);

@@ -6,7 +6,7 @@ Every call of one tile's forward and backward (the victim, recorded on stream A)
       streams' allocator pools are disjoint, so the competitor never writes what the victim reads),
 and after each run every allocator block that one of the victim's pointer arguments points into is copied to the host and hashed.
 
-    python profiles/coresidency_audit.py [trials] [competitor: bx3 | walks | all] [competitor passes per trial]
+    python profiles/coresidency_audit.py [trials] [competitor: bx3 | walks | all | mfma] [competitor passes per trial]
 
 Output: one line per victim call that differs, and a summary per entry point.  Findings: profiles/r05_coresidency.txt."""
 import ctypes
@@ -33,11 +33,15 @@ hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 MAX_BLOCK = 300 << 20
 
+IMAGE = os.environ.get("T2H_AUDIT_IMAGE") == "1"        # BASELINE configs[2]: with the image U-Net
 tiles = [{"inputs": synth_cloud(40000, seed=700 + i).to(dev),
           "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(dev)} for i in range(4)]
-model = det_init_(TomoSAR2Height(berlin_config()), seed=15).to(dev)
+if IMAGE:
+    for i, t in enumerate(tiles):
+        t["image"] = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(40 + i)).to(dev)
+model = det_init_(TomoSAR2Height(berlin_config(use_image=IMAGE)), seed=15).to(dev)
 model.set_channels_last(True)
-tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True)
+tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True, use_image=IMAGE)
 tr.pipeline_tiles = False
 tr.overlap_wgrad = tr.overlap_conv_wgrad = False
 tr.train_step(tiles[0])
@@ -73,6 +77,14 @@ if which == "bx3":
     comp = [c for c in comp_all if "bx3" in c[0]]
 elif which == "walks":
     comp = [c for c in comp_all if "sample_" in c[0] or "segsum" in c[0] or "trunk" in c[0] or "pool" in c[0]]
+elif which == "mfma":        # the synthetic aggressor: a pure v_mfma_f32_16x16x32_f16 loop (profiles/coresidency_aggressor.hip)
+    ag = ctypes.CDLL(os.path.abspath(os.environ.get("T2H_AGGR_LIB", "scratch/libaggr.so")))
+    ag.aggr_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    dummy = torch.zeros(16, device=dev)
+
+    def _aggr(name, *a):
+        assert ag.aggr_launch(3, dummy.data_ptr(), 512, 2000, torch.cuda.current_stream().cuda_stream) == 0
+    comp = [("aggr", ())] * 2
 else:
     comp = comp_all
 print(f"{len(victims)} victim calls ({n_fwd} forward), {len(comp)} competitor calls ({which})")
@@ -169,7 +181,7 @@ for idx, (name, args) in enumerate(victims):
         with torch.cuda.stream(B):
             for _ in range(dense):
                 for cn, ca in comp:
-                    orig(cn, *ca)
+                    (_aggr if cn == "aggr" else orig)(cn, *ca)
         with torch.cuda.stream(A):
             for _ in range(3 * dense):
                 orig(name, *args)

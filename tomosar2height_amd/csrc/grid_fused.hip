@@ -92,6 +92,27 @@ __global__ __launch_bounds__(kT) void reduce_rows_kernel(const float *__restrict
     }
 }
 
+// the head's weight-gradient partials [nblocks][Ctot + 4] -> dw[0 .. Ctot) and dbias (column Ctot), written or accumulated: the
+// same fixed tree as reduce_rows_kernel, results straight to their destinations (r04: a scratch row + two device copies)
+__global__ __launch_bounds__(kT) void head_finish_kernel(const float *__restrict__ partial, int nblocks, int Ctot, int accumulate,
+                                                         float *__restrict__ dw, float *__restrict__ dbias) {
+    __shared__ float red[kT];
+    const int C = Ctot + 4;
+    const int el = threadIdx.x & (kRedCh - 1), q = threadIdx.x / kRedCh;
+    const int c = blockIdx.x * kRedCh + el;
+    float s = 0.f;
+    if (c <= Ctot)
+        for (int b = q; b < nblocks; b += kRedLanes) s += partial[(size_t)b * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (q == 0 && c <= Ctot) {
+        float t = red[el];
+        for (int k = 1; k < kRedLanes; ++k) t += red[k * kRedCh + el];
+        float *dst = c < Ctot ? dw + c : dbias;
+        if (dst) *dst = accumulate ? *dst + t : t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- concat-free 1x1 head
 struct HeadArgs {
     const float *x[4];
@@ -427,17 +448,10 @@ T2H_API int t2h_head1x1_bwd(const float *const *x, float *const *dx, const int *
     int nblocks = (int)((P + kRowsPerBlock - 1) / kRowsPerBlock);
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(head1x1_wgrad_kernel, dim3(nblocks), dim3(kT), 0, s, a, g, (long long)P, partial);
-    // columns [0, Ctot) -> dw, column Ctot -> dbias; row stride Ctot + 4
-    // reduce_rows_kernel expects a dense [nblocks][C] matrix: treat the padded row as C = Ctot + 4 into a scratch tail
-    float *tail = partial + (size_t)nblocks * (a.Ctot + 4);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((a.Ctot + 4 + kRedCh - 1) / kRedCh), dim3(kT), 0, s, partial, nblocks, a.Ctot + 4, 0, tail);
-    rc = check_launch("head1x1_bwd");
-    if (rc) return rc;
-    if (hipMemcpyAsync(dw, tail, (size_t)a.Ctot * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return check_launch("head1x1_bwd/copy dw");
-    if (dbias && hipMemcpyAsync(dbias, tail + a.Ctot, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return check_launch("head1x1_bwd/copy db");
-    return T2H_OK;
+    // columns [0, Ctot) -> dw, column Ctot -> dbias (row stride Ctot + 4); dx_flags bit 1: added to what dw / dbias hold
+    hipLaunchKernelGGL(head_finish_kernel, dim3((a.Ctot + 1 + kRedCh - 1) / kRedCh), dim3(kT), 0, s, partial, nblocks, a.Ctot,
+                       (dx_flags >> 1) & 1, dw, dbias);
+    return check_launch("head1x1_bwd");
 }
 
 T2H_API int t2h_maxpool2x2_nhwc_fwd(const float *in, int B, int H, int W, int C, float *out, uint8_t *which, t2h_stream_t stream) {

@@ -706,18 +706,29 @@ def _head_bwd(xs, dxs, weight, bias, g, relu_inputs=()):
     chans = [x.shape[1] for x in xs]
     ctot = sum(chans)
     wflat = weight.reshape(-1).contiguous()
-    dw = torch.empty(ctot, dtype=torch.float32, device=g.device)
-    db = torch.empty(1, dtype=torch.float32, device=g.device) if bias is not None else None
+    # under mlp.direct_grad_accumulation: straight into the existing .grad buffers (the trainer's bucket), (None, None) returned --
+    # r05: this head was the last layer whose gradients still went through autograd's AccumulateGrad (two adds per tile, and in the
+    # tile pipeline a hop to the stream the accumulator node was created on)
+    wg, bg = weight.grad, (bias.grad if bias is not None else None)
+    direct = (mlp._DIRECT_ACCUM and wg is not None and wg.is_contiguous() and wg.numel() == ctot
+              and (bias is None or (bg is not None and bg.is_contiguous())))
+    if direct:
+        dw, db = wg, bg
+    else:
+        dw = torch.empty(ctot, dtype=torch.float32, device=g.device)
+        db = torch.empty(1, dtype=torch.float32, device=g.device) if bias is not None else None
     ws_bytes = _lib.ws_bytes("t2h_head1x1_bwd_workspace_bytes", b * h * w, ctot)
     ws = _lib.workspace(ws_bytes, g.device)
     xarr, dxarr = _ptr_array(xs), _ptr_array(dxs)
     carr = (ctypes.c_int * len(xs))(*chans)
-    flags = sum(1 << (8 + i) for i in relu_inputs)
+    flags = sum(1 << (8 + i) for i in relu_inputs) | (2 if direct else 0)
     nmask = sum(chans[i] for i in relu_inputs)
     _lib.call("t2h_head1x1_bwd", ctypes.cast(xarr, ctypes.c_void_p), ctypes.cast(dxarr, ctypes.c_void_p),
               ctypes.cast(carr, ctypes.c_void_p), len(xs), _lib.ptr(wflat), _lib.ptr(g), b * h * w, flags, _lib.ptr(dw),
               _lib.ptr(db) if db is not None else None, _lib.ptr(ws), ws_bytes, _lib.stream(),
               nbytes=4 * (2 * ctot + nmask + 1) * b * h * w)
+    if direct:
+        return None, None
     return dw.reshape(weight.shape), db
 
 
