@@ -13,9 +13,9 @@ R=$GRAFT_REPO_ROOT
 # the profiler passes time kernels ALONE (side streams and the tile pipeline off), like the per-kernel leg inside bench.py whose durations they must agree
 # with; the bench legs further down run the product's default (weight gradients on side streams)
 export T2H_OVERLAP_WGRAD=0 T2H_OVERLAP_CONV_WGRAD=0 T2H_PIPELINE_TILES=0
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 > $OUT/trace_bench.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/probe_fetch -o p --output-format csv -- python3 $R/profiles/pmc_probe.py > /dev/null 2> $OUT/probe_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/probe_write -o p --output-format csv -- python3 $R/profiles/pmc_probe.py > /dev/null 2> $OUT/probe_write.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace_infer -o t --output-format csv -- python3 $R/bench.py --mode infer --batch 4 --hip-graph 1 --steps 12 --warmup 4 > $OUT/infer_bench.json 2> $OUT/trace_infer.err
