@@ -68,6 +68,32 @@ def test_head1x1_matches_cat_conv():
         assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * scale
 
 
+def test_head1x1_weight_gradient_accumulates_into_existing_grads():
+    """r05: under ``mlp.direct_grad_accumulation`` the head's weight / bias gradient is ADDED to the ``.grad`` buffers that exist
+    (the trainer's bucket; ``t2h_head1x1_bwd`` dx_flags bit 1) and autograd receives ``None`` for them: exactly the gradient
+    of the plain path on top of what the buffers held, bit for bit (the same fixed summation tree, one more addition)."""
+    from tomosar2height_amd import grid, mlp
+    g = torch.Generator().manual_seed(5)
+    conv = torch.nn.Conv2d(288, 1, 1).to(_dev())
+    xs = [_cl(torch.randn(1, c, 40, 40, generator=g)).requires_grad_(True) for c in (32, 64, 128, 64)]
+    gout = torch.randn(1, 1, 40, 40, generator=g).to(_dev())
+    grid.head1x1(xs, conv).backward(gout)
+    plain_w, plain_b, plain_x = conv.weight.grad.clone(), conv.bias.grad.clone(), [x.grad.clone() for x in xs]
+    held_w, held_b = torch.randn_like(conv.weight), torch.randn_like(conv.bias)
+    conv.weight.grad, conv.bias.grad = held_w.clone(), held_b.clone()
+    for x in xs:
+        x.grad = None
+    seen = []
+    hooks = [conv.weight.register_hook(lambda gr: seen.append(gr)), conv.bias.register_hook(lambda gr: seen.append(gr))]
+    with mlp.direct_grad_accumulation(True):
+        grid.head1x1(xs, conv).backward(gout)
+    for h in hooks:
+        h.remove()
+    assert seen == [None, None]                                        # nothing went through autograd's accumulation
+    assert torch.equal(conv.weight.grad, held_w + plain_w) and torch.equal(conv.bias.grad, held_b + plain_b)
+    assert all(torch.equal(x.grad, p) for x, p in zip(xs, plain_x))
+
+
 @pytest.mark.parametrize("b,c,h,size", [(1, 32, 256, 512), (2, 8, 16, 32), (1, 4, 7, 19)])
 def test_upsample_cl_vs_oracle(b, c, h, size):
     from tomosar2height_amd import grid
