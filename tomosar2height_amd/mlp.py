@@ -64,7 +64,7 @@ def _rows(t: torch.Tensor, what: str):
 GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
 
 
-_BX3_MIN_N = int(os.environ.get("T2H_GEMM_BX3_MIN_N", "128"))
+_BX3_MIN_N = int(os.environ.get("T2H_GEMM_BX3_MIN_N", "64"))
 _BX3_MIN_K = int(os.environ.get("T2H_GEMM_BX3_MIN_K", "128"))
 
 
@@ -72,7 +72,9 @@ def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
     """Where the split form (csrc/conv_bx3.hip, 1-tap) wins, measured.  Every staged A element has to be split and is then used for
     n outputs, and the kernel streams A with one chunk in flight per workgroup: with the bf16 three-way split narrow outputs lost
     (the r = 256 level product 2752 -> 64: 250 us on fp32 MFMA, 278 us split); with the fp16 two-way split and the weights fetched
-    straight into registers (r04d) it is 197 us (profiles/gemm_layout_probe.py), so 64 outputs are in.  One-chunk reductions that
+    straight into registers (r04d) it is 197 us (profiles/gemm_layout_probe.py), so 64 outputs are in (r05: the threshold itself had
+    stayed at 128; at 64 the data gradient of the stacked per-pixel product, 2752 -> 64 over 65 536 rows, goes from 245 to 208 us).
+    One-chunk reductions that
     only WRITE a wide matrix (64 -> 2752: 274 us split against 247 us) stay on the fp32 kernels."""
     if not (GEMM_BX3 and _MODE == "fp32" and bool(_lib.ws_bytes("t2h_gemm_bx3_supported", m, k, n))
             and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
