@@ -201,11 +201,12 @@ def test_full_size_linear_kernels_satisfy_the_bilinear_identities(k, n):
 
 # ---- the 1-tap form of the split-bf16 matrix-core kernels as a GEMM on rows (csrc/conv_bx3.hip, t2h_gemm_bx3) -------------------
 @pytest.mark.parametrize("m,k,n", [(65536, 320, 64), (16384, 832, 128), (1024, 1856, 512), (4096, 64, 832), (128, 64, 32),
-                                   (16384, 128, 2624)])
+                                   (16384, 128, 2624), (8192, 64, 2752)])
 def test_gemm_bx3_rows_vs_float64(m, k, n, monkeypatch):
     """The grid-side products of the deferred point update (deferred.py): y = x W^T and y = x W (k-major weight) on column SLICES
     of wider matrices, with mask / accumulate, and a few-row case whose reduction is split into slabs -- against float64 at the
-    tolerance of the fp32 MFMA GEMMs (2e-5 of the max-norm)."""
+    tolerance of the fp32 MFMA GEMMs (2e-5 of the max-norm).  k = 64 with >= 8 column tiles runs the persistent form (r05: rows staged
+    and split once per workgroup, reused for all its column tiles): (4096, 64, 832) and the stacked per-pixel product's (., 64, 2752)."""
     from tomosar2height_amd import mlp
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(m + k + n)

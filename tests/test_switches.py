@@ -39,8 +39,8 @@ GROUPS = {
     "conv_fp32_mfma": {"T2H_CONV_PRECISION": "fp32", "T2H_CONV_ROWS_WGS_SMALL": "256", "T2H_CONV_ROWS_WGS_LARGE": "256",
                        "T2H_CONV_WGRAD_WGS": "128", "T2H_UPCONV_FWD_TILES": "64"},
     "conv_mixed": {"T2H_BX3_WGRAD": "0", "T2H_UPCONV_BX3": "0", "T2H_GEMM_BX3": "0", "T2H_BX3_MIN_PIXELS": "16384"},
-    "gemm_bx3_wide": {"T2H_GEMM_BX3_MIN_N": "32", "T2H_GEMM_BX3_MIN_K": "64"},
-    "gemm_bx3_narrow": {"T2H_GEMM_BX3_MIN_N": "128"},            # (the default until r05's last day: 64-wide outputs on the fp32 kernels)
+    "gemm_bx3_wide": {"T2H_GEMM_BX3_MIN_N": "32", "T2H_GEMM_BX3_MIN_K": "64", "T2H_BX3_PERSIST_WGS": "512"},
+    "gemm_bx3_narrow": {"T2H_GEMM_BX3_MIN_N": "128", "T2H_BX3_PERSIST_N": "0"},            # (the default until r05's last day: 64-wide outputs on the fp32 kernels)
     # per-point GEMM families, trunk forms, grid-first / deferred thresholds
     "gemm_plain": {"T2H_GEMM_DMA": "0", "T2H_SKINNY": "0", "T2H_SMALLM_BK": "16", "T2H_KWAVES_MIN_K": "100000"},
     "gemm_kwaves": {"T2H_KWAVES_MIN_K": "64", "T2H_KWAVES_MAX_TILES": "100000", "T2H_KWAVES_WGRAD_MAX_ROWS": "100000"},

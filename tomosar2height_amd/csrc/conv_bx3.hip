@@ -258,6 +258,7 @@ struct RowsArgs {
     float *y;                // [B,H,W,Nc], or the slab base when the reduction is split
     int B, H, W, Kc, Nc, flags;
     int splits, chunks_per_split;   // splits > 1: grid = tiles x splits, partial sums to y + split * B H W Nc (no epilogue)
+    int ntn_per_wg;          // PERSIST: column tiles per workgroup (the staged rows are split once and reused for all of them)
     int ldx, ldy, ldm;       // row strides (floats) of x, y and mask: Kc / Nc / Nc for the convolutions, free for the 1-tap (GEMM) form
     // 2x2 stride-2 transposed convolution on the 1-tap form (UPM != 0): the GEMM rows are the pixels of the INPUT plane
     // [*, 2^up_logH, 2^up_logW], the output plane has twice its size and up_cout channels
@@ -283,9 +284,13 @@ __device__ inline size_t up_pixel(long long m, int tap, int logW, int logH) {
 // UPM (1-tap form only): 1 = ConvTranspose2d(2, stride 2) forward -- GEMM [pixels, Cin] x [Cin, (tap, co)] with a SCATTERING epilogue
 // (column tile -> tap -> output pixel up(p, tap)), bias / residual addend there; 2 = its data gradient -- the A rows are GATHERED:
 // chunk c of K = (tap, co) reads dY[up(p, tap)][co0 ..] (alto.py:175,215-218,236).
-template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL, int NTAP, int UPM = 0>
+// PERSIST (1-tap form, ONE staged chunk: K = CCH): a workgroup keeps its staged and split rows in LDS and walks p.ntn_per_wg column
+// tiles with them -- wide outputs of a short reduction (the stacked per-pixel product 64 -> 2752 over 65 536 rows), where the
+// plain form stages and splits the same rows once per 64 output columns and loses to the fp32 MFMA kernel for that
+template <int TH, int BN, int WAVES_M, int WAVES_N, int CCH, int NPL, int NTAP, int UPM = 0, bool PERSIST = false>
 __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     static_assert(UPM == 0 || NTAP == 1, "the transposed convolution runs on the 1-tap form");
+    static_assert(!PERSIST || (NTAP == 1 && UPM == 0 && T2H_BX3_BDIRECT != 0), "PERSIST: plain 1-tap form with register-fetched weights");
     constexpr int PXB = CCH * 2 + 16;     // bytes per pixel and plane of the halo image: CCH bf16 + 16 B (an odd multiple of 16 B)
     constexpr int NQ = CCH / 16, F4 = CCH / 4, NSTEP = NTAP * NQ;
     constexpr int TM = TH / WAVES_M, TN = BN / (32 * WAVES_N);
@@ -297,7 +302,9 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     constexpr int HALO_BYTES = NPL * PLANE;
     constexpr bool BDIRECT = T2H_BX3_BDIRECT != 0;
     constexpr int LDS_WORK = HALO_BYTES + (BDIRECT ? 0 : 2 * BSLAB);
-    constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (the epilogue's patches live in the same array)
+    constexpr int PATCH_BYTES = 4 * 32 * 36 * 4;
+    // (the epilogue's patches live in the same array -- behind the images when the images have to survive the epilogue)
+    constexpr int LDS_BYTES = PERSIST ? LDS_WORK + PATCH_BYTES : (LDS_WORK >= PATCH_BYTES ? LDS_WORK : PATCH_BYTES);
     constexpr bool H2 = NPL == 2;                                        // the fp16 two-way split with block scales
     constexpr int WPL = H2 ? 2 : 3;                                      // planes per tile in the prepared weight buffer
     static_assert(WAVES_M * WAVES_N == 4 && TM * WAVES_M == TH && TN * WAVES_N * 32 == BN, "wave layout");
@@ -313,12 +320,15 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     unsigned t = (xx < rr ? xx * (qq + 1) : rr * (qq + 1) + (xx - rr) * qq) + i8;
     const int split = t % p.splits; t /= p.splits;                      // (the splits of a tile side by side: same halo pixels)
     const int ntn = p.Nc / BN;
-    const int tn = t % ntn; t /= ntn;
+    const int tn_groups = PERSIST ? (ntn + p.ntn_per_wg - 1) / p.ntn_per_wg : ntn;
+    const int tng = t % tn_groups; t /= tn_groups;
+    const int tn_lo = PERSIST ? tng * p.ntn_per_wg : tng, tn_hi = PERSIST ? min(ntn, tn_lo + p.ntn_per_wg) : tng + 1;
     const int tiles_x = p.W / TW;
     const int tx = t % tiles_x; t /= tiles_x;
     const int tiles_y = p.H / TH;
     const int ty = t % tiles_y, b = t / tiles_y;
-    const int x0 = tx * TW, y0 = ty * TH, n0 = tn * BN;
+    const int x0 = tx * TW, y0 = ty * TH;
+    int n0 = tn_lo * BN;
     const int c_beg = split * p.chunks_per_split, c_end = min(p.Kc / CCH, c_beg + p.chunks_per_split);
 
     // halo staging: F4 float4 per pixel and chunk
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     };
     // weight slab (16-channel step c16, tap) = c16 * 9 + tap: (Nc / 32) x 3 KB; this workgroup's BN / 32 tiles are one linear run.
     // Step st of chunk c: tap = st / NQ, q = st % NQ, c16 = c * NQ + q
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * WPL * 1024;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * WPL * 1024;      // (PERSIST: per column tile)
     const size_t slab_stride = (size_t)(p.Nc / 32) * WPL * 1024;
     auto issue_b = [&](int c, int st, unsigned char *dst) {
         const int s = (c * NQ + st % NQ) * NTAP + st / NQ;
@@ -407,6 +417,13 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     };
 
     f32x16 acc[TM][TN];
+    const int r = lane & 31, h = lane >> 5;
+  for (int tn = tn_lo; tn < tn_hi; ++tn) {                               // (one pass unless PERSIST)
+    const bool first = tn == tn_lo;
+    if (PERSIST && !first) {
+        n0 = tn * BN;
+        wbase = reinterpret_cast<const unsigned char *>(p.wf) + (size_t)(n0 / 32) * WPL * 1024;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -414,17 +431,18 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
 #pragma unroll
             for (int z = 0; z < 16; ++z) acc[i][j][z] = 0.0f;
 
-    const int r = lane & 31, h = lane >> 5;
-    halo_load(c_beg);
-    if (H2) {
-        publish_block_max(c_beg & 1);
-        __syncthreads();
+    if (!PERSIST || first) {
+        halo_load(c_beg);
+        if (H2) {
+            publish_block_max(c_beg & 1);
+            __syncthreads();
+        }
     }
     uint4 bnext[TN][NPL];
     if (BDIRECT) load_b(c_beg, 0, bnext);
     int s = 0;                                                           // running step count (selects the weight buffer)
     for (int c = c_beg; c < c_end; ++c) {
-        if (H2) {
+        if (H2 && (!PERSIST || first)) {
             // this chunk's block exponent (the same in every thread); the accumulators follow the smallest exponent (= the largest
             // block) met so far: a power-of-two rescaling of an fp32 accumulator is exact
             const float *sl = slots + (c & 1) * 4;
@@ -442,10 +460,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             }
             e_cur = e_run == E_UNSET ? 0 : e_run;
         }
-        halo_store();                                                    // (the previous chunk's last barrier has passed)
-        if (!BDIRECT && c == c_beg) issue_b(c, 0, bbuf);                 // (later chunks: issued by the previous chunk's last step)
-        if (c + 1 < c_end) halo_load(c + 1);                             // in flight under this chunk's MFMAs
-        __syncthreads();
+        if (!PERSIST || first) {
+            halo_store();                                                // (the previous chunk's last barrier has passed)
+            if (!BDIRECT && c == c_beg) issue_b(c, 0, bbuf);             // (later chunks: issued by the previous chunk's last step)
+            if (c + 1 < c_end) halo_load(c + 1);                         // in flight under this chunk's MFMAs
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int tap = 0; tap < NTAP; ++tap) {
             const int ky = NTAP == 9 ? tap / 3 : 0, kx = NTAP == 9 ? tap - 3 * ky : 0;
@@ -510,11 +530,11 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 if (!BDIRECT) __syncthreads();                           // (also drains the next slab's DMA: vmcnt(0))
             }
         }
-        if (BDIRECT) __syncthreads();                                    // every wave is done with this chunk's halo images
+        if (BDIRECT && !PERSIST) __syncthreads();                        // every wave is done with this chunk's halo images
     }
 
     // epilogue: one 32 x 32 tile at a time through the wave's LDS patch -> float4 rows along the output channels
-    float *patch = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    float *patch = reinterpret_cast<float *>(lds + (PERSIST ? LDS_WORK : 0)) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
     float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.ldy);     // (split == 0 unless the reduction is split)
@@ -590,6 +610,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             *dst = v;
         }
     }
+  }                                                                      // (column tiles of this workgroup)
 }
 
 // ---- wgrad ----------------------------------------------------------------------------------------------------------------------
@@ -935,6 +956,11 @@ int npl_of(int flags) { return (flags & T2H_F16X2) ? 2 : ((flags & T2H_BF16) ? 1
 // trailer of an fp16-prepared weight buffer ([0] largest magnitude bits, [1] 2^-e_w, [2] e_w) behind `planes_bytes` of planes
 const float *f16_trailer(const void *wf, size_t planes_bytes) { return reinterpret_cast<const float *>(static_cast<const unsigned char *>(wf) + planes_bytes); }
 
+bool persist_n_enabled() {
+    static const bool on = !(getenv("T2H_BX3_PERSIST_N") && getenv("T2H_BX3_PERSIST_N")[0] == '0');
+    return on;
+}
+
 int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, const char *what, int ntap = 9, int upm = 0) {
     const RowsPlan r = bx3_rows_plan(a.B, a.H, a.W, a.Kc, a.Nc, ntap, upm);
     const long long grid = r.tiles * r.splits;
@@ -948,7 +974,7 @@ int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, c
         e.accum = a.flags & F_ACCUM; e.relu_out = a.flags & F_RELU_OUT;
         a.y = static_cast<float *>(ws); a.bias = nullptr; a.mask = nullptr; a.flags = 0; a.ldy = a.Nc;
     }
-    a.splits = r.splits; a.chunks_per_split = r.chunks_per_split;
+    a.splits = r.splits; a.chunks_per_split = r.chunks_per_split; a.ntn_per_wg = 1;
     if (upm == 1) {
         if (r.bn == 128) BX3_LAUNCH_UP(128, 2, 2, 1);
         else if (r.bn == 64) BX3_LAUNCH_UP(64, 4, 1, 1);
@@ -967,6 +993,20 @@ int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, c
             else if (r.bn == 64) BX3_LAUNCH(4, 64, 4, 1, 32, 9);
             else BX3_LAUNCH(4, 32, 4, 1, 32, 9);
         }
+    } else if (ntap == 1 && upm == 0 && npl == 2 && a.Kc == 64 && r.splits == 1 && a.Nc / r.bn >= 8 && persist_n_enabled()) {
+        // one staged chunk, many column tiles: the rows are staged and split once per workgroup and reused (PERSIST)
+        const long long row_tiles = (long long)a.B * (a.H / 4) * (a.W / TW);
+        const int pbn = r.bn == 128 ? 64 : r.bn;                          // (128-column tiles spill in this form)
+        const int ntn = a.Nc / pbn;
+        static const long long persist_wgs = getenv("T2H_BX3_PERSIST_WGS") ? atoll(getenv("T2H_BX3_PERSIST_WGS")) : 2048;
+        long long groups = persist_wgs / (row_tiles > 0 ? row_tiles : 1);
+        if (groups < 1) groups = 1;
+        if (groups > ntn) groups = ntn;
+        a.ntn_per_wg = (int)((ntn + groups - 1) / groups);
+        groups = (ntn + a.ntn_per_wg - 1) / a.ntn_per_wg;
+        const long long pgrid = row_tiles * groups;
+        if (pbn == 64) { hipLaunchKernelGGL((bx3_rows_kernel<4, 64, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,64,4,1,64,2,1,0,persist>"); }
+        else { hipLaunchKernelGGL((bx3_rows_kernel<4, 32, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,32,4,1,64,2,1,0,persist>"); }
     } else {
         if (r.tall) {
             if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 32, 1);

@@ -66,6 +66,7 @@ GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
 
 _BX3_MIN_N = int(os.environ.get("T2H_GEMM_BX3_MIN_N", "64"))
 _BX3_MIN_K = int(os.environ.get("T2H_GEMM_BX3_MIN_K", "128"))
+_PERSIST_N = os.environ.get("T2H_BX3_PERSIST_N", "1") != "0"
 
 
 def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
@@ -80,7 +81,10 @@ def _bx3_gemm_ok(m, k, n, *rows, force=False) -> bool:
             and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in rows)):
         return False
     min_n, min_k = _BX3_MIN_N, _BX3_MIN_K
-    return force or (n >= min_n and k >= min_k and m >= 4096)
+    # r05: a ONE-chunk reduction (k = 64) into a wide matrix goes to the split kernel's persistent form (conv_bx3.hip, PERSIST: the
+    # rows are staged and split once per workgroup and reused for all its column tiles); T2H_BX3_PERSIST_N=0: A/B
+    wide_short = _PERSIST_N and k == 64 and n >= 512 and m >= 4096
+    return force or wide_short or (n >= min_n and k >= min_k and m >= 4096)
 
 
 def _gemm_bx3(x, w, w_is_kn, bias, mask, y, relu_out, accumulate, tag):
