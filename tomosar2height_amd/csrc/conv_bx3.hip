@@ -929,13 +929,13 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int up
     do {                                                                                                                    \
         if (npl == 1) {                                                                                                     \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 1, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",1," #NTAP_ ",0>");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",1," #NTAP_ ",0,false>");                      \
         } else if (npl == 2) {                                                                                              \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 2, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",2," #NTAP_ ",0>");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",2," #NTAP_ ",0,false>");                      \
         } else {                                                                                                            \
             hipLaunchKernelGGL((bx3_rows_kernel<TH_, BN_, WM_, WN_, CC_, 3, NTAP_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",3," #NTAP_ ",0>");                      \
+            note_kernel("bx3_rows_kernel<" #TH_ "," #BN_ "," #WM_ "," #WN_ "," #CC_ ",3," #NTAP_ ",0,false>");                      \
         }                                                                                                                   \
     } while (0)
 
@@ -944,10 +944,10 @@ RowsPlan bx3_rows_plan(int B, int H, int W, int Kc, int Nc, int ntap = 9, int up
     do {                                                                                                                    \
         if (npl == 2) {                                                                                                     \
             hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 2, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,2,1," #UPM_ ">");                                  \
+            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,2,1," #UPM_ ",false>");                                  \
         } else {                                                                                                            \
             hipLaunchKernelGGL((bx3_rows_kernel<4, BN_, WM_, WN_, 64, 3, 1, UPM_>), dim3((unsigned)grid), dim3(NT), 0, s, a); \
-            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,3,1," #UPM_ ">");                                  \
+            note_kernel("bx3_rows_kernel<4," #BN_ "," #WM_ "," #WN_ ",64,3,1," #UPM_ ",false>");                                  \
         }                                                                                                                   \
     } while (0)
 
@@ -1005,8 +1005,8 @@ int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, c
         a.ntn_per_wg = (int)((ntn + groups - 1) / groups);
         groups = (ntn + a.ntn_per_wg - 1) / a.ntn_per_wg;
         const long long pgrid = row_tiles * groups;
-        if (pbn == 64) { hipLaunchKernelGGL((bx3_rows_kernel<4, 64, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,64,4,1,64,2,1,0,persist>"); }
-        else { hipLaunchKernelGGL((bx3_rows_kernel<4, 32, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,32,4,1,64,2,1,0,persist>"); }
+        if (pbn == 64) { hipLaunchKernelGGL((bx3_rows_kernel<4, 64, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,64,4,1,64,2,1,0,true>"); }
+        else { hipLaunchKernelGGL((bx3_rows_kernel<4, 32, 4, 1, 64, 2, 1, 0, true>), dim3((unsigned)pgrid), dim3(NT), 0, s, a); note_kernel("bx3_rows_kernel<4,32,4,1,64,2,1,0,true>"); }
     } else {
         if (r.tall) {
             if (r.bn == 128) BX3_LAUNCH(8, 128, 2, 2, 32, 1);
