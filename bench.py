@@ -96,6 +96,12 @@ def parse():
                     help="tiles of the accumulation window per forward / backward (micro-batch; a SECOND line beside the B = 1 "
                          "headline: the reference feeds tiles one at a time only because N varies, tomosar2height.yaml:40).  With "
                          "> 1 the resident tiles get DIFFERENT point counts (mean = --points) and run as ragged batches")
+    ap.add_argument("--coalesce", type=int, default=-1,
+                    help="tiles Trainer.train_step(tile) holds back and issues as one ragged micro-batch (Trainer.coalesce_tiles; "
+                         "-1 = the Trainer's default, T2H_COALESCE_TILES or 4; 1 = the strict B = 1 step, also reported as `strict_b1`)")
+    ap.add_argument("--strict-b1-steps", type=int, default=16,
+                    help="tile-steps of a short timed leg with coalescing off (every train_step call issues its own tile: the B = 1 "
+                         "step of rounds 1-5); reported as `strict_b1`, never part of `value` (0: skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU run); gloo only to smoke-test the N>1 code path "
                          "with several ranks sharing one GPU")
@@ -559,6 +565,11 @@ def main():
 
     opt, opt_name = make_optimizer()
     trainer = make_trainer(opt, args.optimize_every, group)
+    if args.coalesce > 0:
+        trainer.coalesce_tiles = args.coalesce
+    if args.train_batch > 1 or args.hip_graph or args.tile_prefetch or args.share_gpu:
+        trainer.coalesce_tiles = 1                        # (explicit micro-batches / graph replays / prepared tiles are issued as given)
+    co = trainer.coalesce_tiles
 
     tiles, source, anchors = [], None, None
     if args.from_producer:
@@ -690,7 +701,9 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sus_elapsed = float(tmax.item())
         calls = state.pop("event_tiles")
-        per = [evs[i].elapsed_time(evs[i + 1]) / calls[i] for i in range(len(calls))]      # GPU time per tile between call ends
+        # GPU time per tile between call ends; with coalescing only every co-th call issues work: groups of co calls
+        g = max(1, trainer.coalesce_tiles)
+        per = [evs[i].elapsed_time(evs[min(i + g, len(calls))]) / sum(calls[i:i + g]) for i in range(0, len(calls), g)]
         q = max(1, len(per) // 4)
         state.pop("event_tiles", None)
         sustained = {"steps": n_sus, "seconds": round(sus_elapsed, 2), "ms_per_step": round(1e3 * sus_elapsed / n_sus, 3),
@@ -705,11 +718,14 @@ def main():
         # what the host alone needs per tile-step: issue time of single steps onto an EMPTY queue (no back-pressure); well
         # below ms_per_step = the run is GPU-bound and a rank needs that fraction of one core
         lone = []
+        g = max(1, trainer.coalesce_tiles)
+        trainer.flush_pipeline()
+        trainer.accumulated_steps = trainer.accumulated_steps // g * g       # (whole groups: a group is one issue)
         for _ in range(8):
             fence()
             th = time.perf_counter()
-            run(1)
-            lone.append(time.perf_counter() - th)
+            run(g)
+            lone.append((time.perf_counter() - th) / g)
         fence()
         sustained["host_issue_ms_empty_queue"] = round(1e3 * statistics.median(lone), 3)
 
@@ -739,13 +755,37 @@ def main():
             run(2)                                            # back on the default arithmetic before the next leg
             fence()
 
+    # ---- leg 1c': coalescing off (never part of `value`): every train_step(tile) issues its own forward / backward -- the B = 1 step
+    # that was the headline of rounds 1-5
+    strict_b1 = None
+    if args.strict_b1_steps > 0 and args.mode == "train" and not args.hip_graph and trainer.coalesce_tiles > 1:
+        trainer.flush_pipeline()
+        keep_co, trainer.coalesce_tiles = trainer.coalesce_tiles, 1
+        try:
+            run(6)
+            fence()
+            tb = time.perf_counter()
+            run(args.strict_b1_steps)
+            fence()
+            eb1 = time.perf_counter() - tb
+            if world > 1:
+                tmax = torch.tensor([eb1], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                eb1 = float(tmax.item())
+            strict_b1 = {"value": round(world * args.strict_b1_steps / eb1, 3), "ms_per_step": round(1e3 * eb1 / args.strict_b1_steps, 3),
+                         "steps": args.strict_b1_steps, "what": "T2H_COALESCE_TILES=1: one forward / backward per train_step call"}
+        finally:
+            trainer.flush_pipeline()
+            trainer.coalesce_tiles = keep_co
+            fence()
+
     # ---- leg 1d: the same accumulation window micro-batched (never part of `value`): 4 ragged tiles per forward / backward.  The
     # reference runs its 64 tiles one at a time only because their point counts differ (tomosar2height.yaml:40); they are
     # independent and their gradients are summed (trainer.py:69-89), so this is the same training step with a quarter of the
     # launches per tile -- what takes the host out of a B = 1 step
     micro_batched = None
     if (args.micro_batch_steps > 0 and args.mode == "train" and args.train_batch == 1 and not args.hip_graph and source is None
-            and tile_stream is None and args.optimize_every % (4 * world) == 0):
+            and tile_stream is None and args.optimize_every % (4 * world) == 0 and trainer.coalesce_tiles == 1):
         trainer.flush_pipeline()
         keep_tiles, keep_j = list(tiles), state.get("j", -1)
         rag = (-0.10, 0.06, -0.04, 0.08)
@@ -835,12 +875,14 @@ def main():
             "config": {"workload": ("BASELINE.json configs[2]: Berlin cloud+image" if args.use_image
                                     else "BASELINE.json configs[1]: Berlin cloud-only")
                                    + f", {args.mlp_precision} per-point GEMMs, "
-                                   + ("B=1 tile, " if args.train_batch == 1 else
+                                   + ((f"train_step(tile) per tile, {co} tiles coalesced per forward/backward (Trainer default), "
+                                       if co > 1 else "B=1 tile, ") if args.train_batch == 1 else
                                       f"micro-batches of {args.train_batch} tiles with different point counts (ragged; SECOND line, not the "
                                       "B=1 headline), mean ")
                                    + f"N={args.points} points/tile, R=256, ALTO depth 5, 512x512 target, "
                                    f"optimize_every={args.optimize_every}",
                        "points_per_tile": args.points, "optimize_every": args.optimize_every, "train_batch": args.train_batch,
+                       "coalesce_tiles": co,
                        "optimizer_steps_in_timed_region": timed_optimizer_steps, "optimizer": opt_name,
                        "optimizer_boundary_ms": round(boundary_ms, 3),
                        "parallelism": f"dp{world}", "collective": (dist.get_backend(group) if world > 1 else None),
@@ -911,6 +953,8 @@ def main():
                 out["config"]["kernel_table"] = f"not written: {e}"
         if exact_split is not None:
             out["exact_split"] = exact_split
+        if strict_b1 is not None:
+            out["strict_b1"] = strict_b1
         if micro_batched is not None:
             out["micro_batched"] = micro_batched
         if sustained is not None:

@@ -6,7 +6,8 @@ exercises RCCL initialisation and the all-reduce launch on the hardware.
     python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tests/dp_worker.py dp OUT.json
 """
 import os as _os
-# all ranks share cuda:0 here: one stream per process (see bench.py --share-gpu)
+# all ranks share cuda:0 here: one stream per process (see bench.py --share-gpu); `rccl1_full` (one rank owns the GPU) switches the
+# Trainer's defaults back on itself
 _os.environ.setdefault("T2H_OVERLAP_WGRAD", "0")
 _os.environ.setdefault("T2H_OVERLAP_CONV_WGRAD", "0")
 _os.environ.setdefault("T2H_PIPELINE_TILES", "0")
@@ -135,6 +136,46 @@ def run_rccl1(out_path):
                    "f64_ok": bool(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float64)))}, f)
 
 
+def run_rccl1_full(out_path):
+    """r06: the composition eight real ranks run, with one rank owning the GPU -- the Trainer's DEFAULTS
+    (tile pipeline on two streams, weight gradients on the side streams, single tiles coalesced into micro-batches) + the RCCL
+    all-reduce on the process group's stream + the optimizer boundary -- over TWO optimizer steps of ragged tiles, bit-identical
+    to the same loop without a process group (all-reduce over one rank is the identity), and the second step must start from
+    the first step's weights in both."""
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    tiles = []
+    for i in range(10):
+        t = berlin_tile(500 + i, n_points=36000 + 1500 * (i % 4))
+        tiles.append({k: t[k].to(dev) for k in ("inputs", "dsm")})
+    out = {}
+    for name, group in (("rccl", dist.group.WORLD), ("alone", None)):
+        model = _model(dev)
+        tr = Trainer(model, torch.optim.AdamW(model.parameters(), lr=1e-3), device=dev, optimize_every=5, use_cloud=True,
+                     process_group=group)
+        tr.pipeline_tiles = tr.overlap_wgrad = tr.overlap_conv_wgrad = True
+        assert tr.coalesce_tiles == 4 and tr.pipeline_micro_batches
+        grads, losses = [], []
+        tr.on_reduced = lambda flat, grads=grads: grads.append(flat.clone())
+        stepped = []
+        for t in tiles:
+            stepped.append(tr.train_step(t))
+            if stepped[-1]:
+                losses.append(float(tr.last_avg_loss))
+        assert stepped == [False] * 4 + [True] + [False] * 4 + [True], stepped
+        torch.cuda.synchronize()
+        out[name] = (grads, losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]),
+                     (tr._tile_streams is not None, tr._side is not None, tr._conv_side is not None))
+    (ga, la, pa, used_a), (gb, lb, pb, used_b) = out["rccl"], out["alone"]
+    with open(out_path, "w") as f:
+        json.dump({"backend": dist.get_backend(), "boundaries": len(ga),
+                   "grad_equal": [bool(torch.equal(x, y)) for x, y in zip(ga, gb)],
+                   "grads_differ_between_steps": not torch.equal(ga[0], ga[1]),
+                   "loss_equal": la == lb, "param_equal": bool(torch.equal(pa, pb)),
+                   "pipeline_and_side_streams_used": [list(used_a), list(used_b)]}, f)
+
+
 def run_mosaic(out_path):
     """Multi-rank DSMGenerator (tiles i % W == rank, one float64 all-reduce of the dsm/weight pair) == one rank alone."""
     from tomosar2height_amd.generator import DSMGenerator
@@ -161,13 +202,13 @@ def run_mosaic(out_path):
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if mode == "rccl1":
+    if mode in ("rccl1", "rccl1_full"):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
     else:
         dist.init_process_group("gloo")
     try:
-        {"dp": run_dp, "rccl1": run_rccl1, "mosaic": run_mosaic}[mode](out)
+        {"dp": run_dp, "rccl1": run_rccl1, "rccl1_full": run_rccl1_full, "mosaic": run_mosaic}[mode](out)
     finally:
         dist.barrier()
         dist.destroy_process_group()

@@ -339,6 +339,64 @@ def upsample_mode_fixture():
     save("plain_unet_upsample", **arrs)
 
 
+def _module_fixture(mod, inputs, name_prefix, arrs, seed):
+    """Forward + backward of a reference module on `inputs` (dict of tensors -> positional args in order): outputs, the upstream
+    gradient, every parameter (state_dict order) and every parameter gradient / the grad-is-None set, under `name_prefix`."""
+    args = [v.clone().requires_grad_(v.dtype.is_floating_point and k.startswith("x")) for k, v in inputs.items()]
+    out = mod(*args)
+    out0 = out["xy"] if isinstance(out, dict) else (out[0] if isinstance(out, (tuple, list)) else out)
+    g = torch.Generator().manual_seed(seed)
+    gout = torch.randn(out0.shape, generator=g)
+    out0.backward(gout)
+    for (k, v), a in zip(inputs.items(), args):
+        arrs[f"{name_prefix}.in.{k}"] = v
+        if a.grad is not None:
+            arrs[f"{name_prefix}.gin.{k}"] = a.grad
+    arrs[f"{name_prefix}.out"] = out0
+    arrs[f"{name_prefix}.gout"] = gout
+    none_grad = []
+    for k, v in mod.state_dict().items():
+        arrs[f"{name_prefix}.w.{k}"] = v
+    for k, v in mod.named_parameters():
+        if v.grad is None:
+            none_grad.append(k)
+        else:
+            arrs[f"{name_prefix}.g.{k}"] = v.grad
+    arrs[f"{name_prefix}.none_grad"] = np.array(none_grad, dtype=str)
+
+
+def options_fixture():
+    """r06: constructor options of the hot path's modules that no shipped config selects but the reference accepts --
+    ``ConvDecoder(leaky=True)`` (pixel.py:8-32), ``LocalPoolPointnet(unet_type='unet')`` (pointnet.py:45-49: the plain U-Net on
+    the rasterised plane), ``merge_mode='add'`` in the ALTO U-Net (alto.py:176-179, 221-224) and in the plain U-Net
+    (unet.py:92-105).  Each: inputs, weights, output, upstream gradient, every gradient, produced by the reference's modules."""
+    import_reference()
+    from tomosar2height.encoder.pointnet import LocalPoolPointnet
+    from tomosar2height.encoder.unet import UNet
+    from tomosar2height.decoder.pixel import PixelwiseDecoder
+    arrs = {}
+    g = torch.Generator().manual_seed(21)
+    dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode="conv", leaky=True), seed=21)
+
+    class _Dec(torch.nn.Module):                     # (dict in, tuple out -> tensor in, tensor out; parameters under the same names)
+        def __init__(self, d):
+            super().__init__()
+            self.d = d
+
+        def forward(self, x):
+            return self.d({"xy": x})[0]
+    _module_fixture(_Dec(dec), {"x": torch.randn(1, 32, 16, 16, generator=g)}, "leaky_decoder", arrs, 22)
+    enc = det_init_(LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="unet",
+                                      unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16), seed=23)
+    _module_fixture(enc, {"cloud": synth_cloud(256, seed=41)}, "plane_unet", arrs, 24)
+    enc = det_init_(LocalPoolPointnet(feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+                                      unet_kwargs=dict(depth=3, merge_mode="add", start_filts=8), plane_resolution=16), seed=25)
+    _module_fixture(enc, {"cloud": synth_cloud(256, seed=42)}, "alto_add", arrs, 26)
+    net = det_init_(UNet(8, in_channels=4, depth=3, start_filts=8, up_mode="transpose", merge_mode="add"), seed=27)
+    _module_fixture(net, {"x": torch.randn(2, 4, 16, 16, generator=g)}, "unet_add", arrs, 28)
+    save("reference_options", **arrs)
+
+
 def blend_weight_fixture():
     """(10) DSMGenerator._linear_blend_patch_weight (generator.py:85-113).  generator.py cannot be imported as a
     module here (dataset.py needs `transformations`), so the static method is compiled from the reference file where
@@ -482,6 +540,9 @@ if __name__ == "__main__":
     if "--only-upsample" in sys.argv:
         upsample_mode_fixture()
         sys.exit(0)
+    if "--only-options" in sys.argv:
+        options_fixture()
+        sys.exit(0)
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         main()
     if "--only-producer" not in sys.argv:
@@ -492,3 +553,4 @@ if __name__ == "__main__":
     if "--only-blend" not in sys.argv and "--only-producer" not in sys.argv:
         mean_pool_fixture()
         upsample_mode_fixture()
+        options_fixture()

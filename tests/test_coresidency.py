@@ -138,7 +138,7 @@ def test_walks_beside_the_split_convolutions_are_bit_identical():
 
 @gpu
 @pytest.mark.parametrize("ahead,points,image,windows", [(False, 40000, False, 8), (True, 40000, False, 8), (False, 131072, False, 4),
-                                                        (False, 40000, True, 4)],
+                                                        (False, 40000, True, 8)],
                          ids=["lazy", "prepared", "benchmark-size", "cloud+image"])
 def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, points, image, windows):
     """Four-tile windows through the tile pipeline (tile indices built ahead on a side stream or inside the step; the benchmarked
@@ -184,8 +184,4 @@ def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, poi
         n = sum(not torch.equal(got[k], gold[k]) for k in gold)
         if n or losses != gold_losses:
             differing.append((it, n, [a == b for a, b in zip(losses, gold_losses)]))
-    if differing and image:
-        # the one known residue (profiles/r05_coresidency.txt): with the image U-Net's kernels in the mix 1 window in ~170 was seen to
-        # differ (once, inside a full-suite run; 0 of 168 in isolation since).  Reported, not hidden -- but not a red suite either
-        pytest.xfail(f"cloud+image window differs from the synchronised one (iteration, gradients, per-tile loss equal): {differing}")
     assert not differing, f"windows that differ from the synchronised one (iteration, gradients, per-tile loss equal): {differing}"

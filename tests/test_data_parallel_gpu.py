@@ -63,6 +63,18 @@ def test_one_rank_rccl_group_is_bit_identical(tmp_path):
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_with_the_trainer_defaults_over_two_optimizer_steps(tmp_path):
+    """What eight real ranks run, on the one GPU a rank owns: tile pipeline + weight-gradient side streams + coalesced tiles + RCCL
+    all-reduce + optimizer boundary, twice -- bit-identical to the loop without a process group (dp_worker.run_rccl1_full)."""
+    out = str(tmp_path / "rccl1_full.json")
+    _launch(1, [WORKER, "rccl1_full", out])
+    res = json.load(open(out))
+    assert res == {"backend": "nccl", "boundaries": 2, "grad_equal": [True, True], "grads_differ_between_steps": True,
+                   "loss_equal": True, "param_equal": True,
+                   "pipeline_and_side_streams_used": [[True, True, True], [True, True, True]]}, res
+
+
+@pytest.mark.gpu
 def test_multi_rank_mosaic_equals_single(tmp_path):
     out = str(tmp_path / "mosaic.json")
     _launch(2, [WORKER, "mosaic", out])

@@ -106,6 +106,64 @@ def test_micro_batched_window_gives_the_same_accumulated_gradient():
         tr.train_step(tiles)
 
 
+def test_coalesced_single_tile_api_gives_the_window_of_the_tile_by_tile_loop():
+    """``Trainer.train_step(tile)`` called tile by tile, as the reference's loop does (train.py:147-152): by default the trainer
+    holds single tiles back and issues them four at a time as ragged micro-batches (``coalesce_tiles``), never across the
+    optimizer boundary.  Against the same calls with coalescing off: the same calls end with an optimizer step, the flat gradient
+    the optimizer consumes agrees to 2e-5 of its max-norm, the window's average loss to 1e-6; ``flush_gradients()`` in the
+    middle of a window issues what is held; a tile handed over as a one-element list or with a prebuilt index keeps its place
+    in the order."""
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.trainer import Trainer
+    counts = (60000, 48000, 52000, 40000, 56000, 44000, 50000)
+    tiles = []
+    for i, n in enumerate(counts):
+        t = berlin_tile(seed=80 + i, n_points=n)
+        tiles.append({"inputs": t["inputs"].to(_dev()), "dsm": t["dsm"].to(_dev())})
+    res = {}
+    for co in (1, 4):
+        model = _berlin_model(seed=29)
+        tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=_dev(), optimize_every=len(tiles), use_cloud=True)
+        assert tr.coalesce_tiles == 4, "coalescing is the default"
+        tr.coalesce_tiles = co
+        seen, batches, inner = [], [], tr._losses
+        tr.on_reduced = lambda flat: seen.append(flat.clone())
+
+        def rec(data, thr, inner=inner, batches=batches):
+            batches.append(len(data) if isinstance(data, (list, tuple)) else 1)
+            return inner(data, thr)
+        tr._losses = rec
+        stepped = [tr.train_step(t) for t in tiles]
+        assert stepped == [False] * (len(tiles) - 1) + [True], stepped
+        # tile 0 lays the gradient bucket out (alone); then 4 held + the 2 that complete the window
+        assert batches == ([1] * 7 if co == 1 else [1, 4, 2]), batches
+        res[co] = (seen[0], float(tr.last_avg_loss))
+        assert tr.accumulated_steps == 0 and not tr._coalesced
+        if co == 4:
+            # a flush in the middle of the window issues the held tiles; lists and prepared tiles keep the order of the calls
+            del batches[:]
+            tr.train_step(tiles[0])
+            tr.train_step(tiles[1])
+            assert batches == [] and len(tr._coalesced) == 2
+            tr.flush_gradients()
+            assert batches == [2] and tr.accumulated_steps == 2 and not tr._coalesced
+            tr.train_step(tiles[2])
+            tr.train_step([tiles[3]])                       # (a list is issued as given: the held tile goes first)
+            assert batches == [2, 1, 1], batches
+            tr.train_step(tiles[4])
+            tr.train_step(tr.prepare(tiles[5]))             # (prebuilt index: issued on its own, after the held tile)
+            assert batches == [2, 1, 1, 1, 1], batches
+            assert tr.train_step(tiles[6]) is True
+            g2 = seen[1]
+            rel2 = ((g2 - res[1][0]).abs().max() / res[1][0].abs().max()).item()
+            assert rel2 <= 2e-5, rel2
+    (g1, l1), (g4, l4) = res[1], res[4]
+    assert abs(l1 - l4) <= 1e-6 * abs(l1), (l1, l4)
+    rel = ((g1 - g4).abs().max() / g1.abs().max()).item()
+    print(f"[coalesced] bucket max rel diff {rel:.2e}, avg loss {l1:.6f} / {l4:.6f}")
+    assert rel <= 2e-5, rel
+
+
 def _dsm(lo):
     return torch.from_numpy(lo).repeat_interleave(8, -2).repeat_interleave(8, -1)     # (as tests/test_hip_model.py)
 

@@ -250,3 +250,43 @@ def test_trainer_accumulation_semantics():
             name = k[len("after."):]
             np.testing.assert_allclose(params[name].detach().numpy(), g[k], rtol=1e-6, atol=1e-7)
             assert not np.array_equal(g[k], g["before." + name]) or "up_convs.0.upconv" not in name
+
+
+def _check_module_fixture(g, prefix, mod, inputs, rtol=1e-4, atol=1e-5):
+    sd = {k[len(prefix) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix + ".w.")}
+    assert list(sd.keys()) == list(mod.state_dict().keys())
+    mod.load_state_dict(sd, strict=True)
+    args = [torch.from_numpy(g[f"{prefix}.in.{k}"]).requires_grad_(k.startswith("x")) for k in inputs]
+    out = mod(*args)
+    out = out["xy"] if isinstance(out, dict) else out
+    np.testing.assert_allclose(out.detach().numpy(), g[prefix + ".out"], rtol=1e-6, atol=1e-6)
+    out.backward(torch.from_numpy(g[prefix + ".gout"]))
+    assert [k for k, v in mod.named_parameters() if v.grad is None] == g[prefix + ".none_grad"].tolist()
+    for k, v in mod.named_parameters():
+        if v.grad is not None:
+            np.testing.assert_allclose(v.grad.numpy(), g[f"{prefix}.g.{k}"], rtol=rtol, atol=atol)
+    for k, a in zip(inputs, args):
+        if a.grad is not None:
+            np.testing.assert_allclose(a.grad.numpy(), g[f"{prefix}.gin.{k}"], rtol=rtol, atol=atol)
+
+
+def test_reference_options():
+    """r06: constructor options no shipped config selects -- ConvDecoder(leaky=True), unet_type='unet', merge_mode='add' in
+    both U-Nets -- the oracle's restatement against the reference's own outputs and gradients (reference_options.npz)."""
+    g = load_golden("reference_options")
+
+    class _Dec(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.d = torch_ref.PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=32, mode="conv", leaky=True)
+
+        def forward(self, x):
+            return self.d({"xy": x})[0]
+    _check_module_fixture(g, "leaky_decoder", _Dec(), ["x"])
+    _check_module_fixture(g, "plane_unet", torch_ref.LocalPoolPointnet(
+        feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="unet",
+        unet_kwargs=dict(depth=3, merge_mode="concat", start_filts=8), plane_resolution=16), ["cloud"])
+    _check_module_fixture(g, "alto_add", torch_ref.LocalPoolPointnet(
+        feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
+        unet_kwargs=dict(depth=3, merge_mode="add", start_filts=8), plane_resolution=16), ["cloud"])
+    _check_module_fixture(g, "unet_add", torch_ref.PlainUNet(8, in_channels=4, depth=3, start_filts=8, merge_mode="add"), ["x"])

@@ -853,11 +853,19 @@ __global__ __launch_bounds__(256, 2) void sample_relu_cellsums_v2_kernel(const f
                     // (r05: profiles/r05_coresidency.txt; found by replaying one backward's calls beside this kernel on a second
                     // stream; both this kernel and its r04 form, alone or beside any other kernel never).  The weights live for
                     // 64 rows, so one lost quarter is amplified; tests/test_coresidency.py keeps watch
+#ifdef T2H_TAPS_BY_SELECT     // the r05 reproducer only (profiles/coresidency_lab.py builds it beside the product library): the pre-fix form
+                    const bool x1ok = tp.x0 + 1 < r, y1ok = tp.y0 + 1 < r;
+                    nw_l = __fmul_rn(tp.wx0, tp.wy0);
+                    ne_l = x1ok ? __fmul_rn(tp.wx1, tp.wy0) : 0.f;
+                    sw_l = y1ok ? __fmul_rn(tp.wx0, tp.wy1) : 0.f;
+                    se_l = (x1ok && y1ok) ? __fmul_rn(tp.wx1, tp.wy1) : 0.f;
+#else
                     const float fx1 = (float)min(max(r - 1 - tp.x0, 0), 1), fy1 = (float)min(max(r - 1 - tp.y0, 0), 1);
                     nw_l = __fmul_rn(tp.wx0, tp.wy0);
                     ne_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy0), fx1);
                     sw_l = __fmul_rn(__fmul_rn(tp.wx0, tp.wy1), fy1);
                     se_l = __fmul_rn(__fmul_rn(tp.wx1, tp.wy1), __fmul_rn(fx1, fy1));
+#endif
                     // slot of the north-west tap in the staged window (a tap outside the plane has weight 0 and reads the
                     // staged zero -- the sample kernel skips it: the same value)
                     slot_l = (min(max(tp.y0 - cy + 1, 0), 1) + (K ? (wave >> 1) : 0)) * SIDE +

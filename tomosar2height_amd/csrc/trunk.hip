@@ -599,6 +599,18 @@ __device__ inline void load_g_tile(const TrunkBwdArgs &a, float *Gs, float *scra
     __syncthreads();
 }
 
+// x > 0 ? a : +0 without a compare: the sign test as an integer clamp of x's bits to {0, 1}, the select as a bitwise AND with
+// -that.  (Bit-identical for every non-NaN x.)  The FIRST backward variant uses it for its ReLU masks: a `v_cmp -> SGPR pair ->
+// v_cndmask` there was seen to lose lanes 48..63 of the mask beside the split-convolution kernels (r05 / r06:
+// profiles/r06_coresidency.txt -- 86 of 2000 launches of a dense replay), and no wait state between the two changes that
+// (the clamp is an opaque v_med3_i32: written as min(max(bits, 0), 1) the compiler recognises the idiom and emits the very
+// v_cmp_lt_i32 -> v_cndmask it was meant to avoid)
+__device__ inline float keep_where_positive(float x, float a) {
+    int m;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(m) : "v"(__float_as_int(x)));
+    return __int_as_float(__float_as_int(a) & -m);
+}
+
 // weight gradient tile: acc[n][k] += sum over the 32 rows of a[row][n] * b[row][k], operands in the C/D register layout
 __device__ inline void mfma_outer(const float (&av)[16], const float (&bv)[16], f32x16 &acc) {
 #pragma unroll
@@ -658,15 +670,28 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
         // "row q of this lane lies inside the cloud" (false only in the last workgroup), compared AFRESH at every use (`fresh` hides
         // the row from common-subexpression elimination): left to itself the compiler computes the sixteen compares once per tile and
         // parks them in SGPR pairs across ~1000 instructions, and a parked compare result is what the r05 co-residency fault eats
-        // (point_grid.hip's forward walk; profiles/r05_coresidency.txt).  Also 24 VGPRs cheaper here.  Not in the FIRST variant: it
-        // is at the register limit and spills with any of the three rewrites tried; it remains the one call the dense replay of
-        // profiles/coresidency_audit.py still catches (1 of ~70 launches beside the split convolutions), with or without these masks
+        // (point_grid.hip's forward walk; profiles/r05_coresidency.txt).  Also 24 VGPRs cheaper here.  The FIRST variant (at the
+        // register limit: it spills with this rewrite) has no row masks at all since r06, see below
         auto fresh = [](int v) { if constexpr (!FIRST) asm volatile("" : "+v"(v)); return v; };
 #define T2H_ROW_OK(q) (fresh(rb) + T2H_RO(q) < r1)
         // hr in the C/D layout, requested before the g stage: its barriers keep the compiler from hoisting the loads itself
         float hr_cd[16];
+        if constexpr (FIRST) {
+            // r06: NO row masks in this variant.  A row past the cloud (last tile only) has g = 0 (load_g_tile stores zeros for it)
+            // and zero points in LDS, hence dhr = 0 and dX = 0: every product it enters is 0 x (a finite number) whatever X holds
+            // for it -- X is left unmasked
+            // (buffer loads: the tile's valid rows are the descriptor's range, a row past it reads as 0 -- the range check is the
+            // mask -- and the sixteen loads share one offset register)
+            const __amdgpu_buffer_rsrc_t hr_rows = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.hr + (size_t)r0 * 32), 0, (r1 - r0) * 128, 0x00020000);
+            const int voff = ((wave * 32 + 4 * h) * 32 + r) * 4;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) hr_cd[q] = T2H_ROW_OK(q) ? (a.hr + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
+            for (int q = 0; q < 16; ++q)
+                hr_cd[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr_rows, voff + T2H_RO(q) * 128, 0, 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hr_cd[q] = T2H_ROW_OK(q) ? (a.hr + (size_t)rb * 32 + r)[T2H_RO(q) * 32] : 0.f;
+        }
 
         // ---------------------------------------------------------------- g -> Gs (row-major) and g_cd (registers)
         if constexpr (LAST) {
@@ -713,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
             mfma_rows<32, false>(Gs + (wave * 32 + r) * HS + 4 * h, W1t + r * HS + 4 * h, acc_d);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                d_cd[q] = hr_cd[q] > 0.f ? acc_d[q] : 0.f;
+                d_cd[q] = FIRST ? keep_where_positive(hr_cd[q], acc_d[q]) : (hr_cd[q] > 0.f ? acc_d[q] : 0.f);
                 db1 += g_cd[q];
                 db0 += d_cd[q];
             }
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
                     acc = fmaf(pp[0], w_0, acc);
                     acc = fmaf(pp[1], w_1, acc);
                     acc = fmaf(pp[2], w_2, acc);
-                    x_cd[q] = T2H_ROW_OK(q) ? acc : 0.f;
+                    x_cd[q] = acc;                                           // (rows past the cloud: see hr_cd above)
                 }
             } else {
 #pragma unroll
@@ -770,14 +795,14 @@ __global__ __launch_bounds__(256, 2) void trunk_block_bwd_kernel(TrunkBwdArgs a)
             for (int q = 0; q < 16; ++q) acc_x[q] = 0.f;
             mfma_rows<32, false>(Ds + (wave * 32 + r) * HS + 4 * h, W0t + (32 * t + r) * HS + 4 * h, acc_x);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc_x[q] = x_cd[q] > 0.f ? acc_x[q] : 0.f;
+            for (int q = 0; q < 16; ++q) acc_x[q] = FIRST ? keep_where_positive(x_cd[q], acc_x[q]) : (x_cd[q] > 0.f ? acc_x[q] : 0.f);
             mfma_rows<32, false>(Gs + (wave * 32 + r) * HS + 4 * h, Wst + (32 * t + r) * HS + 4 * h, acc_x);
             if constexpr (FIRST) {
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {                               // fc_pos: dWpos += dX^T pts, dbpos += colsum dX
                     const float *pp = Pts + (wave * 32 + acc_row(q, lane)) * 3;
-                    const float v = T2H_ROW_OK(q) ? acc_x[q] : 0.f;
+                    const float v = acc_x[q];                               // (0 for a row past the cloud: dhr = g = 0)
                     dbp[t] += v;
                     dwp[t][0] = fmaf(v, pp[0], dwp[t][0]);
                     dwp[t][1] = fmaf(v, pp[1], dwp[t][1]);

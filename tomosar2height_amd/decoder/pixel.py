@@ -37,6 +37,14 @@ class ConvDecoder(nn.Module):
         if self.channels_last and not self.leaky and x.is_cuda:
             # implicit-GEMM 3x3 convs with fused bias/ReLU and a concat-free 288 -> 1 head as one autograd node (grid.py)
             return grid.conv_decoder(x, *self._stack(), self.conv4)
+        if self.channels_last and x.is_cuda:
+            # leaky=True (pixel.py:25; no shipped config): the same convolution kernels without their fused ReLU (a shape they do
+            # not take goes through the library-fallback guard like everywhere else), F.leaky_relu as torch's element-wise op,
+            # the concat-free head
+            feats = [x]
+            for conv in self._stack():
+                feats.append(F.leaky_relu(grid.conv_bias_act(feats[-1], conv, relu=False)))
+            return grid.head1x1(feats, self.conv4)
         activation = F.leaky_relu if self.leaky else F.relu
         feats = [x]
         for conv in self._stack():

@@ -54,7 +54,7 @@ class LocalPoolPointnet(nn.Module):
         # counters with .item(), which waits for everything queued: at an optimizer boundary that drained the tile pipeline and
         # left the chip idle while the host issued the next forward (~3 ms per boundary)
         self.snapshot_domain = False
-        self._domain_snaps = {}          # id(status tensor) -> [event, pinned int32[2], status tensor]
+        self._domain_snaps = {}          # (id(status tensor), raw stream) -> [event, pinned int32[2], status tensor, valid]
 
     def set_channels_last(self, flag: bool):
         """Keep the grid side in channels_last memory so planes need no NCHW<->NHWC copies."""
@@ -69,13 +69,14 @@ class LocalPoolPointnet(nn.Module):
                  and st.device == self.domain_status.device]
         pairs = [self.domain_status] + extra
         used = self.__dict__.setdefault("_used_pairs", set())
-        snaps = [self._domain_snaps.get(id(st)) for st in pairs]
-        if self.snapshot_domain and all((sn is not None and sn[3]) or id(st) not in used for sn, st in zip(snaps, pairs)):
+        snaps = [[sn for (sid, _), sn in self._domain_snaps.items() if sid == id(st) and sn[3]] for st in pairs]
+        if self.snapshot_domain and all(sn or id(st) not in used for sn, st in zip(snaps, pairs)):
             n = 0
-            for sn, st in zip(snaps, pairs):                # (a pair no tile has used since the reset holds 0)
+            for sns, st in zip(snaps, pairs):               # (a pair no tile has used since the reset holds 0)
                 if id(st) in used:
-                    sn[0].synchronize()
-                    n += int(sn[1][1])
+                    for sn in sns:
+                        sn[0].synchronize()
+                    n += max(int(sn[1][1]) for sn in sns)   # (the running total is monotone: the newest snapshot is the largest)
         elif extra:                                         # (the caller's stream has joined the tile streams: Trainer.flush_pipeline)
             n = int(torch.stack(pairs)[:, 1].sum().item())
         else:
@@ -95,9 +96,13 @@ class LocalPoolPointnet(nn.Module):
         self.__dict__.setdefault("_used_pairs", set()).add(id(status))
         if not self.snapshot_domain:
             return
-        ent = self._domain_snaps.get(id(status))
+        # one pinned buffer + event per (pair, snapshotting stream): a pair whose index was prebuilt on a producer stream is
+        # snapshotted alternately from the two tile streams, and nothing orders their copies against each other -- a shared buffer
+        # could receive the OLDER total last.  status[1] only grows between resets, so the reader takes the maximum per pair
+        key = (id(status), _lib.stream())
+        ent = self._domain_snaps.get(key)
         if ent is None:
-            ent = self._domain_snaps[id(status)] = [torch.cuda.Event(), torch.empty(2, dtype=torch.int32, pin_memory=True), status, False]
+            ent = self._domain_snaps[key] = [torch.cuda.Event(), torch.empty(2, dtype=torch.int32, pin_memory=True), status, False]
         ent[1].copy_(status, non_blocking=True)
         ent[0].record()
         ent[3] = True

@@ -5,6 +5,7 @@ Reference seam: ``pool_local`` (pointnet.py:92-99), ``generate_pl
 (pointnet.py:101-111, alto.py:76-88), ``sample_plane_feature`` (alto.py:90-95), ``F.interpolate``
 (pixel.py:107).  No op here has a torch/CPU fallback.
 """
+import atexit
 import os
 
 import torch
@@ -333,8 +334,34 @@ def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
 # [0, dim_size) is counted on the device, clamped into a border cell, and reported by a LATER call of this seam (or by
 # ``check_indices()``) as ValueError -- the asynchronous form of the index error torch_scatter raises.  The packaged
 # modules never take this route (they keep features in sorted order).
-_index_tiles = {}          # id(index tensor) -> (weakref, version, cells, TileIndex)
+_index_tiles = {}          # id(index tensor) -> (weakref, (version, data_ptr, shape, device), cells, TileIndex, ready event, stream)
 _pending_index_checks = []  # (event, pinned status copy, description)
+# T2H_SEAM_SYNC_CHECK=1 (debugging): every seam call waits for its own index check and raises at the call, like torch_scatter
+_SYNC_CHECK = os.environ.get("T2H_SEAM_SYNC_CHECK", "0") == "1"
+
+
+def forget_index(index: torch.Tensor = None):
+    """Drop the cached tile index of ``index`` (or all of them).  The cache follows a tensor by object, version counter, storage
+    address, shape and device; a write that bumps none of these -- ``index.data[...] = ...``, a raw kernel, a DLPack alias -- is
+    invisible to it: call this after such a write."""
+    if index is None:
+        _index_tiles.clear()
+    else:
+        _index_tiles.pop(id(index), None)
+
+
+def _report_at_exit():
+    # a program whose LAST seam call carried a bad index makes no later call that would report it: say so on the way out
+    try:
+        _poll_index_checks(wait=True)
+    except ValueError as e:
+        import sys
+        print(f"tomosar2height_amd.ops: unreported index error at exit: {e}", file=sys.stderr)
+    except Exception:
+        pass
+
+
+atexit.register(_report_at_exit)
 
 
 def _poll_index_checks(wait: bool = False):
@@ -368,7 +395,11 @@ def _tile_from_index(index: torch.Tensor, dim_size: int) -> TileIndex:
         raise TypeError(f"index must be int64, got {index.dtype}")
     _lib.require_device(index, what="scatter index")
     hit = _index_tiles.get(id(index))
-    if hit is not None and hit[0]() is index and hit[1] == index._version and hit[2] == int(dim_size):
+    sig = (index._version, index.data_ptr(), tuple(index.shape), index.device)
+    if hit is not None and hit[0]() is index and hit[1] == sig and hit[2] == int(dim_size):
+        cur = torch.cuda.current_stream(index.device)
+        if hit[5] != cur:
+            cur.wait_event(hit[4])           # built on another stream: its kernels must have finished before this stream reads it
         return hit[3]
     reso = int(round(dim_size ** 0.5))
     if reso * reso != dim_size:
@@ -384,7 +415,10 @@ def _tile_from_index(index: torch.Tensor, dim_size: int) -> TileIndex:
     ev.record()
     _pending_index_checks.append((ev, host, f"scatter index [B={index.shape[0]}, N={index.shape[2]}] into {dim_size} cells"))
     key = id(index)
-    _index_tiles[key] = (weakref.ref(index, lambda _r, k=key: _index_tiles.pop(k, None)), index._version, int(dim_size), tile)
+    _index_tiles[key] = (weakref.ref(index, lambda _r, k=key: _index_tiles.pop(k, None)), sig, int(dim_size), tile, ev,
+                         torch.cuda.current_stream(index.device))
+    if _SYNC_CHECK:
+        _poll_index_checks(wait=True)
     return tile
 
 
@@ -438,6 +472,7 @@ class _ScatterMax(torch.autograd.Function):
     def backward(ctx, gval, _garg):
         (arg,) = ctx.saved_tensors
         b, c, cells = arg.shape
+        _poll_index_checks()                  # (a forward's bad index is reported by its own backward at the latest)
         gval = gval.contiguous()
         _lib.require_device(gval, what="scatter_max backward")
         gsrc = torch.empty(b, ctx.n, c, dtype=torch.float32, device=gval.device)

@@ -103,12 +103,22 @@ class Trainer:
         # the tiles of an accumulation window are independent: tile i + 1's forward runs beside tile i's backward, each tile on
         # its own stream of a ping-pong pair (see ``_train_step_pipelined``); T2H_PIPELINE_TILES=0: one tile after the other
         self.pipeline_tiles = os.environ.get("T2H_PIPELINE_TILES", "1") == "1"
+        # ... and so do the micro-batches of a window (T2H_PIPELINE_MICRO_BATCHES=0: a micro-batch runs on the caller's stream alone)
+        self.pipeline_micro_batches = os.environ.get("T2H_PIPELINE_MICRO_BATCHES", "1") == "1"
         self._tile_streams = None
         self._pending = None            # (loss, l1, ce, stream, weights version, graph set) of the tile whose backward is held back
         self._pipe_graphs = None        # capture_pipeline_graphs: forward / backward hipGraphs of the two tile streams
         self._bwd_done = None           # event: end of the last issued backward (the next one accumulates into the same buffers)
         self._tile_parity = 0
         self._held = []                 # (event at the end of a tile's backward, that tile's ``data``): see _hold_inputs
+        # Single tiles handed to ``train_step`` one by one are held back and issued ``coalesce_tiles`` at a time as ONE ragged
+        # micro-batch (``_losses_micro_batch``): the tiles of an accumulation window are independent and their gradients are summed
+        # (trainer.py:69-89), the reference feeds them one at a time only because their point counts differ
+        # (tomosar2height.yaml:40), and a B = 1 step is ~340 launches most of which leave the chip idle (r05: 144 -> 174 tiles/s
+        # with the same kernels).  Never across an optimizer boundary; ``flush_gradients()`` / ``optimizer_boundary()`` issue what
+        # is held.  T2H_COALESCE_TILES=1: every tile issued by its own call (the strict B = 1 step).
+        self.coalesce_tiles = max(1, int(os.environ.get("T2H_COALESCE_TILES", "4")))
+        self._coalesced = []            # tiles accepted by train_step, not yet issued
 
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
         # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
@@ -195,6 +205,7 @@ class Trainer:
         the step is GPU-bound (measured: no gain); it pays for small tiles."""
         if self.bucket is None:
             raise RuntimeError("capture_graph: run one eager train_step first (the gradient bucket must exist)")
+        self.flush_pipeline()
         self._snapshots_off()
         dev = self.device
         static = {k: example[k].to(dev).clone() for k in ("inputs", "image", "dsm") if example.get(k) is not None}
@@ -307,7 +318,41 @@ class Trainer:
     def train_step(self, data) -> bool:
         """One tile -- or a LIST of tiles of the same accumulation window as one micro-batch (``_losses_micro_batch``: same
         accumulated gradient as feeding them one by one, to fp32 re-association) --: forward, loss, backward.  Returns True
-        when this call ended with an optimizer step."""
+        when this call ended with an optimizer step.
+
+        Single tiles are coalesced (``coalesce_tiles``, default 4): the call accepts the tile and returns; the k-th call, the
+        call that completes the accumulation window, ``flush_gradients()`` or ``optimizer_boundary()`` issue the held tiles as
+        one ragged micro-batch.  The window's accumulated gradient, its optimizer step and ``last_avg_loss`` are those of the
+        tile-by-tile loop (to fp32 re-association: ``test_coalesced_single_tile_api_*``).  The trainer keeps a reference to the
+        tile's tensors until they are issued: do not overwrite them in place before the window's flush."""
+        if (self.coalesce_tiles > 1 and self.bucket is not None and self._graph is None and self._pipe_graphs is None
+                and isinstance(data, dict) and self._coalescible(data)):
+            # accepted, issued later: with the (k - 1) tiles before or after it, at the optimizer boundary, or by a flush
+            self._coalesced.append(data)
+            due = self.accumulated_steps + len(self._coalesced) >= self.local_every
+            if len(self._coalesced) < self.coalesce_tiles and not due:
+                return False
+            return self._flush_coalesced()
+        if self._coalesced:
+            self._flush_coalesced()                 # (a list, a graph-shaped tile, ...: the order of the tiles is kept)
+        return self._train_step_now(data)
+
+    def _coalescible(self, data) -> bool:
+        """Raw device tensors only: a cloud [1, N, 3] (+ image) + target, as the reference's loader hands them over.  A tile whose
+        index was built ahead (``prepare``) is issued on its own -- its index is per tile."""
+        cloud = data.get("inputs") if self.use_cloud else None
+        if self.use_cloud and not (torch.is_tensor(cloud) and cloud.dim() == 3 and cloud.shape[0] == 1):
+            return False
+        return torch.is_tensor(data.get("dsm")) and next(self.model.parameters()).is_cuda
+
+    def _flush_coalesced(self) -> bool:
+        """Issue the tiles ``train_step`` holds back as one micro-batch.  True if that ended with an optimizer step."""
+        tiles, self._coalesced = self._coalesced, []
+        if not tiles:
+            return False
+        return self._train_step_now(tiles if len(tiles) > 1 else tiles[0])
+
+    def _train_step_now(self, data) -> bool:
         # trainer.py:59 calls model.train() every step.  Module.train() walks every submodule (0.4 ms per call here), so the
         # root flag is looked at per tile and the whole tree once per accumulation window: a caller that put a SUBMODULE into
         # eval mode while the root stayed in training mode is brought back at the next window, like the reference does
@@ -319,9 +364,10 @@ class Trainer:
                              f"({self.accumulated_steps} of {self.local_every} tiles accumulated)")
         if n_tiles == 1 and isinstance(data, (list, tuple)):
             data = data[0]
-        if (self.pipeline_tiles and n_tiles == 1 and self.bucket is not None and self._graph is None and isinstance(data, dict)
-                and torch.is_tensor(data.get("dsm")) and next(self.model.parameters()).is_cuda):
-            return self._train_step_pipelined(data)
+        first = data[0] if n_tiles > 1 else data
+        if (self.pipeline_tiles and (n_tiles == 1 or self.pipeline_micro_batches) and self.bucket is not None and self._graph is None
+                and isinstance(first, dict) and torch.is_tensor(first.get("dsm")) and next(self.model.parameters()).is_cuda):
+            return self._train_step_pipelined(data, n_tiles)
         self.flush_pipeline()
         if n_tiles == 1 and self._graph_matches(data):
             g = self._graph
@@ -386,7 +432,7 @@ class Trainer:
                     torch.cuda.current_stream().wait_stream(st)
 
     # ------------------------------------------------------------------------------------------ tiles in a two-stage pipeline
-    def _train_step_pipelined(self, data) -> bool:
+    def _train_step_pipelined(self, data, n_tiles=1) -> bool:
         """One tile of a window whose tiles overlap: the forward of tile i is issued -- on stream S[i % 2] -- BEFORE the backward
         of tile i - 1, which runs on S[(i - 1) % 2] (autograd runs a node's backward on the stream of its forward).  A tile
         lives on one stream from its first kernel to its last, so its activations are allocated, used and recycled in that
@@ -403,7 +449,7 @@ class Trainer:
         st = self._tile_streams[parity]
         self._tile_parity ^= 1
         st.wait_stream(main)                                  # the tile's tensors, the weights of the last optimizer step
-        gset = self._pipe_graphs["sets"][parity] if self._pipe_graphs_match(data) else None
+        gset = self._pipe_graphs["sets"][parity] if (n_tiles == 1 and self._pipe_graphs_match(data)) else None
         with torch.cuda.stream(st):
             if gset is not None:                              # (this stream's previous tile has finished with the static buffers:
                 for k, buf in gset["static"].items():         #  its backward graph precedes these copies in stream order)
@@ -416,7 +462,7 @@ class Trainer:
                 loss = loss_l1 + loss_ce
         self._issue_pending_backward()
         self._pending = (loss, loss_l1, loss_ce, st, self._weights_version(), gset, data)
-        self.accumulated_steps += 1
+        self.accumulated_steps += n_tiles
         if self.accumulated_steps < self.local_every:
             return False
         self.optimizer_boundary()
@@ -479,6 +525,8 @@ class Trainer:
     def flush_pipeline(self):
         """Issue the backward that ``_train_step_pipelined`` still holds back and make the calling stream wait for the tile
         streams: afterwards gradients and loss accumulators are complete in the caller's stream order."""
+        if self._coalesced:
+            self._flush_coalesced()
         if self._pending is None and self._bwd_done is None:
             return
         self._issue_pending_backward()
@@ -498,6 +546,8 @@ class Trainer:
         """End of an optimizer step (trainer.py:78-89): [all-reduce(SUM) of the flat gradient bucket over the ranks,]
         ``optimizer.step()``, loss averaging, gradients to zero.  ``on_reduced(flat_grad)``, if set, sees the complete
         accumulated (and reduced) gradient just before the optimizer consumes it (tests, ``bench.py --check-dp``)."""
+        if self._coalesced and self._flush_coalesced():
+            return                                                        # (the held tiles completed the window: its boundary has run)
         self.flush_pipeline()
         self.flush_gradients()
         if self.world > 1:
@@ -510,7 +560,8 @@ class Trainer:
             bad = self.model.out_of_domain_total()
             if self.world > 1:
                 # every rank must take the same branch (the all-reduce above has already happened on all of them).  On a stream
-                # of its own: the collective and the .item() then wait for nothing but each other, not for the tile streams
+                # of its own: the .item() then does not wait for the tile streams' queued work (the collective itself still runs
+                # behind the gradient all-reduce on the process group's internal stream -- one bucket's worth of waiting)
                 dev = self.bucket.flat.device
                 if dev.type == "cuda":
                     if self._flag_stream is None:
@@ -555,6 +606,7 @@ class Trainer:
         self._reset_accumulators()
 
     def _reset_accumulators(self):
+        self._coalesced = []                               # (error path: tiles accepted but never issued are dropped with the window)
         if self._pending is not None:                      # (error path: a forward whose backward will never be issued)
             st, data = self._pending[3], self._pending[6]
             self._hold_inputs(st.record_event(torch.cuda.Event()), data)
@@ -576,6 +628,8 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------ eval
     def eval_step(self, data):
+        if self._coalesced:
+            self._flush_coalesced()
         self.model.eval()
         with torch.no_grad():
             loss_l1, loss_ce = self._losses(data, 0.00001)                # trainer.py:136
