@@ -384,10 +384,12 @@ def check_dp(args, world, rank, dev, group, model, make_trainer):
 
     null_opt = torch.optim.SGD(model.parameters(), lr=0.0)
     dp = make_trainer(null_opt, 2 * world, group)
-    dp.on_reduced = grab("dp")
+    dp.coalesce_tiles = 1           # tile by tile on both sides: the difference is then the ranks' summation order alone (a rank's
+    dp.on_reduced = grab("dp")      # 2 tiles and the single run's 2W tiles would otherwise be cut into different micro-batches)
     for i in range(2):
         dp.train_step(tiles[rank + i * world])           # rank r: tiles r, r + W  (i mod W == r)
     single = make_trainer(null_opt, 2 * world, None)
+    single.coalesce_tiles = 1
     single.on_reduced = grab("single")
     for t in tiles:
         single.train_step(t)
@@ -721,13 +723,19 @@ def main():
         g = max(1, trainer.coalesce_tiles)
         trainer.flush_pipeline()
         trainer.accumulated_steps = trainer.accumulated_steps // g * g       # (whole groups: a group is one issue)
+        lone_cpu = []
         for _ in range(8):
             fence()
-            th = time.perf_counter()
+            th, tc = time.perf_counter(), time.process_time()
             run(g)
             lone.append((time.perf_counter() - th) / g)
+            lone_cpu.append((time.process_time() - tc) / g)
         fence()
         sustained["host_issue_ms_empty_queue"] = round(1e3 * statistics.median(lone), 3)
+        # CPU time of this process (all threads) while issuing onto an empty queue: what the step costs the host when nothing
+        # blocks.  `host_cpu_ms_per_step` above is taken while the queue is full: it then mostly counts the HIP runtime's
+        # spin-waits for queue space (about two threads' worth of the wall time), not work
+        sustained["host_cpu_ms_empty_queue"] = round(1e3 * statistics.median(lone_cpu), 3)
 
     # ---- leg 1c: the same step with the convolutions in the EXACT split arithmetic (never part of `value`): what `dtype: f32`
     # costs when no block-floating-point caveat is accepted (DESIGN 4.1a vs 4.1b)

@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 14
+#define T2H_ABI_VERSION 15
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -558,6 +558,28 @@ int t2h_nchw_to_nhwc(const float *in, int B, int C, int P, float *out, t2h_strea
 int t2h_nhwc_to_nchw(const float *in, int B, int C, int P, float *out, t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * sample_mode = 'bicubic' (r06; no shipped config selects it: tomosar2height.yaml:27)
+ *   F.interpolate(c, size, mode='bicubic', align_corners=True)                            decoder/pixel.py:107,110
+ *   F.grid_sample(c, vgrid, padding_mode='border', align_corners=True, mode='bicubic')    encoder/alto.py:95,204
+ * ATen's cubic convolution (A = -0.75), taps outside the plane clamped to the border pixel.  Planes [B, C, h, w] in NCHW or
+ * (channels_last != 0) NHWC memory.  t2h_upsample_bicubic_bwd is a gather (deterministic); t2h_sample_bicubic_bwd zeroes gplane
+ * and adds with atomics (like t2h_sample_bwd_atomic: the order of its additions is not reproducible run to run).
+ *   pts   [B * N, dim] rows with x, y in the plane's [0, 1] coordinates (vgrid = 2 xy - 1);  out / gout [B * N, C] point-major */
+int t2h_upsample_bicubic_fwd(const float *in, const float *addend, int B, int C, int h, int w, int H, int W, int channels_last,
+                             float *out, t2h_stream_t stream);
+int t2h_upsample_bicubic_bwd(const float *gout, int B, int C, int h, int w, int H, int W, int channels_last, float *gin,
+                             t2h_stream_t stream);
+int t2h_sample_bicubic_fwd(const float *plane, const float *pts, int dim, int B, int64_t N, int r, int C, int channels_last,
+                           float *out, t2h_stream_t stream);
+int t2h_sample_bicubic_bwd(const float *gout, const float *pts, int dim, int B, int64_t N, int r, int C, int channels_last,
+                           float *gplane, t2h_stream_t stream);
+/* mode = 'nearest' of the same call (grid_sampler_2d: the coordinate clipped to the plane, then rounded half to even) */
+int t2h_sample_nearest_fwd(const float *plane, const float *pts, int dim, int B, int64_t N, int r, int C, int channels_last,
+                           float *out, t2h_stream_t stream);
+int t2h_sample_nearest_bwd(const float *gout, const float *pts, int dim, int B, int64_t N, int r, int C, int channels_last,
+                           float *gplane, t2h_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * nn.Conv2d(Cin <= 8, Cout, 3, padding=1): the image U-Net's first layer              encoder/unet.py:112-187
  * (Conv2d(3, 32, ...) at 512 x 512: the one convolution of the image configs that t2h_conv3x3_* does not take --
  * their reduction runs in 16-channel slabs).  NHWC activations, weight memory [Cout][3][3][Cin], Cout % 4 == 0, <= 64.
@@ -587,6 +609,24 @@ int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const flo
                         const float *w1, const float *b1, const float *ws, const float *wc, const float *bc, int64_t M,
                         float *x_full, float *pooled, float *hr, float *out, int ld_out, uint8_t *winner, float *c_out,
                         t2h_stream_t stream);
+
+/* r06 (ABI 15): the whole trunk forward of pointnet.py:72-82 -- fc_pos, n_blocks x ResnetBlockFC(64 -> 32) with the
+ * pool_local (scatter_max + gather + cat, pointnet.py:76-78, 92-99) between them, fc_c -- in ONE launch, for hidden_dim = 32.
+ * All poolings use the same finest-level cells (pointnet.py:70), and a cell is a run of consecutive sorted rows, so a workgroup
+ * that owns whole cells needs nothing from its neighbours between the blocks: the activations of its rows stay in LDS from the
+ * points to c.  What is written is what the backward (t2h_trunk_block_bwd) reads: per block b the hidden activations hr[b] and
+ * the output out[b] ([M, 32] each), for b >= 1 the pooled half pooled[b] [M, 32] and the arg-max bits winner[b] [M, 8] of the
+ * pooling that feeds block b (pooled[0] / winner[0] are not read), and c_out [M, 32].  Results are bit-identical to
+ * n_blocks t2h_trunk_block_fwd launches.
+ *   block_params  HOST array of 5 * n_blocks DEVICE pointers: w0, b0, w1, b1, ws of block 0, then of block 1, ...
+ *   hr, out, pooled, winner   HOST arrays of n_blocks device pointers
+ *   stride        rows per work unit before snapping to cell boundaries (0: default 112, at most 128); units of more than 128
+ *                 rows (a cell of more than 129 - stride rows at a unit's end) run block by block through memory inside the launch
+ * 2 <= n_blocks <= 8. */
+int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *const *block_params,
+                        int n_blocks, const float *wc, const float *bc, const int32_t *cell, const int32_t *off0, int64_t M,
+                        float *const *hr, float *const *out, float *const *pooled, uint8_t *const *winner, float *c_out,
+                        int stride, t2h_stream_t stream);
 
 /* Backward of t2h_trunk_block_fwd, one launch per block (+ one small reduction):
  *     g   = g_net + route(sum over each row's cell of g_pool)     (g_pool != NULL: the backward of the pooling that

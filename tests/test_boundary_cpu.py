@@ -142,6 +142,13 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_upsample2x_nhwc_bwd": (n, 1, 32, 16, 16, n, n),
         "t2h_bias_relu_fwd": (n, n, 100, 32, 1, n),
         "t2h_bias_relu_bwd": (n, n, n, 100, 32, 1, 0, n, n, 0, n),
+        "t2h_upsample_bicubic_fwd": (n, n, 1, 32, 16, 16, 32, 32, 0, n, n),
+        "t2h_upsample_bicubic_bwd": (n, 1, 32, 16, 16, 32, 32, 0, n, n),
+        "t2h_sample_bicubic_fwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
+        "t2h_sample_bicubic_bwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
+        "t2h_sample_nearest_fwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
+        "t2h_sample_nearest_bwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
+        "t2h_trunk_fused_fwd": (n, 3, n, n, n, 5, n, n, n, n, 100, n, n, n, n, n, 0, n),
         "t2h_head1x1_fwd": (n, n, 4, n, n, 100, n, n),
         "t2h_head1x1_bwd": (n, n, n, 4, n, n, 100, 0, n, n, n, 0, n),
         "t2h_relu_mask": (n, n, n, 128, n),

@@ -137,16 +137,20 @@ def test_walks_beside_the_split_convolutions_are_bit_identical():
 
 
 @gpu
-@pytest.mark.parametrize("ahead,points,image,windows", [(False, 40000, False, 8), (True, 40000, False, 8), (False, 131072, False, 4),
-                                                        (False, 40000, True, 8)],
-                         ids=["lazy", "prepared", "benchmark-size", "cloud+image"])
-def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, points, image, windows):
-    """Four-tile windows through the tile pipeline (tile indices built ahead on a side stream or inside the step; the benchmarked
-    N = 131 072; BASELINE configs[2] with the image U-Net), each against the same window with a device synchronise after every step:
-    losses and every gradient bit for bit, every time -- before the fix above 4-50 % of the windows differed."""
+@pytest.mark.parametrize("ahead,points,image,windows,coalesce",
+                         [(False, 40000, False, 8, 1), (True, 40000, False, 8, 1), (False, 131072, False, 4, 1), (False, 40000, True, 8, 1),
+                          (False, 40000, False, 8, 4), (False, 131072, False, 4, 4), (False, 40000, True, 8, 4)],
+                         ids=["lazy", "prepared", "benchmark-size", "cloud+image",
+                              "coalesced", "coalesced-benchmark-size", "coalesced-cloud+image"])
+def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, points, image, windows, coalesce):
+    """Windows through the tile pipeline (tile indices built ahead on a side stream or inside the step; the benchmarked
+    N = 131 072; BASELINE configs[2] with the image U-Net; tile by tile -- four tiles -- and, r06, with the Trainer's default
+    coalescing: nine tiles = micro-batches of 1, 4 and 4 whose forwards and backwards overlap), each against the same window with a
+    device synchronise after every step: losses and every gradient bit for bit, every time -- before the r05 fix 4-50 % of the
+    windows differed.  r06: the cloud+image case is a hard assertion like the others (it was reported as an expected failure)."""
     det_init_, synth_cloud, TomoSAR2Height, berlin_config, Trainer = _setup()
     dev = torch.device("cuda:0")
-    tiles = _tiles(synth_cloud, dev, 4, points)
+    tiles = _tiles(synth_cloud, dev, 4 if coalesce == 1 else 9, points)
     if image:
         for i, t in enumerate(tiles):
             t["image"] = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(40 + i)).to(dev)
@@ -156,6 +160,7 @@ def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, poi
         model = det_init_(TomoSAR2Height(cfg), seed=15).to(dev)
         model.set_channels_last(True)
         tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True, use_image=image)
+        tr.coalesce_tiles = coalesce
         side = torch.cuda.Stream() if ahead else None
         prep = (lambda t: tr.prepare(t, side)) if ahead else (lambda t: t)
         losses, inner = [], tr._losses
@@ -177,7 +182,8 @@ def test_pipelined_window_equals_the_step_synchronised_one_every_time(ahead, poi
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, [float(x) for x in losses]
 
-    gold, gold_losses = run(False, True)
+    gold, gold_losses = run(ahead, True)
+    assert len(gold_losses) == (4 if coalesce == 1 else 3)           # (tile by tile; or micro-batches of 1 + 4 + 4 tiles)
     differing = []
     for it in range(windows):
         got, losses = run(ahead, False)

@@ -86,6 +86,50 @@ def test_fused_forward_vs_unfused_and_pool_exact(name):
         np.testing.assert_allclose(got.cpu().numpy(), out.cpu().numpy(), rtol=0, atol=2e-6 * (out.abs().max().item() + 1))
 
 
+@pytest.mark.parametrize("name", ["ragged", "tiny", "single", "one_cell", "ties", "big", "benchmark", "dense_cells", "batch"])
+@pytest.mark.parametrize("stride", [0, 96, 128, 40])
+def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride):
+    """r06: t2h_trunk_fused_fwd (fc_pos -> 5 blocks with their 4 poolings -> fc_c in ONE launch, whole cells per workgroup,
+    activations in LDS) against the five t2h_trunk_block_fwd launches: every tensor the backward reads -- hr and out of every
+    block, the pooled halves, the winner bits -- and c, bit for bit.  Clouds: ragged sizes, fewer rows than a tile, one row, ONE
+    CELL holding 700 rows and a tile of ~80 points per cell (work units longer than a tile: the block-by-block path inside the
+    launch), exact ties, the benchmark tile, a ragged batch of three tiles; unit strides 112 (default), 96, 128 and 40."""
+    from tomosar2height_amd import mlp
+    from tomosar2height_amd.synthetic import berlin_tile
+    from tomosar2height_amd.tile import TileIndex
+    enc = _trunk_modules(seed=13)
+    reso = 256
+    if name == "benchmark":
+        cloud = berlin_tile(seed=3, n_points=131072)["inputs"].to(_dev())
+    elif name == "dense_cells":
+        cloud, reso = synth_cloud(20000, seed=8).to(_dev()), 16
+    elif name == "batch":
+        cloud = [synth_cloud(n, seed=20 + i).to(_dev()) for i, n in enumerate((5000, 777, 12001))]
+    else:
+        cloud = _clouds()[name].to(_dev())
+    tile = TileIndex(cloud, reso)
+    params = [p.detach() for p in _params(enc)]
+    nb = len(enc.blocks)
+    blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
+    old = (mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE)
+    try:
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE = True, stride
+        one = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+        mlp._TRUNK_FUSED = False
+        per = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+    finally:
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE = old
+    names = ("c", "nets", "pooled", "hrs", "winners")
+    assert torch.equal(one[0], per[0]), "c"
+    for what, a, b in zip(names[1:], one[1:], per[1:]):
+        assert len(a) == len(b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            if x is None or y is None:
+                assert x is None and y is None
+                continue
+            assert torch.equal(x, y), f"{what}[{i}] differs ({int((x != y).sum())} of {x.numel()} elements)"
+
+
 def test_fused_pool_matches_c_oracle_scatter_max():
     """The in-loader pooling against the oracle's restated torch_scatter semantics (first maximum wins, pointnet.py:92-99)."""
     from oracle import scatter_ref

@@ -478,6 +478,274 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
 
 
 // =====================================================================================================================
+// r06: the WHOLE trunk forward in one launch (pointnet.py:72-82): fc_pos -> block 0 -> n x {pool_local, block} -> fc_c.
+//
+// All poolings of the trunk use the SAME finest-level cells (pointnet.py:70, 76-79), and after the tile sort a cell is a run of
+// consecutive rows.  A workgroup that owns WHOLE cells therefore needs nothing from any other workgroup between the blocks: work
+// unit k = the cells whose first row lies in [k S, (k + 1) S) (S = `stride` rows, 112 by default), found from `cell` / `off0`
+// with two dependent loads per boundary.  A unit of at most TR = 128 rows (every unit unless a cell with more than TR - S + 1
+// rows starts near its end) takes the FAST path: X = fc_pos(points) is formed in LDS, every block's output goes back into the
+// left half of the X tile from the MFMA registers, the segmented max runs on the tile in LDS (head masks of the unit's cells by
+// one ballot, kept in registers for all blocks; each row scans its own cell: the strict '>' scan of pool_into_tile_v2, no border
+// cells), and only what the backward reads leaves the chip: hr, out, the pooled half and the winner bits of every block, c.
+// Between two blocks: one barrier before the pooling (all waves have written their rows of `out`), one after it (which also covers
+// the next block's weights: they are fetched from L2 into LDS beside the pooling).  A longer unit takes the SLOW path inside the same
+// launch: block by block over 128-row chunks with the one-block loader (pool_into_tile: its border runs are rows of this unit,
+// written by this workgroup and published by a device-scope fence + barrier between the blocks) -- correct for any cell size,
+// one workgroup per heavy unit.  Arithmetic and summation order per element are those of trunk_block_fwd_kernel: the two forms
+// agree bit for bit (tests/test_hip_trunk.py).
+constexpr int kMaxTrunkBlocks = 8;
+struct TrunkFusedArgs {
+    const float *pts; int dim; const float *wpos, *bpos;
+    const float *w0[kMaxTrunkBlocks], *b0[kMaxTrunkBlocks], *w1[kMaxTrunkBlocks], *b1[kMaxTrunkBlocks], *ws[kMaxTrunkBlocks];
+    const float *wc, *bc;
+    const int32_t *cell, *off0;
+    int M, nb, stride, n_units;
+    int ablate;          // lab builds (-DT2H_TRUNK_ABLATE) only: bit 0 no pooling, 1 no global stores, 2 weights staged once, 3 no MFMAs
+    float *hr[kMaxTrunkBlocks], *out[kMaxTrunkBlocks], *pooled[kMaxTrunkBlocks];
+    uint8_t *winner[kMaxTrunkBlocks];
+    float *c_out;
+};
+
+#ifdef T2H_TRUNK_ABLATE
+#define T2H_ABL(a, bit) (((a).ablate >> (bit)) & 1)
+#else
+#define T2H_ABL(a, bit) 0
+#endif
+
+__device__ inline int unit_start(const TrunkFusedArgs &a, int k) {
+    const long long row = (long long)k * a.stride;
+    if (row >= a.M) return a.M;
+    const int c = a.cell[row], st = a.off0[c];
+    return st == (int)row ? (int)row : a.off0[c + 1];
+}
+
+// block weights -> LDS (row-major [n][k], padded rows); the caller separates this from the GEMMs that read them by a barrier
+__device__ inline void stage_block_weights(const TrunkFusedArgs &a, int b, float *W0s, float *Wss, float *W1s, float *Wcs, float *bsm,
+                                           int tid) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int idx = tid + f * 256, n = idx >> 4, k4 = (idx & 15) * 4;
+        *reinterpret_cast<float4 *>(W0s + n * XS + k4) = *reinterpret_cast<const float4 *>(a.w0[b] + n * 64 + k4);
+        *reinterpret_cast<float4 *>(Wss + n * XS + k4) = *reinterpret_cast<const float4 *>(a.ws[b] + n * 64 + k4);
+    }
+    const int n = tid >> 3, k4 = (tid & 7) * 4;
+    *reinterpret_cast<float4 *>(W1s + n * HS + k4) = *reinterpret_cast<const float4 *>(a.w1[b] + n * 32 + k4);
+    if (b == a.nb - 1) *reinterpret_cast<float4 *>(Wcs + n * HS + k4) = *reinterpret_cast<const float4 *>(a.wc + n * 32 + k4);
+    if (tid < 32) { bsm[tid] = a.b0[b][tid]; bsm[32 + tid] = a.b1[b][tid]; if (b == a.nb - 1) bsm[64 + tid] = a.bc[tid]; }
+}
+
+// the GEMMs of one block on this wave's 32 rows of the X tile (the code of trunk_block_fwd_kernel, same order of operations);
+// rows [row0, row_end) of the tile are real.  keep: also write `out` into the left half of this wave's X rows (next block's input)
+__device__ inline void fused_block_gemms(float *Xs, float *Hsm, const float *W0s, const float *Wss, const float *W1s, const float *Wcs,
+                                         const float *bsm, int row0, int row_end, float *hr, float *out, float *c_out, bool last,
+                                         bool keep, int lane, int wave, int abl = 0) {
+    const bool no_store = (abl >> 1) & 1, no_mfma = (abl >> 3) & 1;          // (lab builds only: always 0 otherwise)
+    const int r = lane & 31, h = lane >> 5;
+    const float *xa = Xs + (wave * 32 + r) * XS + 4 * h;
+    const int rb = row0 + wave * 32 + 4 * h;
+    f32x16 acc_h, acc_s, acc_d;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc_h[q] = 0.f; acc_s[q] = 0.f; acc_d[q] = 0.f; }
+    if (!no_mfma) mfma_rows_pair<64>(xa, W0s + r * XS + 4 * h, Wss + r * XS + 4 * h, acc_h, acc_s);
+    float *ht = Hsm + wave * 32 * HS;
+    {
+        const float b0 = bsm[r];
+        float *hp = hr + (size_t)rb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            const float v = fmaxf(acc_h[q] + b0, 0.f);
+            ht[(ro + 4 * h) * HS + r] = v;
+            if (rb + ro < row_end && !no_store) hp[ro * 32] = v;
+        }
+    }
+    wave_sync();
+    if (!no_mfma) mfma_rows<32, false>(ht + r * HS + 4 * h, W1s + r * HS + 4 * h, acc_d);
+    {
+        const float b1 = bsm[32 + r];
+        float *op = out + (size_t)rb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            acc_s[q] = acc_s[q] + (acc_d[q] + b1);
+            if (rb + ro < row_end && !no_store) op[(size_t)ro * 32] = acc_s[q];
+        }
+    }
+    if (last) {
+        float *ot = Xs + wave * 32 * XS;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ot[acc_row(q, lane) * HS + r] = acc_s[q];
+        wave_sync();
+        f32x16 acc_c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc_c[q] = 0.f;
+        mfma_rows<32, true>(ot + r * HS + 4 * h, Wcs + r * HS + 4 * h, acc_c);
+        const float bc = bsm[64 + r];
+        float *cp = c_out + (size_t)rb * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            if (rb + ro < row_end) cp[ro * 32] = acc_c[q] + bc;
+        }
+    } else if (keep) {
+        // this wave's rows of X are consumed (only this wave reads them in the GEMM phase): the block's output becomes the left
+        // half of the next block's input; rows past the unit hold zeros like the loader's
+        float *xt = Xs + (wave * 32) * XS;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ro = (q & 3) + 8 * (q >> 2);
+            xt[(ro + 4 * h) * XS + r] = rb + ro < row_end ? acc_s[q] : 0.f;
+        }
+    }
+}
+
+// fc_pos of the unit's (or chunk's) points -> the X tile (the loader of the FIRST variant)
+__device__ inline void fused_fc_pos(const TrunkFusedArgs &a, float *Xs, const float *wps, int r0, int r1, int tid) {
+    const int row = tid >> 1, c0 = (tid & 1) * 32;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (r0 + row < r1) {
+        const float *p = a.pts + (size_t)(r0 + row) * a.dim;
+        p0 = p[0]; p1 = p[1]; p2 = p[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = c0 + c + j;
+            float acc = wps[192 + n];
+            acc = fmaf(p0, wps[n * 3 + 0], acc);
+            acc = fmaf(p1, wps[n * 3 + 1], acc);
+            acc = fmaf(p2, wps[n * 3 + 2], acc);
+            v[j] = r0 + row < r1 ? acc : 0.f;
+        }
+        *reinterpret_cast<float4 *>(Xs + row * XS + c0 + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// segmented max of the unit's rows (left half of the X tile, whole cells only) -> right half, winner bits and pooled half to
+// global.  m0 / m1: head masks of the unit's cells (bit i: tile row i starts a cell; rows past the unit are heads of their own)
+__device__ inline void fused_pool_local(float *Xs, unsigned long long m0, unsigned long long m1, int s, int rows, uint8_t *winner,
+                                        float *pooled, int tid, int abl = 0) {
+    const int lane = tid & (G - 1), grp = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int me = p * NG + grp;
+        if (me >= rows) {
+            *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int cs = mask_prev_head(m0, m1, me), ce = mask_next_head(m0, m1, me);
+        Best b; best_init(b);
+        int n = cs;
+        for (; n + 3 < ce; n += 4) {
+            const float *xp = Xs + n * XS + lane * 4;
+            const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + XS);
+            const float4 v2 = *reinterpret_cast<const float4 *>(xp + 2 * XS), v3 = *reinterpret_cast<const float4 *>(xp + 3 * XS);
+            best_strict(b, v0, n); best_strict(b, v1, n + 1); best_strict(b, v2, n + 2); best_strict(b, v3, n + 3);
+        }
+        for (; n < ce; ++n) best_strict(b, *reinterpret_cast<const float4 *>(Xs + n * XS + lane * 4), n);
+        const float4 pv = make_float4(b.a.x == -1 ? 0.f : b.v.x, b.a.y == -1 ? 0.f : b.v.y, b.a.z == -1 ? 0.f : b.v.z,
+                                      b.a.w == -1 ? 0.f : b.v.w);
+        *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = pv;
+        if ((abl >> 1) & 1) continue;
+        *reinterpret_cast<float4 *>(pooled + (size_t)(s + me) * 32 + lane * 4) = pv;
+        winner[(size_t)(s + me) * G + lane] = (uint8_t)((b.a.x == me) | ((b.a.y == me) << 1) | ((b.a.z == me) << 2) | ((b.a.w == me) << 3));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float Xs[TR * XS];
+    __shared__ __attribute__((aligned(16))) float Hsm[TR * HS];
+    __shared__ __attribute__((aligned(16))) float W0s[32 * XS];
+    __shared__ __attribute__((aligned(16))) float Wss[32 * XS];
+    __shared__ __attribute__((aligned(16))) float W1s[32 * HS];
+    __shared__ __attribute__((aligned(16))) float Wcs[32 * HS];
+    __shared__ float bsm[96];
+    __shared__ float wps[256];
+    __shared__ int unit[2];
+    __shared__ unsigned long long heads[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 192) wps[tid] = a.wpos[tid];
+    if (tid < 64) wps[192 + tid] = a.bpos[tid];
+    for (int k = blockIdx.x; k < a.n_units; k += gridDim.x) {
+        __syncthreads();                                     // the previous unit is done with every LDS buffer (and wps is staged)
+#ifdef T2H_TRUNK_ABLATE
+        const int abl = a.ablate;
+        if (tid == 0) {
+            if (abl & 16) { unit[0] = min(k * a.stride, a.M); unit[1] = min((k + 1) * a.stride, a.M); }
+            else { unit[0] = unit_start(a, k); unit[1] = unit_start(a, k + 1); }
+        }
+#else
+        constexpr int abl = 0;
+        if (tid == 0) { unit[0] = unit_start(a, k); unit[1] = unit_start(a, k + 1); }
+#endif
+        stage_block_weights(a, 0, W0s, Wss, W1s, Wcs, bsm, tid);
+        __syncthreads();
+        const int s = unit[0], e = unit[1], rows = e - s;
+        if (rows <= 0) continue;                             // (uniform: the cell that starts before k S covers the whole window)
+        if (rows <= TR) {
+            // ---------------------------------------------------------------- fast path: the unit lives in LDS for all blocks
+            int *cells = reinterpret_cast<int *>(Hsm);       // (Hsm is free until the first GEMM)
+            if (tid < TR) cells[tid] = tid < rows ? a.cell[s + tid] : -1 - tid;
+            fused_fc_pos(a, Xs, wps, s, e, tid);
+            __syncthreads();
+            if (tid < TR) {
+                const bool head = tid == 0 || cells[tid] != cells[tid - 1];
+                const unsigned long long m = __ballot(head);
+                if ((tid & 63) == 0) heads[tid >> 6] = m;
+            }
+            __syncthreads();
+            const unsigned long long m0 = heads[0], m1 = heads[1];
+            for (int b = 0; b < a.nb; ++b) {
+                const bool last = b == a.nb - 1;
+                if (wave * 32 < rows)
+                    fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, s, e, a.hr[b], a.out[b], a.c_out, last, !last, lane, wave, abl);
+                else if (!last) {                           // a wave without rows still owes the next loader its zero rows
+                    for (int i = lane; i < 32 * 8; i += 64)
+                        *reinterpret_cast<float4 *>(Xs + (wave * 32 + (i >> 3)) * XS + (i & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (last) break;
+                __syncthreads();                             // every wave's `out` rows are in the tile; the block's weights are consumed
+                if (!(abl & 4)) stage_block_weights(a, b + 1, W0s, Wss, W1s, Wcs, bsm, tid);
+                if (!(abl & 1)) fused_pool_local(Xs, m0, m1, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
+                __syncthreads();
+            }
+        } else {
+            // ---------------------------------------------------------------- slow path: chunks of TR rows, block by block, through HBM
+            for (int b = 0; b < a.nb; ++b) {
+                const bool last = b == a.nb - 1;
+                if (b > 0) {
+                    __threadfence();                         // this workgroup's `out` rows of the previous block, device-wide
+                    __syncthreads();
+                    stage_block_weights(a, b, W0s, Wss, W1s, Wcs, bsm, tid);
+                    __syncthreads();
+                }
+                TrunkFwdArgs t{};
+                t.net_prev = b > 0 ? a.out[b - 1] : nullptr; t.ld_prev = 32; t.cell = a.cell; t.off0 = a.off0;
+                t.M = a.M; t.pooled = a.pooled[b]; t.winner = a.winner[b]; t.loader = 1;
+                for (int c0 = s; c0 < e; c0 += TR) {
+                    const int c1 = min(c0 + TR, e);
+                    if (b == 0) { fused_fc_pos(a, Xs, wps, c0, c1, tid); __syncthreads(); }
+                    else {
+                        pool_into_tile(t, Xs, Hsm, c0, c1, tid);
+                        for (int f = 0; f < 4; ++f) {        // the pooled half the backward reads: every wave its own rows
+                            const int idx = lane + f * 64, row = wave * 32 + (idx >> 3), c = (idx & 7) * 4;
+                            if (c0 + row < c1)
+                                *reinterpret_cast<float4 *>(a.pooled[b] + (size_t)(c0 + row) * 32 + c) =
+                                    *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
+                        }
+                    }
+                    fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, c0, c1, a.hr[b], a.out[b], a.c_out, last, false, lane, wave);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
 // Backward of one block (resnet.py:36-54 + the gather / scatter_max backward of pointnet.py:92-99), one launch:
 //
 //     g    = g_net + route(sum over the cell of g_pool)       (the pooling's backward, folded into this loader;
@@ -958,6 +1226,41 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     else hipLaunchKernelGGL((trunk_block_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
     note_kernel(first ? "trunk_block_fwd_kernel<true,false>" : (last ? "trunk_block_fwd_kernel<false,true>" : "trunk_block_fwd_kernel<false,false>"));
     return check_launch("trunk_block_fwd");
+}
+
+T2H_API int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *const *block_params,
+                                int n_blocks, const float *wc, const float *bc, const int32_t *cell, const int32_t *off0, int64_t M,
+                                float *const *hr, float *const *out, float *const *pooled, uint8_t *const *winner, float *c_out,
+                                int stride, t2h_stream_t stream) {
+    if (!pts || !w_pos || !b_pos || !block_params || !wc || !bc || !cell || !off0 || !hr || !out || !pooled || !winner || !c_out)
+        return fail(T2H_ERR_ARG, "trunk_fused_fwd: null pointer");
+    if (n_blocks < 2 || n_blocks > kMaxTrunkBlocks) return fail(T2H_ERR_ARG, "trunk_fused_fwd: 2 <= n_blocks <= %d", kMaxTrunkBlocks);
+    if (dim < 3 || M < 0 || M >= ((int64_t)1 << 31) - TR) return fail(T2H_ERR_ARG, "trunk_fused_fwd: bad shape");
+    int ablate = 0;
+#ifdef T2H_TRUNK_ABLATE
+    ablate = stride >> 8; stride &= 255;
+#endif
+    if (stride <= 0) stride = 112;
+    if (stride > TR) return fail(T2H_ERR_ARG, "trunk_fused_fwd: stride must be <= %d rows", TR);
+    if (M == 0) return T2H_OK;
+    TrunkFusedArgs a{};
+    a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos; a.wc = wc; a.bc = bc; a.cell = cell; a.off0 = off0;
+    a.M = (int)M; a.nb = n_blocks; a.stride = stride; a.c_out = c_out; a.ablate = ablate;
+    a.n_units = (int)((M + stride - 1) / stride);
+    for (int b = 0; b < n_blocks; ++b) {
+        a.w0[b] = block_params[5 * b]; a.b0[b] = block_params[5 * b + 1]; a.w1[b] = block_params[5 * b + 2];
+        a.b1[b] = block_params[5 * b + 3]; a.ws[b] = block_params[5 * b + 4];
+        a.hr[b] = hr[b]; a.out[b] = out[b]; a.pooled[b] = pooled[b]; a.winner[b] = winner[b];
+        if (!a.w0[b] || !a.b0[b] || !a.w1[b] || !a.b1[b] || !a.ws[b] || !a.hr[b] || !a.out[b] || (b > 0 && (!a.pooled[b] || !a.winner[b])))
+            return fail(T2H_ERR_ARG, "trunk_fused_fwd: null pointer in block %d", b);
+        if (!al16(a.w0[b]) || !al16(a.w1[b]) || !al16(a.ws[b]) || !al16(a.hr[b]) || !al16(a.out[b]) || (b > 0 && !al16(a.pooled[b])))
+            return fail(T2H_ERR_ARG, "trunk_fused_fwd: pointers must be 16-byte aligned");
+    }
+    if (!al16(wc) || !al16(c_out)) return fail(T2H_ERR_ARG, "trunk_fused_fwd: pointers must be 16-byte aligned");
+    const dim3 grid((unsigned)(a.n_units < 512 ? a.n_units : 512));       // two resident per CU, each walks its units
+    hipLaunchKernelGGL(trunk_fused_fwd_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    note_kernel("trunk_fused_fwd_kernel");
+    return check_launch("trunk_fused_fwd");
 }
 
 constexpr int kTrunkSlabFloats = 6240;      // 5184 shared + max(last: 1024 + 32, first: 192 + 64), multiple of 4

@@ -76,12 +76,11 @@ class PixelwiseDecoder(nn.Module):
     def __init__(self, hidden_dim=32, out_dim=1, output_size=512, leaky=False, sample_mode="bilinear", mode="conv",
                  use_footprint=False, **kwargs):
         super().__init__()
-        if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
-                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
-                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
-                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
-                                      "no kernel here")
+        if sample_mode not in ("bilinear", "bicubic"):
+            raise NotImplementedError("sample_mode must be 'bilinear' (every shipped config, tomosar2height.yaml:27) or 'bicubic'.  "
+                                      "Of the others torch accepts, 'nearest' cannot run in the reference either -- its decoder "
+                                      "calls F.interpolate(..., mode=sample_mode, align_corners=True), pixel.py:107, which "
+                                      "raises for 'nearest' (and for 'area'); 'linear' / 'trilinear' are not 4-D modes")
         if mode not in ("conv", "fc"):
             raise ValueError("Invalid mode. Use 'conv' or 'fc'.")
         self.mode, self.use_footprint = mode, bool(use_footprint)
@@ -100,6 +99,8 @@ class PixelwiseDecoder(nn.Module):
                 m.channels_last = bool(flag)
 
     def _resample(self, x, addend=None):
+        if self.sample_mode == "bicubic":
+            return ops.upsample_bicubic(x, self.output_size, addend)
         if self.channels_last and x.shape[1] % 4 == 0:
             return grid.upsample_bilinear_cl(x, self.output_size, addend)
         return ops.upsample_bilinear(x, self.output_size, addend)

@@ -75,6 +75,17 @@ class _PointGridLevel(nn.Module):
         activations, never materialised."""
         fa, fb = self.fc_comm[0], self.fc_comm[2]
         r, ch = plane.shape[2], plane.shape[1]
+        if self.sample_mode != "bilinear":
+            # r06: 'bicubic' / 'nearest' (alto.py:95,204; no shipped config, and the reference's own U-Net never passes the
+            # argument on -- only a directly constructed level can carry it): the plain sample -> MLP -> rasterise on the
+            # mode's own kernels (csrc/bicubic.hip); the re-associated forms below rest on the bilinear kernels
+            if isinstance(c_last, deferred.Deferred):
+                raise NotImplementedError("a level with sample_mode != 'bilinear' after a deferred level: construct the whole "
+                                          "U-Net's levels with the same mode (UNet.forward_sorted then defers nothing)")
+            sampled = ops.sample_plane_mode(tile, plane, self.sample_mode)
+            c = mlp.comm_mlp(sampled, fa.weight, fa.bias, fb.weight, fb.bias, c_last, self.fc_c.weight, self.fc_c.bias)
+            raster, c = ops.rasterise_mean_thru(tile, c, plane.shape[2], self.channels_last)
+            return raster, c, plane
         if isinstance(c_last, deferred.Deferred) or (later_res is not None and torch.is_tensor(c_last)
                                                      and deferred.applicable(tile, r, ch)):
             if isinstance(c_last, deferred.Deferred):
@@ -106,12 +117,9 @@ class DownConv(_PointGridLevel):
 
     def __init__(self, in_channels, out_channels, i, pooling, depth, sample_mode="bilinear"):
         super().__init__()
-        if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
-                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
-                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
-                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
-                                      "no kernel here")
+        if sample_mode not in ("bilinear", "bicubic", "nearest"):         # (the three modes F.grid_sample takes for 4-D input)
+            raise ValueError(f"sample_mode={sample_mode!r}: F.grid_sample (alto.py:95,204) accepts 'bilinear', 'nearest', 'bicubic'")
+        self.sample_mode = sample_mode
         self.in_channels, self.out_channels = in_channels, out_channels
         self.pooling, self.downsample, self.depth = pooling, i, depth
         self.conv1 = conv3x3(in_channels, out_channels)
@@ -142,12 +150,9 @@ class UpConv(_PointGridLevel):
     def __init__(self, in_channels, out_channels, i, depth, merge_mode="concat", up_mode="transpose",
                  sample_mode="bilinear"):
         super().__init__()
-        if sample_mode != "bilinear":
-            raise NotImplementedError("only sample_mode='bilinear' is built (the one value every shipped config uses, "
-                                      "tomosar2height.yaml:27).  Of the others torch accepts, 'nearest' cannot run in the "
-                                      "reference either -- its decoder calls F.interpolate(..., mode=sample_mode, "
-                                      "align_corners=True), pixel.py:107, which raises for 'nearest' -- and 'bicubic' has "
-                                      "no kernel here")
+        if sample_mode not in ("bilinear", "bicubic", "nearest"):         # (the three modes F.grid_sample takes for 4-D input)
+            raise ValueError(f"sample_mode={sample_mode!r}: F.grid_sample (alto.py:95,204) accepts 'bilinear', 'nearest', 'bicubic'")
+        self.sample_mode = sample_mode
         self.in_channels, self.out_channels = in_channels, out_channels
         self.merge_mode, self.up_mode, self.depth = merge_mode, up_mode, depth
         self.is_last = i == depth - 2
@@ -236,12 +241,15 @@ class UNet(nn.Module):
                 chs.append(up.out_channels)
         pos = 0
         cache = getattr(self, "compose_cache", None)        # set by the Trainer (deferred.ComposeCache), else plain autograd
+        # (levels with another sample_mode -- swapped in by hand, the constructor cannot set it -- switch the deferred form off)
+        plain = any(getattr(m, "sample_mode", "bilinear") != "bilinear" for m in list(self.down_convs) + list(self.up_convs))
+        later = (lambda: None) if plain else (lambda: (res[pos:], chs[pos:], cache))
         for down in self.down_convs:
-            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, (res[pos:], chs[pos:], cache))
+            plane, raster, prev_conv, c = down(tile, plane, prev_conv, c, later())
             skips.append(raster)
             pos += 1
         for i, up in enumerate(self.up_convs):
-            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, (res[pos:], chs[pos:], cache))
+            plane, prev_conv, c = up(tile, skips[-(i + 2)], plane, prev_conv, c, later())
             pos += 1
         if self.down_convs[0].channels_last:
             return grid.conv1x1(plane, self.conv_final)

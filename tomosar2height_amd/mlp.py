@@ -597,11 +597,42 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
+# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd); T2H_TRUNK_FUSED=0: one launch per block (bit-identical)
+_TRUNK_FUSED = os.environ.get("T2H_TRUNK_FUSED", "1") != "0"
+_TRUNK_FUSED_STRIDE = int(os.environ.get("T2H_TRUNK_FUSED_STRIDE", "0"))
+
+
+def _trunk_forward_one_launch(tile, pts, w_pos, b_pos, blocks, w_c, b_c):
+    """pointnet.py:72-82 as ONE launch: same return value as the per-block form."""
+    import ctypes
+    m, nb, dev = pts.shape[0], len(blocks), pts.device
+    hrs = [_empty(m, 32, pts) for _ in range(nb)]
+    nets = [_empty(m, 32, pts) for _ in range(nb)]
+    pooled = [None] + [_empty(m, 32, pts) for _ in range(nb - 1)]
+    winners = [torch.empty(m, 8, dtype=torch.uint8, device=dev) for _ in range(nb - 1)]
+    c_out = _empty(m, 32, pts)
+    keep = [t.contiguous() for blk in blocks for t in blk] + [w_pos.contiguous(), w_c.contiguous()]
+    arr = ctypes.c_void_p * nb
+    params = (ctypes.c_void_p * (5 * nb))(*[t.data_ptr() for t in keep[:5 * nb]])
+    a_hr, a_out = arr(*[t.data_ptr() for t in hrs]), arr(*[t.data_ptr() for t in nets])
+    a_pool = arr(None, *[t.data_ptr() for t in pooled[1:]])
+    a_win = arr(None, *[t.data_ptr() for t in winners])
+    # algorithmic bytes: points in; hr, out of every block, pooled + winner bits of every pooling, c out (what the backward reads)
+    nbytes = m * (4 * pts.shape[1] + nb * 256 + (nb - 1) * (128 + 8 + 4) + 128)
+    flops = 2 * m * (nb * (2 * 64 * 32 + 32 * 32) + 32 * 32 + 3 * 64)
+    _lib.call("t2h_trunk_fused_fwd", _lib.ptr(pts), pts.shape[1], _lib.ptr(keep[-2]), _lib.ptr(b_pos), params, nb,
+              _lib.ptr(keep[-1]), _lib.ptr(b_c), _lib.ptr(tile.cell), _lib.ptr(tile.off0), m, a_hr, a_out, a_pool, a_win,
+              _lib.ptr(c_out), _TRUNK_FUSED_STRIDE, _lib.stream(), nbytes=nbytes, flops=flops, tag="t2h_trunk_fused_fwd")
+    return c_out, nets, pooled, hrs, winners
+
+
 def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, want_x_full=False):
     """pointnet.py:72-82 as one launch per block.  Returns (c, nets, pooled, hrs, winners[, x_full]): nets[i] = block i's
     [M, 32] output, pooled[i] (i >= 1) = the pooled half of block i's input (= pool_local(nets[i-1])), winners[i-1] its
     arg-max bits, hrs[i] the hidden activations; ``want_x_full`` also materialises every block's [M, 64] input (tests)."""
     m, nb, dev = pts.shape[0], len(blocks), pts.device
+    if not want_x_full and _TRUNK_FUSED and 2 <= nb <= 8 and m > 0:
+        return _trunk_forward_one_launch(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
     nets, pooled, hrs, winners, x_fulls = [], [None], [], [], []
     net_prev, c_out = None, None
     for i, (w0, b0, w1, b1, ws) in enumerate(blocks):

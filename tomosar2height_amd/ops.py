@@ -313,6 +313,94 @@ def upsample_bilinear(x: torch.Tensor, size: int, addend: torch.Tensor = None) -
     return _UpsampleBilinear.apply(x, int(size), addend)
 
 
+# --------------------------------------------------------------------------------------- sample_mode = 'bicubic' (r06)
+def _plane_layout(x: torch.Tensor):
+    """-> (tensor whose memory is dense NCHW or dense NHWC, channels_last flag)."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a [B, C, H, W] plane, got {tuple(x.shape)}")
+    if x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous():
+        return x, 1
+    return x.contiguous(), 0
+
+
+def _empty_like_layout(b, c, h, w, cl, device):
+    if cl:
+        return torch.empty(b, h, w, c, dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+    return torch.empty(b, c, h, w, dtype=torch.float32, device=device)
+
+
+class _UpsampleBicubic(torch.autograd.Function):
+    """``F.interpolate(x, size, mode='bicubic', align_corners=True)`` (+ addend), pixel.py:107,110 with sample_mode='bicubic'."""
+
+    @staticmethod
+    def forward(ctx, x, size: int, addend):
+        x, cl = _plane_layout(_f32(x, "upsample_bicubic"))
+        _lib.require_device(x, what="upsample_bicubic")
+        b, c, h, w = x.shape
+        out = _empty_like_layout(b, c, size, size, cl, x.device)
+        if addend is not None:
+            if tuple(addend.shape) != (b, c, size, size):
+                raise ValueError("upsample_bicubic: addend must already have the output size")
+            addend = addend.contiguous(memory_format=torch.channels_last) if cl else addend.contiguous()
+        _lib.call("t2h_upsample_bicubic_fwd", _lib.ptr(x), _lib.ptr(addend) if addend is not None else None, b, c, h, w, size, size,
+                  cl, out.data_ptr(), _lib.stream(), nbytes=4 * (x.numel() + out.numel() * (2 if addend is not None else 1)))
+        ctx.meta = (b, c, h, w, size, cl)
+        ctx.has_addend = addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, h, w, size, cl = ctx.meta
+        g = g.contiguous(memory_format=torch.channels_last) if cl else g.contiguous()
+        gin = _empty_like_layout(b, c, h, w, cl, g.device)
+        _lib.call("t2h_upsample_bicubic_bwd", _lib.ptr(g), b, c, h, w, size, size, cl, gin.data_ptr(), _lib.stream(),
+                  nbytes=4 * (g.numel() + gin.numel()))
+        return gin, None, (g if ctx.has_addend else None)
+
+
+def upsample_bicubic(x: torch.Tensor, size: int, addend: torch.Tensor = None) -> torch.Tensor:
+    return _UpsampleBicubic.apply(x, int(size), addend)
+
+
+class _SampleBicubic(torch.autograd.Function):
+    """Bicubic / border / align_corners sample of plane [B, C, r, r] at pts [B, N, 2+] (x, y in [0, 1]) -> [B, N, C] point-major.
+    The backward adds into the plane gradient with atomics (an off-default mode: alto.py:95 with sample_mode='bicubic')."""
+
+    @staticmethod
+    def forward(ctx, plane, pts, mode="bicubic"):
+        plane, cl = _plane_layout(_f32(plane, "sample_bicubic"))
+        _lib.require_device(plane, what="sample_bicubic")
+        b, c, r, r2 = plane.shape
+        if r != r2 or pts.shape[0] != b:
+            raise ValueError(f"sample_bicubic: plane {tuple(plane.shape)} / points {tuple(pts.shape)}")
+        pts = _f32(pts, "sample_bicubic points").contiguous()
+        n = pts.shape[1]
+        out = torch.empty(b, n, c, dtype=torch.float32, device=plane.device)
+        _lib.call(f"t2h_sample_{mode}_fwd", _lib.ptr(plane), _lib.ptr(pts), pts.shape[2], b, n, r, c, cl, _lib.ptr(out), _lib.stream(),
+                  nbytes=4 * c * b * n + 4 * pts.numel() + 4 * plane.numel())
+        ctx.save_for_backward(pts)
+        ctx.meta = (b, c, r, n, cl, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (pts,) = ctx.saved_tensors
+        b, c, r, n, cl, mode = ctx.meta
+        gout = gout.contiguous()
+        gplane = _empty_like_layout(b, c, r, r, cl, gout.device)
+        _lib.call(f"t2h_sample_{mode}_bwd", _lib.ptr(gout), _lib.ptr(pts), pts.shape[2], b, n, r, c, cl, gplane.data_ptr(), _lib.stream(),
+                  nbytes=4 * c * b * n + 4 * pts.numel() + 4 * gplane.numel())
+        return gplane, None, None
+
+
+def sample_plane_mode(tile: TileIndex, plane: torch.Tensor, mode: str) -> torch.Tensor:
+    """alto.py:90-95 with sample_mode='bicubic' / 'nearest' on the tile's sorted rows -> [rows, C] (regular batches only)."""
+    if tile.pts.shape[0] != tile.B * tile.N:
+        raise NotImplementedError(f"sample_mode={mode!r} is built for regular [B, N, 3] batches only")
+    pts = tile.pts.view(tile.B, tile.N, tile.pts.shape[1])
+    return _SampleBicubic.apply(plane, pts, mode).reshape(-1, plane.shape[1])
+
+
 # --------------------------------------------------------------------------------------- operator-level drop-ins
 def coordinate2index(x: torch.Tensor, reso: int) -> torch.Tensor:
     """utils/coordinate.py:12-28: ``x [B,N,2+] -> int64 [B,1,N]``, bit exact."""
@@ -542,24 +630,28 @@ def grid_sample(input: torch.Tensor, grid: torch.Tensor, mode: str = "bilinear",
     vgrid was produced that way (every reference call), so taps and weights are ATen's bit for bit on such grids; an
     arbitrary grid is evaluated within 2^-25 of its coordinate.  Differentiable w.r.t. ``input`` only (the reference's
     points do not require grad)."""
-    if mode != "bilinear" or padding_mode != "border" or not align_corners:
-        raise NotImplementedError("grid_sample: only mode='bilinear', padding_mode='border', align_corners=True (the "
-                                  "reference's call, alto.py:95) is built")
+    if mode not in ("bilinear", "bicubic", "nearest") or padding_mode != "border" or not align_corners:
+        raise NotImplementedError("grid_sample: mode='bilinear' / 'bicubic' / 'nearest' with padding_mode='border', "
+                                  "align_corners=True (the reference's call, alto.py:95) is built")
     if grid.dim() != 4 or grid.shape[2] != 1 or grid.shape[3] != 2:
         raise NotImplementedError("grid_sample: the grid must be [B, N, 1, 2] (one sampling location per point)")
     if grid.requires_grad:
         raise NotImplementedError("grid_sample: no gradient w.r.t. the grid is built (the reference's points are data)")
     xy = ((grid[:, :, 0, :].double() + 1.0) * 0.5).float()
+    if mode != "bilinear":
+        return _SampleBicubic.apply(input, xy, mode).permute(0, 2, 1).unsqueeze(-1)
     return _GridSamplePoints.apply(input, xy).unsqueeze(-1)
 
 
 def interpolate(input: torch.Tensor, size=None, scale_factor=None, mode: str = "bilinear",
                 align_corners: bool = True) -> torch.Tensor:
-    """``F.interpolate(x, size=S, mode='bilinear', align_corners=True)`` with the reference's signature (pixel.py:107)."""
-    if mode != "bilinear" or not align_corners or scale_factor is not None or size is None:
-        raise NotImplementedError("interpolate: only size=S, mode='bilinear', align_corners=True (pixel.py:107) is built")
+    """``F.interpolate(x, size=S, mode='bilinear' | 'bicubic', align_corners=True)`` with the reference's signature (pixel.py:107)."""
+    if mode not in ("bilinear", "bicubic") or not align_corners or scale_factor is not None or size is None:
+        raise NotImplementedError("interpolate: only size=S, mode='bilinear' / 'bicubic', align_corners=True (pixel.py:107) is built")
     if isinstance(size, (tuple, list)):
         if len(size) != 2 or size[0] != size[1]:
             raise NotImplementedError("interpolate: square outputs only")
         size = size[0]
+    if mode == "bicubic":
+        return upsample_bicubic(input, int(size))
     return upsample_bilinear(input, int(size))

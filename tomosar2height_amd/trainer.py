@@ -119,6 +119,7 @@ class Trainer:
         # is held.  T2H_COALESCE_TILES=1: every tile issued by its own call (the strict B = 1 step).
         self.coalesce_tiles = max(1, int(os.environ.get("T2H_COALESCE_TILES", "4")))
         self._coalesced = []            # tiles accepted by train_step, not yet issued
+        self._coalesced_version = None  # the weights' version counter when the first of them was accepted
 
         # The composed weight maps of the deferred ALTO levels depend on the weights only: computed once per optimizer step,
         # their gradient accumulated over the step's tiles and back-propagated once (deferred.ComposeCache).  Parameter
@@ -328,6 +329,8 @@ class Trainer:
         if (self.coalesce_tiles > 1 and self.bucket is not None and self._graph is None and self._pipe_graphs is None
                 and isinstance(data, dict) and self._coalescible(data)):
             # accepted, issued later: with the (k - 1) tiles before or after it, at the optimizer boundary, or by a flush
+            if not self._coalesced:
+                self._coalesced_version = self._weights_version()
             self._coalesced.append(data)
             due = self.accumulated_steps + len(self._coalesced) >= self.local_every
             if len(self._coalesced) < self.coalesce_tiles and not due:
@@ -350,6 +353,12 @@ class Trainer:
         tiles, self._coalesced = self._coalesced, []
         if not tiles:
             return False
+        if self._coalesced_version != self._weights_version():
+            # in the tile-by-tile loop these tiles' forwards would have run on the weights of their train_step call
+            self._reset_accumulators()
+            raise RuntimeError("the weights changed (an optimizer step outside the Trainer?) while tiles accepted by train_step were "
+                               "still unflushed (coalescing): call Trainer.flush_gradients() before stepping an optimizer yourself "
+                               "-- the accumulated gradients of this window have been dropped")
         return self._train_step_now(tiles if len(tiles) > 1 else tiles[0])
 
     def _train_step_now(self, data) -> bool:
