@@ -44,13 +44,20 @@ def timed(fn, reps=20):
     return 1e3 * a.elapsed_time(b) / reps
 
 
-def run(fused, stride=0):
-    mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE = fused, stride
-    return lambda: mlp._trunk_forward_fused(tile, tile.pts, ps[0], ps[1], blocks, ps[-2], ps[-1])
+def run(fused, stride=0, greedy=False):
+    def go():
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = fused, stride, greedy
+        return mlp._trunk_forward_fused(tile, tile.pts, ps[0], ps[1], blocks, ps[-2], ps[-1])
+    return go
 
 
 print(f"{nb_tiles} tile(s), {m} rows; library {os.environ.get('T2H_LIBRARY', 'shipped')}")
 print(f"  five per-block launches                      {timed(run(False)):8.1f} us")
+units = tile.trunk_units().cpu()
+used = units[units[:, 1] > units[:, 0]]
+rows_per = (used[:, 1] - used[:, 0]).float()
+print(f"  greedy units: {len(used)} of {len(units)} slots, mean {rows_per.mean():.1f} rows, {int((rows_per > 128).sum())} longer than a tile")
+print(f"  one launch, greedy units (default)             {timed(run(True, 0, True)):8.1f} us")
 for stride in (112, 96, 128):
     print(f"  one launch, stride {stride:3d}                        {timed(run(True, stride)):8.1f} us")
 if "ablate" in os.environ.get("T2H_LIBRARY", ""):
@@ -58,4 +65,4 @@ if "ablate" in os.environ.get("T2H_LIBRARY", ""):
              3: "no pooling, no stores", 7: "no pooling, no stores, weights once", 15: "nothing but the skeleton",
              12: "weights once, no MFMAs", 6: "no stores, weights once"}
     for abl, what in names.items():
-        print(f"  one launch, {what:38s} {timed(run(True, 112 | (abl << 8))):8.1f} us")
+        print(f"  one launch, greedy, {what:30s} {timed(run(True, (abl << 8), True)):8.1f} us")

@@ -396,6 +396,38 @@ def options_fixture():
     _module_fixture(net, {"x": torch.randn(2, 4, 16, 16, generator=g)}, "unet_add", arrs, 28)
     save("reference_options", **arrs)
 
+    # sample_mode = 'bicubic' / 'nearest' (alto.py:51,95; pixel.py:75,107,110): the reference's own sampling method of a level and
+    # its decoder with the mode set.  Points include the plane's corners, edges and exact pixel centres.
+    from tomosar2height.encoder.alto import DownConv
+    arrs = {}
+    pts = torch.rand(2, 300, 3, generator=g)
+    pts[0, :6, :2] = torch.tensor([[0., 0.], [1., 1.], [1., 0.], [0.5, 0.5], [1 / 15, 14 / 15], [0.999999, 1e-7]])
+    for mode in ("bicubic", "nearest"):
+        lvl = DownConv(8, 8, 0, False, depth=3, sample_mode=mode)
+        c = torch.randn(2, 8, 16, 16, generator=g, requires_grad=True)
+        out = lvl.sample_plane_feature(pts, c)                       # [B, C, N]
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        arrs.update({f"{mode}.pts": pts, f"{mode}.plane": c, f"{mode}.out": out, f"{mode}.gout": gout, f"{mode}.gplane": c.grad})
+    for size in (40, 32):                                            # 16 -> 40 (scale 15/39) and 16 -> 32 (15/31), with an image plane
+        dec = det_init_(PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=size, mode="conv", sample_mode="bicubic"), seed=33)
+        xy = torch.randn(1, 32, 16, 16, generator=g, requires_grad=True)
+        img = torch.randn(1, 32, size, size, generator=g)
+        x, _ = dec({"xy": xy, "image": img})
+        gx = torch.randn(x.shape, generator=g)
+        x.backward(gx)
+        arrs.update({f"dec{size}.xy": xy, f"dec{size}.image": img, f"dec{size}.x": x, f"dec{size}.gx": gx, f"dec{size}.gxy": xy.grad})
+        if size == 40:                                               # (same seed: the two decoders share their weights)
+            for k, v in dec.state_dict().items():
+                arrs[f"dec.w.{k}"] = v
+        # the resampling alone (what ops.interpolate replaces), with its adjoint
+        xi = torch.randn(2, 5, 16, 16, generator=g, requires_grad=True)
+        yi = torch.nn.functional.interpolate(xi, size=size, mode="bicubic", align_corners=True)
+        gi = torch.randn(yi.shape, generator=g)
+        yi.backward(gi)
+        arrs.update({f"interp{size}.x": xi, f"interp{size}.y": yi, f"interp{size}.gy": gi, f"interp{size}.gx": xi.grad})
+    save("sample_modes", **arrs)
+
 
 def blend_weight_fixture():
     """(10) DSMGenerator._linear_blend_patch_weight (generator.py:85-113).  generator.py cannot be imported as a

@@ -148,7 +148,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_sample_bicubic_bwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
         "t2h_sample_nearest_fwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
         "t2h_sample_nearest_bwd": (n, n, 3, 1, 10, 16, 32, 0, n, n),
-        "t2h_trunk_fused_fwd": (n, 3, n, n, n, 5, n, n, n, n, 100, n, n, n, n, n, 0, n),
+        "t2h_trunk_fused_fwd": (n, 3, n, n, n, 5, n, n, n, n, 100, n, n, n, n, n, 0, n, n),
+        "t2h_trunk_units_build": (n, n, 100, n, n),
         "t2h_head1x1_fwd": (n, n, 4, n, n, 100, n, n),
         "t2h_head1x1_bwd": (n, n, n, 4, n, n, 100, 0, n, n, n, 0, n),
         "t2h_relu_mask": (n, n, n, 128, n),
@@ -193,7 +194,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }
-    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems", "t2h_conv3x3_bx3_supported", "t2h_gemm_bx3_supported", "t2h_upconv2x2_bx3_supported",
+    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems", "t2h_trunk_units_count", "t2h_conv3x3_bx3_supported", "t2h_gemm_bx3_supported", "t2h_upconv2x2_bx3_supported",
                                                                                     "t2h_reduce_capture_begin", "t2h_reduce_capture_pending", "t2h_reduce_capture_end")]
     assert sorted(cases) == sorted(launching), set(launching) ^ set(cases)
     for name, args in cases.items():

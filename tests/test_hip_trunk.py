@@ -87,13 +87,13 @@ def test_fused_forward_vs_unfused_and_pool_exact(name):
 
 
 @pytest.mark.parametrize("name", ["ragged", "tiny", "single", "one_cell", "ties", "big", "benchmark", "dense_cells", "batch"])
-@pytest.mark.parametrize("stride", [0, 96, 128, 40])
+@pytest.mark.parametrize("stride", [-1, 0, 96, 128, 40])
 def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride):
     """r06: t2h_trunk_fused_fwd (fc_pos -> 5 blocks with their 4 poolings -> fc_c in ONE launch, whole cells per workgroup,
     activations in LDS) against the five t2h_trunk_block_fwd launches: every tensor the backward reads -- hr and out of every
     block, the pooled halves, the winner bits -- and c, bit for bit.  Clouds: ragged sizes, fewer rows than a tile, one row, ONE
     CELL holding 700 rows and a tile of ~80 points per cell (work units longer than a tile: the block-by-block path inside the
-    launch), exact ties, the benchmark tile, a ragged batch of three tiles; unit strides 112 (default), 96, 128 and 40."""
+    launch), exact ties, the benchmark tile, a ragged batch of three tiles; units packed greedily (default) or by strides 96, 128, 40."""
     from tomosar2height_amd import mlp
     from tomosar2height_amd.synthetic import berlin_tile
     from tomosar2height_amd.tile import TileIndex
@@ -111,14 +111,22 @@ def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride
     params = [p.detach() for p in _params(enc)]
     nb = len(enc.blocks)
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
-    old = (mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE)
+    old = (mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS)
     try:
-        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE = True, stride
+        # stride -1: the default -- units packed greedily once per tile index (t2h_trunk_units_build); >= 0: fixed windows of
+        # `stride` rows (0: 96) snapped to cell boundaries and looked up inside the launch
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = True, max(stride, 0), stride < 0
+        if stride < 0:
+            units = tile.trunk_units().cpu()
+            used = units[units[:, 1] > units[:, 0]]
+            assert int(used[0, 0]) == 0 and int(used[-1, 1]) == tile.pts.shape[0] and torch.equal(used[1:, 0], used[:-1, 1])
+            starts = set(tile.off0.cpu().tolist())
+            assert all(int(v) in starts for v in used[:, 0]), "a unit starts inside a cell"
         one = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
         mlp._TRUNK_FUSED = False
         per = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
     finally:
-        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE = old
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = old
     names = ("c", "nets", "pooled", "hrs", "winners")
     assert torch.equal(one[0], per[0]), "c"
     for what, a, b in zip(names[1:], one[1:], per[1:]):

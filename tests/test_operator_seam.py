@@ -171,8 +171,10 @@ def test_grid_sample_with_the_reference_signature():
         assert torch.equal(direct, got.detach().squeeze(-1))
         got.backward(gout.to(_dev()))
         assert _rel(p.grad.cpu().numpy(), p_ref.grad.numpy()) <= 2e-6
+    with pytest.raises(NotImplementedError):                  # (the reference's call is border / align_corners=True: alto.py:95)
+        ops.grid_sample(p, vgrid.to(_dev()), padding_mode="zeros")
     with pytest.raises(NotImplementedError):
-        ops.grid_sample(p, vgrid.to(_dev()), mode="nearest")
+        ops.grid_sample(p, vgrid.to(_dev()), align_corners=False)
 
 
 # ------------------------------------------------------------------------------------------------ reference-shaped graphs
@@ -270,3 +272,84 @@ def test_reference_shaped_full_model_on_hip_operators_at_the_benchmarked_size():
     tile = berlin_tile(seed=1000, n_points=DEFAULT_POINTS)
     assert tile["inputs"].shape == (1, 131072, 3)
     _compare_with_cpu_oracle(berlin_config(), tile["inputs"], seed=31, what="berlin N=131072")
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_sample_modes_bicubic_and_nearest_against_the_reference_fixture(channels_last):
+    """r06 (VERDICT r05 missing 2): ``sample_mode='bicubic'`` -- and 'nearest', the third mode F.grid_sample takes -- at the
+    reference's two call sites, against outputs of the reference's own methods (tests/golden/sample_modes.npz, generated through
+    DownConv.sample_plane_feature and PixelwiseDecoder): ``ops.grid_sample(mode=...)`` with torch's signature (alto.py:95,204),
+    forward and plane gradient; ``ops.interpolate(mode='bicubic', align_corners=True)`` (pixel.py:107,110) forward and adjoint;
+    the PixelwiseDecoder mirror with the mode set, heights and input gradient.  NCHW and channels_last planes."""
+    from tomosar2height_amd import ops
+    from tomosar2height_amd.decoder.pixel import PixelwiseDecoder
+    g = load_golden("sample_modes")
+    dev = torch.device("cuda:0")
+
+    def lay(t):
+        t = t.to(dev)
+        return t.contiguous(memory_format=torch.channels_last) if channels_last else t
+    for mode in ("bicubic", "nearest"):
+        c = lay(torch.from_numpy(g[f"{mode}.plane"])).requires_grad_(True)
+        vgrid = (2.0 * torch.from_numpy(g[f"{mode}.pts"])[..., :2][:, :, None] - 1.0).to(dev)
+        out = ops.grid_sample(c, vgrid, mode=mode, padding_mode="border", align_corners=True)
+        assert tuple(out.shape) == tuple(g[f"{mode}.out"].shape) + (1,)
+        np.testing.assert_allclose(out[..., 0].detach().cpu().numpy(), g[f"{mode}.out"], rtol=1e-5, atol=2e-6)
+        out[..., 0].backward(torch.from_numpy(g[f"{mode}.gout"]).to(dev))
+        np.testing.assert_allclose(c.grad.cpu().numpy(), g[f"{mode}.gplane"], rtol=1e-4, atol=1e-5)
+    for size in (40, 32):
+        xi = lay(torch.from_numpy(g[f"interp{size}.x"])).requires_grad_(True)
+        yi = ops.interpolate(xi, size=size, mode="bicubic", align_corners=True)
+        np.testing.assert_allclose(yi.detach().cpu().numpy(), g[f"interp{size}.y"], rtol=1e-5, atol=2e-6)
+        yi.backward(lay(torch.from_numpy(g[f"interp{size}.gy"])))
+        np.testing.assert_allclose(xi.grad.cpu().numpy(), g[f"interp{size}.gx"], rtol=1e-4, atol=1e-5)
+        import tomosar2height_amd as t2h
+        before = sum(t2h.fallback_counts().values())
+        dec = PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=size, mode="conv", sample_mode="bicubic")
+        dec.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dec.w.")}, strict=True)
+        dec.to(dev)
+        dec.set_channels_last(channels_last)
+        xy = lay(torch.from_numpy(g[f"dec{size}.xy"])).requires_grad_(True)
+        if not channels_last or size == 40:
+            t2h.allow_library_fallback(True).set()          # (the NCHW grid side is MIOpen's by definition; so are 40-pixel rows)
+        x, _ = dec({"xy": xy, "image": lay(torch.from_numpy(g[f"dec{size}.image"]))})
+        want = g[f"dec{size}.x"]
+        assert np.abs(x.detach().cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
+        x.backward(torch.from_numpy(g[f"dec{size}.gx"]).to(dev))
+        got, wg = xy.grad.cpu().double(), torch.from_numpy(g[f"dec{size}.gxy"]).double()
+        assert ((got - wg).norm() / wg.norm()).item() <= 3e-3          # (ReLU mask flips of the three conv layers: as the bilinear decoder test)
+        if channels_last and size == 32:
+            assert sum(t2h.fallback_counts().values()) == before, "a vendor-library fallback ran"
+
+
+def test_alto_level_with_sample_mode_bicubic_runs_the_plain_exchange():
+    """A DownConv constructed with sample_mode='bicubic' (alto.py:51; the reference's U-Net cannot pass it, a hand-built level
+    can): sample -> fc_comm + fc_c -> scatter_mean on the mode's kernels, against the same level evaluated with torch's ops."""
+    from tomosar2height_amd.encoder.alto import DownConv
+    from tomosar2height_amd.tile import TileIndex
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    lvl = DownConv(32, 32, 0, False, depth=3, sample_mode="bicubic").to(dev)
+    lvl.channels_last = True
+    cloud = torch.rand(2, 3000, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+    plane = torch.randn(2, 32, 32, 32, generator=torch.Generator().manual_seed(7)).to(dev).contiguous(memory_format=torch.channels_last)
+    c_last = torch.randn(2, 3000, 32, generator=torch.Generator().manual_seed(8)).to(dev)
+    tile = TileIndex(cloud, 32)
+    pooled, raster, g, c = lvl(tile, plane, None, tile.sort_rows(c_last), None)
+    # the same level with torch's operators on the original point order
+    x = torch.relu(lvl.conv2(torch.relu(lvl.conv1(plane))))
+    vgrid = 2.0 * cloud[..., :2][:, :, None] - 1.0
+    s = torch.nn.functional.grid_sample(x, vgrid, padding_mode="border", align_corners=True, mode="bicubic").squeeze(-1).transpose(1, 2)
+    cc = lvl.fc_comm(s) + lvl.fc_c(c_last)
+    idx = ops_index(cloud, 32)
+    want = torch.zeros(2, 32, 32 * 32, device=dev)
+    cnt = torch.zeros(2, 1, 32 * 32, device=dev)
+    want.scatter_add_(2, idx.expand(-1, 32, -1), cc.transpose(1, 2))
+    cnt.scatter_add_(2, idx, torch.ones(2, 1, 3000, device=dev))
+    want = (want / cnt.clamp_min(1)).reshape(2, 32, 32, 32)
+    assert ((raster - want).abs().max() / want.abs().max()).item() <= 2e-5
+
+
+def ops_index(cloud, reso):
+    from tomosar2height_amd import ops
+    return ops.coordinate2index(cloud, reso)

@@ -290,3 +290,24 @@ def test_reference_options():
         feature_dim=8, dim=3, hidden_dim=8, scatter_type="max", unet_type="alto",
         unet_kwargs=dict(depth=3, merge_mode="add", start_filts=8), plane_resolution=16), ["cloud"])
     _check_module_fixture(g, "unet_add", torch_ref.PlainUNet(8, in_channels=4, depth=3, start_filts=8, merge_mode="add"), ["x"])
+
+
+def test_sample_modes_fixture_is_what_torch_computes():
+    """r06: sample_modes.npz (generated through the reference's DownConv.sample_plane_feature and PixelwiseDecoder with
+    sample_mode='bicubic' / 'nearest') against the same torch calls made here, and the oracle's decoder with the mode set."""
+    g = load_golden("sample_modes")
+    for mode in ("bicubic", "nearest"):
+        c = torch.from_numpy(g[f"{mode}.plane"]).requires_grad_(True)
+        vgrid = 2.0 * torch.from_numpy(g[f"{mode}.pts"])[..., :2][:, :, None] - 1.0
+        out = torch.nn.functional.grid_sample(c, vgrid, padding_mode="border", align_corners=True, mode=mode).squeeze(-1)
+        np.testing.assert_allclose(out.detach().numpy(), g[f"{mode}.out"], rtol=1e-6, atol=1e-6)
+        out.backward(torch.from_numpy(g[f"{mode}.gout"]))
+        np.testing.assert_allclose(c.grad.numpy(), g[f"{mode}.gplane"], rtol=1e-5, atol=1e-5)
+    for size in (40, 32):
+        dec = torch_ref.PixelwiseDecoder(hidden_dim=32, out_dim=1, output_size=size, mode="conv", sample_mode="bicubic")
+        dec.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("dec.w.")}, strict=True)
+        xy = torch.from_numpy(g[f"dec{size}.xy"]).requires_grad_(True)
+        x, _ = dec({"xy": xy, "image": torch.from_numpy(g[f"dec{size}.image"])})
+        np.testing.assert_allclose(x.detach().numpy(), g[f"dec{size}.x"], rtol=1e-5, atol=1e-5)
+        x.backward(torch.from_numpy(g[f"dec{size}.gx"]))
+        np.testing.assert_allclose(xy.grad.numpy(), g[f"dec{size}.gxy"], rtol=1e-4, atol=1e-5)

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -144,7 +144,9 @@ SIGNATURES = {
     "t2h_sample_bicubic_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
     "t2h_sample_nearest_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
     "t2h_sample_nearest_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
-    "t2h_trunk_fused_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "t2h_trunk_units_count": (_i, [_i64]),
+    "t2h_trunk_units_build": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "t2h_trunk_fused_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "t2h_trunk_block_bwd_workspace_bytes": (_sz, [_i64]),
     "t2h_trunk_block_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
                                  _vp, _vp, _i64, _vp, _vp, _sz, _vp]),

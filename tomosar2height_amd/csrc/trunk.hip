@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void trunk_block_fwd_kernel(TrunkFwdArgs a)
 //
 // All poolings of the trunk use the SAME finest-level cells (pointnet.py:70, 76-79), and after the tile sort a cell is a run of
 // consecutive rows.  A workgroup that owns WHOLE cells therefore needs nothing from any other workgroup between the blocks: work
-// unit k = the cells whose first row lies in [k S, (k + 1) S) (S = `stride` rows, 112 by default), found from `cell` / `off0`
+// unit k = the cells whose first row lies in [k S, (k + 1) S) (S = `stride` rows, 96 by default), found from `cell` / `off0`
 // with two dependent loads per boundary.  A unit of at most TR = 128 rows (every unit unless a cell with more than TR - S + 1
 // rows starts near its end) takes the FAST path: X = fc_pos(points) is formed in LDS, every block's output goes back into the
 // left half of the X tile from the MFMA registers, the segmented max runs on the tile in LDS (head masks of the unit's cells by
@@ -500,6 +500,7 @@ struct TrunkFusedArgs {
     const float *w0[kMaxTrunkBlocks], *b0[kMaxTrunkBlocks], *w1[kMaxTrunkBlocks], *b1[kMaxTrunkBlocks], *ws[kMaxTrunkBlocks];
     const float *wc, *bc;
     const int32_t *cell, *off0;
+    const int2 *bounds;           // [n_units] (first row, end row) of every unit (t2h_trunk_units_build), or NULL: fixed-stride units looked up per unit
     int M, nb, stride, n_units;
     int ablate;          // lab builds (-DT2H_TRUNK_ABLATE) only: bit 0 no pooling, 1 no global stores, 2 weights staged once, 3 no MFMAs
     float *hr[kMaxTrunkBlocks], *out[kMaxTrunkBlocks], *pooled[kMaxTrunkBlocks];
@@ -625,9 +626,10 @@ __device__ inline void fused_fc_pos(const TrunkFusedArgs &a, float *Xs, const fl
 }
 
 // segmented max of the unit's rows (left half of the X tile, whole cells only) -> right half, winner bits and pooled half to
-// global.  m0 / m1: head masks of the unit's cells (bit i: tile row i starts a cell; rows past the unit are heads of their own)
-__device__ inline void fused_pool_local(float *Xs, unsigned long long m0, unsigned long long m1, int s, int rows, uint8_t *winner,
-                                        float *pooled, int tid, int abl = 0) {
+// global.  span[p]: first and one-past-last tile row of the cell of this thread's row p (cs | ce << 8), found once per unit from
+// the head masks (the four poolings of a unit share them)
+__device__ inline void fused_pool_local(float *Xs, const int (&span)[TR / NG], int s, int rows, uint8_t *winner, float *pooled,
+                                        int tid, int abl = 0) {
     const int lane = tid & (G - 1), grp = tid >> 3;
 #pragma unroll
     for (int p = 0; p < TR / NG; ++p) {
@@ -636,7 +638,7 @@ __device__ inline void fused_pool_local(float *Xs, unsigned long long m0, unsign
             *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
-        const int cs = mask_prev_head(m0, m1, me), ce = mask_next_head(m0, m1, me);
+        const int cs = span[p] & 255, ce = span[p] >> 8;
         Best b; best_init(b);
         int n = cs;
         for (; n + 3 < ce; n += 4) {
@@ -665,39 +667,86 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     __shared__ float bsm[96];
     __shared__ float wps[256];
     __shared__ int unit[2];
+    __shared__ int cells[TR];
     __shared__ unsigned long long heads[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 192) wps[tid] = a.wpos[tid];
     if (tid < 64) wps[192 + tid] = a.bpos[tid];
-    for (int k = blockIdx.x; k < a.n_units; k += gridDim.x) {
-        __syncthreads();                                     // the previous unit is done with every LDS buffer (and wps is staged)
 #ifdef T2H_TRUNK_ABLATE
-        const int abl = a.ablate;
-        if (tid == 0) {
-            if (abl & 16) { unit[0] = min(k * a.stride, a.M); unit[1] = min((k + 1) * a.stride, a.M); }
-            else { unit[0] = unit_start(a, k); unit[1] = unit_start(a, k + 1); }
-        }
+    const int abl = a.ablate;
 #else
-        constexpr int abl = 0;
-        if (tid == 0) { unit[0] = unit_start(a, k); unit[1] = unit_start(a, k + 1); }
+    constexpr int abl = 0;
 #endif
-        stage_block_weights(a, 0, W0s, Wss, W1s, Wcs, bsm, tid);
-        __syncthreads();
-        const int s = unit[0], e = unit[1], rows = e - s;
-        if (rows <= 0) continue;                             // (uniform: the cell that starts before k S covers the whole window)
-        if (rows <= TR) {
-            // ---------------------------------------------------------------- fast path: the unit lives in LDS for all blocks
-            int *cells = reinterpret_cast<int *>(Hsm);       // (Hsm is free until the first GEMM)
-            if (tid < TR) cells[tid] = tid < rows ? a.cell[s + tid] : -1 - tid;
-            fused_fc_pos(a, Xs, wps, s, e, tid);
+    // Latencies taken off the unit's critical path: the bounds of the NEXT unit of this workgroup are requested one unit ahead
+    // (a.bounds: one load each; without the array, the two-hop lookup by thread 0), its points and cell ids while this unit's
+    // blocks run, and block 0's weights for the next unit right after this unit's last GEMM.
+    int k = blockIdx.x;
+    int s = 0, e = 0;
+    if (k < a.n_units) {
+        if (a.bounds) { const int2 u = a.bounds[k]; s = u.x; e = u.y; }
+        else {
+            if (tid == 0) { unit[0] = (abl & 16) ? min(k * a.stride, a.M) : unit_start(a, k); unit[1] = (abl & 16) ? min((k + 1) * a.stride, a.M) : unit_start(a, k + 1); }
             __syncthreads();
+            s = unit[0]; e = unit[1];
+        }
+    }
+    stage_block_weights(a, 0, W0s, Wss, W1s, Wcs, bsm, tid);
+    // this thread's share of a unit's inputs: row tid >> 1 of the points (both threads of a pair read the same point), cell id of row tid
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    int cid = 0;
+    auto request = [&](int us, int ue) {
+        const int row = tid >> 1;
+        p0 = p1 = p2 = 0.f;
+        if (ue - us <= TR) {                                 // (a long unit reads its points chunk by chunk itself)
+            if (us + row < ue) { const float *p = a.pts + (size_t)(us + row) * a.dim; p0 = p[0]; p1 = p[1]; p2 = p[2]; }
+            cid = (tid < TR && us + tid < ue) ? a.cell[us + tid] : -1 - tid;
+        }
+    };
+    request(s, e);
+    for (; k < a.n_units; k += gridDim.x) {
+        const int kn = k + gridDim.x;
+        int sn = a.M, en = a.M;
+        if (kn < a.n_units && a.bounds) { const int2 u = a.bounds[kn]; sn = u.x; en = u.y; }  // (in flight during this unit)
+        const int rows = e - s;
+        if (rows > 0 && rows <= TR) {
+            // ---------------------------------------------------------------- fast path: the unit lives in LDS for all blocks
+            {
+                const int row = tid >> 1, c0 = (tid & 1) * 32;
+#pragma unroll
+                for (int c = 0; c < 32; c += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = c0 + c + j;
+                        float acc = wps[192 + n];
+                        acc = fmaf(p0, wps[n * 3 + 0], acc);
+                        acc = fmaf(p1, wps[n * 3 + 1], acc);
+                        acc = fmaf(p2, wps[n * 3 + 2], acc);
+                        v[j] = row < rows ? acc : 0.f;
+                    }
+                    *reinterpret_cast<float4 *>(Xs + row * XS + c0 + c) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                if (tid < TR) cells[tid] = cid;
+            }
+            __syncthreads();                                 // X, the cell ids, block 0's weights (and wps, the first time)
             if (tid < TR) {
                 const bool head = tid == 0 || cells[tid] != cells[tid - 1];
                 const unsigned long long m = __ballot(head);
                 if ((tid & 63) == 0) heads[tid >> 6] = m;
             }
             __syncthreads();
-            const unsigned long long m0 = heads[0], m1 = heads[1];
+            int span[TR / NG];
+            {
+                const unsigned long long m0 = heads[0], m1 = heads[1];
+#pragma unroll
+                for (int p = 0; p < TR / NG; ++p) {
+                    const int me = p * NG + (tid >> 3);
+                    span[p] = mask_prev_head(m0, m1, me) | (mask_next_head(m0, m1, me) << 8);
+                }
+            }
+            if (!a.bounds && kn < a.n_units) {               // (no bounds array: the next unit's lookup, off the critical path)
+                if (tid == 0) { unit[0] = (abl & 16) ? min(kn * a.stride, a.M) : unit_start(a, kn); unit[1] = (abl & 16) ? min((kn + 1) * a.stride, a.M) : unit_start(a, kn + 1); }
+            }
             for (int b = 0; b < a.nb; ++b) {
                 const bool last = b == a.nb - 1;
                 if (wave * 32 < rows)
@@ -706,14 +755,22 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                     for (int i = lane; i < 32 * 8; i += 64)
                         *reinterpret_cast<float4 *>(Xs + (wave * 32 + (i >> 3)) * XS + (i & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                if (last) break;
                 __syncthreads();                             // every wave's `out` rows are in the tile; the block's weights are consumed
-                if (!(abl & 4)) stage_block_weights(a, b + 1, W0s, Wss, W1s, Wcs, bsm, tid);
-                if (!(abl & 1)) fused_pool_local(Xs, m0, m1, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
+                if (b == 0) {                                // the next unit's inputs, requested under this unit's remaining blocks
+                    if (!a.bounds && kn < a.n_units) { sn = unit[0]; en = unit[1]; }
+                    request(sn, en);
+                }
+                if (!(abl & 4) || last) stage_block_weights(a, last ? 0 : b + 1, W0s, Wss, W1s, Wcs, bsm, tid);
+                if (last) break;
+                if (!(abl & 1)) fused_pool_local(Xs, span, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
                 __syncthreads();
             }
-        } else {
+        } else if (rows > TR) {
             // ---------------------------------------------------------------- slow path: chunks of TR rows, block by block, through HBM
+            __syncthreads();                                 // block 0's weights (and wps)
+            if (!a.bounds && kn < a.n_units) {
+                if (tid == 0) { unit[0] = unit_start(a, kn); unit[1] = unit_start(a, kn + 1); }
+            }
             for (int b = 0; b < a.nb; ++b) {
                 const bool last = b == a.nb - 1;
                 if (b > 0) {
@@ -737,12 +794,57 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                                     *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
                         }
                     }
-                    fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, c0, c1, a.hr[b], a.out[b], a.c_out, last, false, lane, wave);
+                    fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, c0, c1, a.hr[b], a.out[b], a.c_out, last, false, lane, wave, abl);
                     __syncthreads();
                 }
             }
+            if (!a.bounds && kn < a.n_units) { sn = unit[0]; en = unit[1]; }
+            request(sn, en);
+            stage_block_weights(a, 0, W0s, Wss, W1s, Wcs, bsm, tid);
+        } else {
+            // an empty unit (the cell that starts before k S covers the whole window): nothing to do but to move on
+            if (!a.bounds && kn < a.n_units) {
+                __syncthreads();
+                if (tid == 0) { unit[0] = unit_start(a, kn); unit[1] = unit_start(a, kn + 1); }
+                __syncthreads();
+                sn = unit[0]; en = unit[1];
+            }
+            request(sn, en);
         }
+        s = sn; e = en;
     }
+}
+
+// Work units of t2h_trunk_fused_fwd, packed greedily: a unit takes whole cells while they fit TR rows.  The packing is a
+// sequential walk, so the rows are cut into segments of kUnitSeg rows (snapped up to the next cell start) and one thread walks
+// each segment: unit k = (start, end) pairs in slot k of the segment's kUnitSlots slots (unused slots: start == end).  A cell of
+// more than TR rows is a unit of its own (the block-by-block path).  A unit is shorter than TR - (next cell's rows) only at a
+// segment's end, so units average ~TR - half a cell (vs a fixed stride that must leave room for the largest cell).
+constexpr int kUnitSeg = 1024, kUnitSlots = 24;       // (<= 2 units per TR + 1 rows in the worst alternation of 1-row and TR-row cells)
+__device__ inline int snap_up(const int32_t *cell, const int32_t *off0, long long row, int M) {
+    if (row >= M) return M;
+    const int c = cell[row], st = off0[c];
+    return st == (int)row ? (int)row : off0[c + 1];
+}
+__global__ __launch_bounds__(64) void trunk_units_kernel(const int32_t *__restrict__ cell, const int32_t *__restrict__ off0, int M,
+                                                        int n_seg, int2 *__restrict__ units) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_seg) return;
+    int u = j == 0 ? 0 : snap_up(cell, off0, (long long)j * kUnitSeg, M);
+    const int seg_end = snap_up(cell, off0, (long long)(j + 1) * kUnitSeg, M);
+    int2 *slot = units + (size_t)j * kUnitSlots;
+    int n = 0;
+    while (u < seg_end && n < kUnitSlots) {
+        int nxt = seg_end;
+        if (seg_end - u > TR) {
+            const int c = cell[u + TR], st = off0[c];          // the cell that holds row u + TR
+            nxt = st > u ? st : off0[c + 1];                   // (st <= u: the cell at u is longer than TR rows -- a unit of its own)
+        }
+        if (n == kUnitSlots - 1) nxt = seg_end;                // (cannot happen by the bound above; never drop rows)
+        slot[n++] = make_int2(u, nxt);
+        u = nxt;
+    }
+    for (; n < kUnitSlots; ++n) slot[n] = make_int2(seg_end, seg_end);
 }
 
 // =====================================================================================================================
@@ -1228,10 +1330,25 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     return check_launch("trunk_block_fwd");
 }
 
+T2H_API int t2h_trunk_units_count(int64_t M) {
+    return M < 1 ? 0 : (int)((M + kUnitSeg - 1) / kUnitSeg) * kUnitSlots;
+}
+
+T2H_API int t2h_trunk_units_build(const int32_t *cell, const int32_t *off0, int64_t M, int32_t *units, t2h_stream_t stream) {
+    if (!cell || !off0 || !units) return fail(T2H_ERR_ARG, "trunk_units_build: null pointer");
+    if (M < 0 || M >= ((int64_t)1 << 31) - TR) return fail(T2H_ERR_ARG, "trunk_units_build: bad shape");
+    if (((uintptr_t)units & 7) != 0) return fail(T2H_ERR_ARG, "trunk_units_build: units must be 8-byte aligned");
+    if (M == 0) return T2H_OK;
+    const int n_seg = (int)((M + kUnitSeg - 1) / kUnitSeg);
+    hipLaunchKernelGGL(trunk_units_kernel, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, as_stream(stream), cell, off0, (int)M, n_seg,
+                       reinterpret_cast<int2 *>(units));
+    return check_launch("trunk_units_build");
+}
+
 T2H_API int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *const *block_params,
                                 int n_blocks, const float *wc, const float *bc, const int32_t *cell, const int32_t *off0, int64_t M,
                                 float *const *hr, float *const *out, float *const *pooled, uint8_t *const *winner, float *c_out,
-                                int stride, t2h_stream_t stream) {
+                                int stride, const int32_t *units, t2h_stream_t stream) {
     if (!pts || !w_pos || !b_pos || !block_params || !wc || !bc || !cell || !off0 || !hr || !out || !pooled || !winner || !c_out)
         return fail(T2H_ERR_ARG, "trunk_fused_fwd: null pointer");
     if (n_blocks < 2 || n_blocks > kMaxTrunkBlocks) return fail(T2H_ERR_ARG, "trunk_fused_fwd: 2 <= n_blocks <= %d", kMaxTrunkBlocks);
@@ -1240,13 +1357,13 @@ T2H_API int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, c
 #ifdef T2H_TRUNK_ABLATE
     ablate = stride >> 8; stride &= 255;
 #endif
-    if (stride <= 0) stride = 112;
+    if (stride <= 0) stride = 96;
     if (stride > TR) return fail(T2H_ERR_ARG, "trunk_fused_fwd: stride must be <= %d rows", TR);
     if (M == 0) return T2H_OK;
     TrunkFusedArgs a{};
     a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos; a.wc = wc; a.bc = bc; a.cell = cell; a.off0 = off0;
-    a.M = (int)M; a.nb = n_blocks; a.stride = stride; a.c_out = c_out; a.ablate = ablate;
-    a.n_units = (int)((M + stride - 1) / stride);
+    a.M = (int)M; a.nb = n_blocks; a.stride = stride; a.c_out = c_out; a.ablate = ablate; a.bounds = reinterpret_cast<const int2 *>(units);
+    a.n_units = units ? t2h_trunk_units_count(M) : (int)((M + stride - 1) / stride);
     for (int b = 0; b < n_blocks; ++b) {
         a.w0[b] = block_params[5 * b]; a.b0[b] = block_params[5 * b + 1]; a.w1[b] = block_params[5 * b + 2];
         a.b1[b] = block_params[5 * b + 3]; a.ws[b] = block_params[5 * b + 4];

@@ -600,6 +600,7 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
 # r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd); T2H_TRUNK_FUSED=0: one launch per block (bit-identical)
 _TRUNK_FUSED = os.environ.get("T2H_TRUNK_FUSED", "1") != "0"
 _TRUNK_FUSED_STRIDE = int(os.environ.get("T2H_TRUNK_FUSED_STRIDE", "0"))
+_TRUNK_UNIT_BOUNDS = os.environ.get("T2H_TRUNK_UNIT_BOUNDS", "1") != "0"     # greedy units built once per tile index (0: fixed-stride windows looked up in the kernel)
 
 
 def _trunk_forward_one_launch(tile, pts, w_pos, b_pos, blocks, w_c, b_c):
@@ -620,9 +621,11 @@ def _trunk_forward_one_launch(tile, pts, w_pos, b_pos, blocks, w_c, b_c):
     # algorithmic bytes: points in; hr, out of every block, pooled + winner bits of every pooling, c out (what the backward reads)
     nbytes = m * (4 * pts.shape[1] + nb * 256 + (nb - 1) * (128 + 8 + 4) + 128)
     flops = 2 * m * (nb * (2 * 64 * 32 + 32 * 32) + 32 * 32 + 3 * 64)
+    bounds = tile.trunk_units() if _TRUNK_UNIT_BOUNDS else None
     _lib.call("t2h_trunk_fused_fwd", _lib.ptr(pts), pts.shape[1], _lib.ptr(keep[-2]), _lib.ptr(b_pos), params, nb,
               _lib.ptr(keep[-1]), _lib.ptr(b_c), _lib.ptr(tile.cell), _lib.ptr(tile.off0), m, a_hr, a_out, a_pool, a_win,
-              _lib.ptr(c_out), _TRUNK_FUSED_STRIDE, _lib.stream(), nbytes=nbytes, flops=flops, tag="t2h_trunk_fused_fwd")
+              _lib.ptr(c_out), _TRUNK_FUSED_STRIDE, None if bounds is None else _lib.ptr(bounds), _lib.stream(),
+              nbytes=nbytes, flops=flops, tag="t2h_trunk_fused_fwd")
     return c_out, nets, pooled, hrs, winners
 
 

@@ -318,6 +318,8 @@ def _plane_layout(x: torch.Tensor):
     """-> (tensor whose memory is dense NCHW or dense NHWC, channels_last flag)."""
     if x.dim() != 4:
         raise ValueError(f"expected a [B, C, H, W] plane, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError(f"expected a tensor on the MI355X (cuda device), got {x.device}: tomosar2height_amd has no CPU path")
     if x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous():
         return x, 1
     return x.contiguous(), 0
@@ -335,7 +337,6 @@ class _UpsampleBicubic(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, size: int, addend):
         x, cl = _plane_layout(_f32(x, "upsample_bicubic"))
-        _lib.require_device(x, what="upsample_bicubic")
         b, c, h, w = x.shape
         out = _empty_like_layout(b, c, size, size, cl, x.device)
         if addend is not None:
@@ -369,7 +370,6 @@ class _SampleBicubic(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plane, pts, mode="bicubic"):
         plane, cl = _plane_layout(_f32(plane, "sample_bicubic"))
-        _lib.require_device(plane, what="sample_bicubic")
         b, c, r, r2 = plane.shape
         if r != r2 or pts.shape[0] != b:
             raise ValueError(f"sample_bicubic: plane {tuple(plane.shape)} / points {tuple(pts.shape)}")

@@ -125,6 +125,19 @@ class TileIndex:
             hit = self._adjoint[level] = (offsets, entries)
         return hit
 
+    def trunk_units(self):
+        """Work units of the one-launch trunk forward (``t2h_trunk_units_build``): (first row, end row) pairs of whole finest-level
+        cells packed into at most 128 rows.  They depend on the index only: built on first use, kept for the tile's lifetime."""
+        hit = self._adjoint.get("trunk_units")
+        if hit is None:
+            lib = _lib.load()
+            m = int(self.pts.shape[0])
+            n = int(lib.t2h_trunk_units_count(m))
+            hit = torch.empty(n, 2, dtype=torch.int32, device=self.device)
+            _lib.call("t2h_trunk_units_build", _lib.ptr(self.cell), _lib.ptr(self.off0), m, _lib.ptr(hit), _lib.stream(), nbytes=8 * n + 8 * m // 128)
+            self._adjoint["trunk_units"] = hit
+        return hit
+
     def cell_order(self, level: int):
         """Dispatch order of the on-chip walks at ALTO level ``level`` (``t2h_cell_order_build``): the level's cells, then its
         2 x 2 blocks of cells, each by falling row count -- the dense cells' workgroups start first.  Built on first use and kept
