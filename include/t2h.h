@@ -620,13 +620,13 @@ int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, const flo
  * n_blocks t2h_trunk_block_fwd launches.
  *   block_params  HOST array of 5 * n_blocks DEVICE pointers: w0, b0, w1, b1, ws of block 0, then of block 1, ...
  *   hr, out, pooled, winner   HOST arrays of n_blocks device pointers
- *   units         device array of t2h_trunk_units_count(M) (first row, end row) int32 pairs from t2h_trunk_units_build: the work
- *                 units, whole cells packed greedily into at most 128 rows (a cell of more than 128 rows is a unit of its own and
- *                 runs block by block through memory inside the launch).  They depend on the tile index only: build once per
- *                 tile, reuse for every forward.  NULL: fixed windows of `stride` rows (0: 96, at most 128) snapped to cell
+ *   units         device buffer of t2h_trunk_units_words(M) int32 words (8-byte aligned) filled by t2h_trunk_units_build: the work
+ *                 units as a dense list of (first row, end row) pairs + their number -- whole cells packed greedily into at most
+ *                 128 rows (a cell of more than 128 rows is a unit of its own and runs block by block through memory inside the
+ *                 launch).  They depend on the tile index only: build once per tile, reuse for every forward.  NULL: fixed windows of `stride` rows (0: 96, at most 128) snapped to cell
  *                 boundaries, looked up by every workgroup itself; a window's unit of more than 128 rows takes the slow path
  * 2 <= n_blocks <= 8. */
-int t2h_trunk_units_count(int64_t M);
+int64_t t2h_trunk_units_words(int64_t M);
 int t2h_trunk_units_build(const int32_t *cell, const int32_t *off0, int64_t M, int32_t *units, t2h_stream_t stream);
 int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, const float *b_pos, const float *const *block_params,
                         int n_blocks, const float *wc, const float *bc, const int32_t *cell, const int32_t *off0, int64_t M,

@@ -13,9 +13,9 @@ R=$GRAFT_REPO_ROOT
 # the profiler passes time kernels ALONE (side streams and the tile pipeline off), like the per-kernel leg inside bench.py whose durations they must agree
 # with; the bench legs further down run the product's default (weight gradients on side streams)
 export T2H_OVERLAP_WGRAD=0 T2H_OVERLAP_CONV_WGRAD=0 T2H_PIPELINE_TILES=0
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > $OUT/trace_bench.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 36 --warmup 9 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 --strict-b1-steps 0 > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o p --output-format csv -- python3 $R/bench.py --steps 16 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 --strict-b1-steps 0 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o p --output-format csv -- python3 $R/bench.py --steps 16 --warmup 5 --skip-cpu-baseline --profile-steps 0 --sustain-s 0 --exact-split-steps 0 --micro-batch-steps 0 --strict-b1-steps 0 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/probe_fetch -o p --output-format csv -- python3 $R/profiles/pmc_probe.py > /dev/null 2> $OUT/probe_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/probe_write -o p --output-format csv -- python3 $R/profiles/pmc_probe.py > /dev/null 2> $OUT/probe_write.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace_infer -o t --output-format csv -- python3 $R/bench.py --mode infer --batch 4 --hip-graph 1 --steps 12 --warmup 4 > $OUT/infer_bench.json 2> $OUT/trace_infer.err
@@ -23,7 +23,7 @@ cd $R
 unset T2H_OVERLAP_WGRAD T2H_OVERLAP_CONV_WGRAD T2H_PIPELINE_TILES
 python3 profiles/collect_pmc.py --bench $OUT/pmc_fetch $OUT/pmc_write --probe $OUT/probe_fetch $OUT/probe_write --tag $TAG > $OUT/pmc_summary.txt 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
-python3 profiles/summarize_trace.py $(ls $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv 2>/dev/null | head -1) --steps 6 --top 70 --tag $TAG --json profiles/rocprof_kernels.json > $OUT/kernel_trace_steady_state.txt 2>&1
+python3 profiles/summarize_trace.py $(ls $OUT/trace/*kernel_trace.csv $OUT/trace/*/*kernel_trace.csv 2>/dev/null | head -1) --steps 6 --tiles-per-step 4 --top 70 --tag $TAG --json profiles/rocprof_kernels.json > $OUT/kernel_trace_steady_state.txt 2>&1
 cp profiles/rocprof_kernels.json $OUT/rocprof_kernels.json
 python3 profiles/summarize_trace.py $(ls $OUT/trace_infer/*kernel_trace.csv $OUT/trace_infer/*/*kernel_trace.csv 2>/dev/null | head -1) --steps 4 --top 40 > $OUT/infer_kernel_trace_steady_state.txt 2>&1
 cp $(ls $OUT/trace/*kernel_stats.csv $OUT/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/rocprofv3_kernel_stats.csv
@@ -36,8 +36,8 @@ python3 bench.py --steps 20 --warmup 5 --kernel-table $OUT/bench_kernels.json > 
 # secondary lines (same box), each named after the oracle test that checked its configuration (tests/test_full_size_vs_oracle.py,
 # tests/test_hip_ragged.py): micro-batched accumulation window; tiles from the device tile producer; BASELINE configs[2]
 # (cloud+image, bf16 mode) and its fp32 sibling; the other tile sizes of SURVEY 8d; the no-skew control
-python3 bench.py --steps 64 --warmup 8 --train-batch 4 --skip-cpu-baseline --kernel-table $OUT/bench_b4_kernels.json > $OUT/bench_b4.json 2> $OUT/bench_b4.err
-python3 bench.py --steps 64 --warmup 8 --train-batch 8 --skip-cpu-baseline --profile-steps 0 --sustain-s 2 > $OUT/bench_b8.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 5 --coalesce 1 --skip-cpu-baseline --kernel-table $OUT/bench_b1_kernels.json > $OUT/bench_b1.json 2> $OUT/bench_b1.err
+python3 bench.py --steps 64 --warmup 8 --coalesce 8 --skip-cpu-baseline --profile-steps 0 --sustain-s 2 > $OUT/bench_b8.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --from-producer --skip-cpu-baseline --kernel-table $OUT/bench_producer_kernels.json > $OUT/bench_producer.json 2> $OUT/bench_producer.err
 python3 bench.py --steps 20 --warmup 5 --use-image --mlp-precision bf16 --skip-cpu-baseline --profile-steps 0 > $OUT/bench_image_bf16.json 2> $OUT/bench_image_bf16.err
 python3 bench.py --steps 20 --warmup 5 --use-image --skip-cpu-baseline --profile-steps 0 > $OUT/bench_image_fp32.json 2> $OUT/bench_image_fp32.err

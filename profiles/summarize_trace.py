@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--top", type=int, default=45)
     ap.add_argument("--json", default="", help="also write {tag, steps, kernels: {symbol: {avg_us, launches_per_step}}} here")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--tiles-per-step", type=int, default=1,
+                    help="tiles per delimited step (r06: the Trainer coalesces 4 tiles per forward / backward = one tile_keys launch); "
+                         "the ms/step and launches/step columns are per such step, the headline also per tile")
     a = ap.parse_args()
     rows = sorted(csv.DictReader(open(a.trace)), key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "tile_keys_kernel" in r["Kernel_Name"]]
@@ -62,8 +65,9 @@ def main():
         agg[r["Kernel_Name"]][0] += 1
         agg[r["Kernel_Name"]][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     busy = sum(v[1] for v in agg.values()) / 1e3 / a.steps
-    print(f"steady state over the last {a.steps} tile-steps: wall {wall:.2f} ms/step, kernel-busy {busy:.2f} ms/step, "
-          f"{len(sel) / a.steps:.0f} launches/step")
+    tps = max(1, a.tiles_per_step)
+    print(f"steady state over the last {a.steps} steps of {tps} tile(s): wall {wall:.2f} ms/step, kernel-busy {busy:.2f} ms/step, "
+          f"{len(sel) / a.steps:.0f} launches/step  =  {wall / tps:.2f} ms, {busy / tps:.2f} ms kernel-busy, {len(sel) / a.steps / tps:.0f} launches per TILE")
     cat = collections.defaultdict(float)
     for k, (c, t) in agg.items():
         cat[category(k)] += t
@@ -79,7 +83,7 @@ def main():
             e = kernels.setdefault(short_symbol(k), {"us": 0.0, "launches": 0})
             e["us"] += t
             e["launches"] += c
-        out = {"tag": a.tag, "steps": a.steps, "wall_ms_per_step": round(wall, 3), "busy_ms_per_step": round(busy, 3),
+        out = {"tag": a.tag, "steps": a.steps, "tiles_per_step": tps, "wall_ms_per_step": round(wall, 3), "busy_ms_per_step": round(busy, 3),
                "launches_per_step": round(len(sel) / a.steps, 1),
                "kernels": {k: {"avg_us": round(v["us"] / v["launches"], 2), "launches_per_step": round(v["launches"] / a.steps, 2)}
                            for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["us"])}}

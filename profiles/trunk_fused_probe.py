@@ -53,10 +53,9 @@ def run(fused, stride=0, greedy=False):
 
 print(f"{nb_tiles} tile(s), {m} rows; library {os.environ.get('T2H_LIBRARY', 'shipped')}")
 print(f"  five per-block launches                      {timed(run(False)):8.1f} us")
-units = tile.trunk_units().cpu()
-used = units[units[:, 1] > units[:, 0]]
+used = tile.trunk_unit_list().cpu()
 rows_per = (used[:, 1] - used[:, 0]).float()
-print(f"  greedy units: {len(used)} of {len(units)} slots, mean {rows_per.mean():.1f} rows, {int((rows_per > 128).sum())} longer than a tile")
+print(f"  greedy units: {len(used)}, mean {rows_per.mean():.1f} rows, {int((rows_per > 128).sum())} longer than a tile")
 print(f"  one launch, greedy units (default)             {timed(run(True, 0, True)):8.1f} us")
 for stride in (112, 96, 128):
     print(f"  one launch, stride {stride:3d}                        {timed(run(True, stride)):8.1f} us")

@@ -117,8 +117,8 @@ def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride
         # `stride` rows (0: 96) snapped to cell boundaries and looked up inside the launch
         mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = True, max(stride, 0), stride < 0
         if stride < 0:
-            units = tile.trunk_units().cpu()
-            used = units[units[:, 1] > units[:, 0]]
+            used = tile.trunk_unit_list().cpu()
+            assert bool((used[:, 1] > used[:, 0]).all())
             assert int(used[0, 0]) == 0 and int(used[-1, 1]) == tile.pts.shape[0] and torch.equal(used[1:, 0], used[:-1, 1])
             starts = set(tile.off0.cpu().tolist())
             assert all(int(v) in starts for v in used[:, 0]), "a unit starts inside a cell"

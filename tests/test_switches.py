@@ -45,6 +45,12 @@ GROUPS = {
     "gemm_plain": {"T2H_GEMM_DMA": "0", "T2H_SKINNY": "0", "T2H_SMALLM_BK": "16", "T2H_KWAVES_MIN_K": "100000"},
     "gemm_kwaves": {"T2H_KWAVES_MIN_K": "64", "T2H_KWAVES_MAX_TILES": "100000", "T2H_KWAVES_WGRAD_MAX_ROWS": "100000"},
     "trunk_unfused": {"T2H_FUSED_TRUNK": "0"},
+    # r06: the whole trunk forward in one launch (greedy work units per tile index; fixed-stride windows looked up in the launch),
+    # coalescing off / eight tiles, micro-batches outside the tile pipeline
+    "trunk_one_launch": {"T2H_TRUNK_FUSED": "1"},
+    "trunk_one_launch_strided": {"T2H_TRUNK_FUSED": "1", "T2H_TRUNK_UNIT_BOUNDS": "0", "T2H_TRUNK_FUSED_STRIDE": "112"},
+    "trainer_tile_by_tile": {"T2H_COALESCE_TILES": "1"},
+    "trainer_coalesce_two_unpipelined": {"T2H_COALESCE_TILES": "2", "T2H_PIPELINE_MICRO_BATCHES": "0"},
     "trunk_loader0": {"T2H_TRUNK_LOADER": "0"},
     "point_first": {"T2H_GRID_FIRST_MIN_RATIO": "1000000"},
     "no_deferred": {"T2H_DEFER_MIN_CHANNELS": "0", "T2H_SAMPLE_ADJOINT_MAX_ROWS": "0"},

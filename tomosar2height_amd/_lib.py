@@ -144,7 +144,7 @@ SIGNATURES = {
     "t2h_sample_bicubic_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
     "t2h_sample_nearest_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
     "t2h_sample_nearest_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _i, _vp, _vp]),
-    "t2h_trunk_units_count": (_i, [_i64]),
+    "t2h_trunk_units_words": (_i64, [_i64]),
     "t2h_trunk_units_build": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "t2h_trunk_fused_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "t2h_trunk_block_bwd_workspace_bytes": (_sz, [_i64]),

@@ -500,7 +500,8 @@ struct TrunkFusedArgs {
     const float *w0[kMaxTrunkBlocks], *b0[kMaxTrunkBlocks], *w1[kMaxTrunkBlocks], *b1[kMaxTrunkBlocks], *ws[kMaxTrunkBlocks];
     const float *wc, *bc;
     const int32_t *cell, *off0;
-    const int2 *bounds;           // [n_units] (first row, end row) of every unit (t2h_trunk_units_build), or NULL: fixed-stride units looked up per unit
+    const int2 *bounds;           // (first row, end row) of every unit (t2h_trunk_units_build), or NULL: fixed-stride units looked up per unit
+    const int *n_bounds;          // their number (device word written by t2h_trunk_units_build)
     int M, nb, stride, n_units;
     int ablate;          // lab builds (-DT2H_TRUNK_ABLATE) only: bit 0 no pooling, 1 no global stores, 2 weights staged once, 3 no MFMAs
     float *hr[kMaxTrunkBlocks], *out[kMaxTrunkBlocks], *pooled[kMaxTrunkBlocks];
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     // blocks run, and block 0's weights for the next unit right after this unit's last GEMM.
     int k = blockIdx.x;
     int s = 0, e = 0;
+    if (a.bounds) a.n_units = *a.n_bounds;
     if (k < a.n_units) {
         if (a.bounds) { const int2 u = a.bounds[k]; s = u.x; e = u.y; }
         else {
@@ -827,7 +829,7 @@ __device__ inline int snap_up(const int32_t *cell, const int32_t *off0, long lon
     return st == (int)row ? (int)row : off0[c + 1];
 }
 __global__ __launch_bounds__(64) void trunk_units_kernel(const int32_t *__restrict__ cell, const int32_t *__restrict__ off0, int M,
-                                                        int n_seg, int2 *__restrict__ units) {
+                                                        int n_seg, int2 *__restrict__ units, int *__restrict__ counts) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_seg) return;
     int u = j == 0 ? 0 : snap_up(cell, off0, (long long)j * kUnitSeg, M);
@@ -844,7 +846,35 @@ __global__ __launch_bounds__(64) void trunk_units_kernel(const int32_t *__restri
         slot[n++] = make_int2(u, nxt);
         u = nxt;
     }
+    counts[j] = n;
     for (; n < kUnitSlots; ++n) slot[n] = make_int2(seg_end, seg_end);
+}
+
+// the used slots of all segments -> one dense list (segment order = row order) + their number: one workgroup, chunks of 1024 segments
+__global__ __launch_bounds__(1024) void trunk_units_compact_kernel(const int2 *__restrict__ raw, const int *__restrict__ counts, int n_seg,
+                                                                  int2 *__restrict__ dense, int *__restrict__ total) {
+    __shared__ int scan[1024];
+    __shared__ int carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_seg; base += 1024) {
+        const int j = base + t, c = j < n_seg ? counts[j] : 0;
+        scan[t] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                 // inclusive scan (Hillis-Steele)
+            const int v = t >= d ? scan[t - d] : 0;
+            __syncthreads();
+            scan[t] += v;
+            __syncthreads();
+        }
+        const int at = carry + scan[t] - c;
+        for (int i = 0; i < c; ++i) dense[at + i] = raw[(size_t)j * kUnitSlots + i];
+        __syncthreads();
+        if (t == 1023) carry += scan[1023];
+        __syncthreads();
+    }
+    if (t == 0) *total = carry;
 }
 
 // =====================================================================================================================
@@ -1330,8 +1360,12 @@ T2H_API int t2h_trunk_block_fwd(const float *pts, int dim, const float *w_pos, c
     return check_launch("trunk_block_fwd");
 }
 
-T2H_API int t2h_trunk_units_count(int64_t M) {
-    return M < 1 ? 0 : (int)((M + kUnitSeg - 1) / kUnitSeg) * kUnitSlots;
+// capacity (units) of a tile of M rows, and the int32 words t2h_trunk_units_build needs: [dense pairs 2 cap][count, 3 pad][raw pairs
+// 2 cap][per-segment counts]
+static int trunk_units_cap(int64_t M) { return M < 1 ? 0 : (int)((M + kUnitSeg - 1) / kUnitSeg) * kUnitSlots; }
+T2H_API int64_t t2h_trunk_units_words(int64_t M) {
+    const int64_t cap = trunk_units_cap(M);
+    return cap == 0 ? 0 : 4 * cap + 4 + (M + kUnitSeg - 1) / kUnitSeg;
 }
 
 T2H_API int t2h_trunk_units_build(const int32_t *cell, const int32_t *off0, int64_t M, int32_t *units, t2h_stream_t stream) {
@@ -1339,9 +1373,12 @@ T2H_API int t2h_trunk_units_build(const int32_t *cell, const int32_t *off0, int6
     if (M < 0 || M >= ((int64_t)1 << 31) - TR) return fail(T2H_ERR_ARG, "trunk_units_build: bad shape");
     if (((uintptr_t)units & 7) != 0) return fail(T2H_ERR_ARG, "trunk_units_build: units must be 8-byte aligned");
     if (M == 0) return T2H_OK;
-    const int n_seg = (int)((M + kUnitSeg - 1) / kUnitSeg);
+    const int n_seg = (int)((M + kUnitSeg - 1) / kUnitSeg), cap = trunk_units_cap(M);
+    int2 *dense = reinterpret_cast<int2 *>(units), *raw = reinterpret_cast<int2 *>(units + 2 * cap + 4);
+    int *total = units + 2 * cap, *counts = units + 4 * cap + 4;
     hipLaunchKernelGGL(trunk_units_kernel, dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, as_stream(stream), cell, off0, (int)M, n_seg,
-                       reinterpret_cast<int2 *>(units));
+                       raw, counts);
+    hipLaunchKernelGGL(trunk_units_compact_kernel, dim3(1), dim3(1024), 0, as_stream(stream), raw, counts, n_seg, dense, total);
     return check_launch("trunk_units_build");
 }
 
@@ -1363,7 +1400,8 @@ T2H_API int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, c
     TrunkFusedArgs a{};
     a.pts = pts; a.dim = dim; a.wpos = w_pos; a.bpos = b_pos; a.wc = wc; a.bc = bc; a.cell = cell; a.off0 = off0;
     a.M = (int)M; a.nb = n_blocks; a.stride = stride; a.c_out = c_out; a.ablate = ablate; a.bounds = reinterpret_cast<const int2 *>(units);
-    a.n_units = units ? t2h_trunk_units_count(M) : (int)((M + stride - 1) / stride);
+    a.n_bounds = units ? units + 2 * trunk_units_cap(M) : nullptr;
+    a.n_units = units ? trunk_units_cap(M) : (int)((M + stride - 1) / stride);       // (with a list: an upper bound for the grid; the kernel reads the count)
     for (int b = 0; b < n_blocks; ++b) {
         a.w0[b] = block_params[5 * b]; a.b0[b] = block_params[5 * b + 1]; a.w1[b] = block_params[5 * b + 2];
         a.b1[b] = block_params[5 * b + 3]; a.ws[b] = block_params[5 * b + 4];
@@ -1374,7 +1412,8 @@ T2H_API int t2h_trunk_fused_fwd(const float *pts, int dim, const float *w_pos, c
             return fail(T2H_ERR_ARG, "trunk_fused_fwd: pointers must be 16-byte aligned");
     }
     if (!al16(wc) || !al16(c_out)) return fail(T2H_ERR_ARG, "trunk_fused_fwd: pointers must be 16-byte aligned");
-    const dim3 grid((unsigned)(a.n_units < 512 ? a.n_units : 512));       // two resident per CU, each walks its units
+    const int64_t expect = units ? (M + 95) / 96 : a.n_units;
+    const dim3 grid((unsigned)(expect < 512 ? (expect < 1 ? 1 : expect) : 512));  // two resident per CU, each walks its units
     hipLaunchKernelGGL(trunk_fused_fwd_kernel, grid, dim3(256), 0, as_stream(stream), a);
     note_kernel("trunk_fused_fwd_kernel");
     return check_launch("trunk_fused_fwd");

@@ -126,17 +126,26 @@ class TileIndex:
         return hit
 
     def trunk_units(self):
-        """Work units of the one-launch trunk forward (``t2h_trunk_units_build``): (first row, end row) pairs of whole finest-level
-        cells packed into at most 128 rows.  They depend on the index only: built on first use, kept for the tile's lifetime."""
+        """Work units of the one-launch trunk forward (``t2h_trunk_units_build``): a dense list of (first row, end row) pairs of whole
+        finest-level cells packed into at most 128 rows, then their number (``trunk_unit_list`` decodes it).  They depend on the
+        index only: built on first use, kept for the tile's lifetime."""
         hit = self._adjoint.get("trunk_units")
         if hit is None:
             lib = _lib.load()
             m = int(self.pts.shape[0])
-            n = int(lib.t2h_trunk_units_count(m))
-            hit = torch.empty(n, 2, dtype=torch.int32, device=self.device)
-            _lib.call("t2h_trunk_units_build", _lib.ptr(self.cell), _lib.ptr(self.off0), m, _lib.ptr(hit), _lib.stream(), nbytes=8 * n + 8 * m // 128)
+            n = int(lib.t2h_trunk_units_words(m))
+            hit = torch.empty(n + (n & 1), dtype=torch.int32, device=self.device)
+            _lib.call("t2h_trunk_units_build", _lib.ptr(self.cell), _lib.ptr(self.off0), m, _lib.ptr(hit), _lib.stream(), nbytes=4 * n)
             self._adjoint["trunk_units"] = hit
         return hit
+
+    def trunk_unit_list(self) -> torch.Tensor:
+        """The work units as an [n, 2] int32 tensor on the host side of a synchronisation (tests, probes)."""
+        buf = self.trunk_units()
+        m = int(self.pts.shape[0])
+        cap = (m + 1023) // 1024 * 24
+        n = int(buf[2 * cap].item())
+        return buf[:2 * n].view(n, 2)
 
     def cell_order(self, level: int):
         """Dispatch order of the on-chip walks at ALTO level ``level`` (``t2h_cell_order_build``): the level's cells, then its
