@@ -597,9 +597,9 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
-# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block).  OFF by default: measured
-# on the benchmarked tiles it is no faster than the five launches (profiles/r06_trunk_fused.txt: 2 x 80 KB workgroups per CU leave
-# its phases -- GEMMs, pooling, weight staging -- to run one after the other; 701-772 vs 730 us per four-tile batch); T2H_TRUNK_FUSED=1
+# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block).  OFF by default: 633 against
+# 730 us at four tiles per launch, 218 against 192 us at one (profiles/r06_trunk_fused.txt: 2 x 80 KB workgroups per CU leave its
+# phases -- GEMMs, pooling, weight staging -- to run one after the other) -- 24 us per tile of a 5.4 ms step; T2H_TRUNK_FUSED=1
 _TRUNK_FUSED = os.environ.get("T2H_TRUNK_FUSED", "0") == "1"
 _TRUNK_FUSED_STRIDE = int(os.environ.get("T2H_TRUNK_FUSED_STRIDE", "0"))
 _TRUNK_UNIT_BOUNDS = os.environ.get("T2H_TRUNK_UNIT_BOUNDS", "1") != "0"     # greedy units built once per tile index (0: fixed-stride windows looked up in the kernel)
