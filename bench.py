@@ -55,7 +55,9 @@ MFMA_BX3_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6
 SCATTER_REDUCE_TAGS = ("t2h_sample_relu_cellsums[C=1024,r=32]", "t2h_sample_bwd_from_sums[C=1024,r=32]",
                        "t2h_segsum_fwd[C=128,r=256]",       # the per-cell sums that still run as a kernel of their own (last level)
                        "t2h_segsum_fwd[C=1024,r=256]", "t2h_segsum_fwd[C=512,r=256]", "t2h_segmean_fwd[C=512,r=32]",
-                       "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]", "t2h_pool_max_fwd", "t2h_pool_max_bwd")
+                       # r06: with the micro-batches of the default Trainer the trunk forward (fc_pos, 5 blocks, the 4 pool_locals, fc_c) is ONE
+                       # launch, t2h_trunk_fused_fwd; tile by tile it is the five t2h_trunk_block_fwd launches
+                       "t2h_trunk_fused_fwd", "t2h_trunk_block_fwd[mid]", "t2h_trunk_block_bwd[mid]", "t2h_pool_max_fwd", "t2h_pool_max_bwd")
 
 
 def parse():

@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 16
+#define T2H_ABI_VERSION 17
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -428,6 +428,18 @@ int t2h_gemm_bx3_prepare(const float *w, int ldw, int K, int N, int w_is_kn, voi
 size_t t2h_gemm_bx3_workspace_bytes(int64_t M, int K, int N);
 int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *bias, const float *mask, int ldm, float *y, int ldy,
                  int64_t M, int K, int N, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* r06: the weight gradient of the same product on the split kernels: dw [N, K] = [dw +] dy^T x, db [N] = [db +] colsum(dy) (db may be
+ * NULL) -- the transposed product over the M rows (alto.py:123-130 re-associated: the Linear layers on pixel rows / per-cell sums;
+ * autograd of nn.Linear).  Every fp32 product from three fp16 MFMAs (flag T2H_F16X2: the two-way split with one power-of-two scale
+ * per 32-row unit and operand; the only arithmetic built for this form), deterministic split slabs + reduction.
+ * M % 32 == 0, K in {64, 128, 256}, N % 64 == 0; row strides lddy >= N, ldx >= K in floats.  T2H_ACCUM, T2H_DEFER_REDUCE as
+ * t2h_conv3x3_bx3_wgrad. */
+int t2h_gemm_bx3_wgrad_supported(int64_t M, int K, int N);
+size_t t2h_gemm_bx3_wgrad_workspace_bytes(int64_t M, int K, int N);
+int t2h_gemm_bx3_wgrad(const float *dy, int lddy, const float *x, int ldx, int64_t M, int K, int N, float *dw, float *db, int flags,
+                       void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
 
 /* fp16 two-way split (flag T2H_F16X2 on t2h_conv3x3_bx3_fwd / _dgrad / _wgrad, t2h_gemm_bx3, t2h_upconv2x2_bx3_*).  Each operand
  * element is x 2^e = h1 + h2, two fp16 numbers (11 + 11 significant bits), with ONE power of two 2^e per staged block -- activations:

@@ -46,7 +46,7 @@ def timed(fn, reps=20):
 
 def run(fused, stride=0, greedy=False):
     def go():
-        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = fused, stride, greedy
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS, mlp._TRUNK_FUSED_MIN_ROWS = fused, stride, greedy, 0
         return mlp._trunk_forward_fused(tile, tile.pts, ps[0], ps[1], blocks, ps[-2], ps[-1])
     return go
 

@@ -538,7 +538,7 @@ def test_upconv2x2_on_split_bf16_kernels(b, h, w, cin, cout, mode, monkeypatch):
         names = [r[5] for r in tl.records if r[5].startswith("bx3_")]
         if on:
             assert names[0].endswith(f",64,{npl},1,1,false>") and names[1].endswith(f",64,{npl},1,2,false>"), names
-            assert names[2:] == ([f"bx3_wgrad_kernel<{4 if cin % 128 == 0 else 2},{npl},true>"] if w >= 32 else []), names
+            assert names[2:] == ([f"bx3_wgrad_kernel<{4 if cin % 128 == 0 else 2},{npl},true,0>"] if w >= 32 else []), names
         else:
             assert not names, names
         outs[on] = (y.detach().clone(), xg.grad.clone(), ag.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())

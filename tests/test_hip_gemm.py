@@ -241,6 +241,52 @@ def test_gemm_bx3_rows_vs_float64(m, k, n, monkeypatch):
     assert torch.equal(y2, y.contiguous())
 
 
+@pytest.mark.parametrize("m,k,n", [(65536, 64, 2752), (16384, 128, 2624), (4096, 256, 2368), (262144, 64, 2752), (4096, 64, 1024),
+                                   (32, 64, 64)])
+def test_gemm_bx3_wgrad_vs_float64(m, k, n, monkeypatch):
+    """r06: the weight gradients of the wide grid-side products (dW = dY^T X over the pixel rows of a level: N = 2368 .. 2752
+    columns, K = 64 .. 256, alto.py:123-130 re-associated) on the split kernels, t2h_gemm_bx3_wgrad = bx3_wgrad_kernel<2, 2, false,
+    K / 32> -- against float64 at the tolerance of the fp32 MFMA GEMMs (2e-5 of the max-norm of dW, 2e-5 for db), on strided row
+    slices, with accumulate, with row blocks whose magnitudes are 2^20 apart (one power-of-two scale per 32-row unit and operand),
+    at one and at four tiles' rows, and bit-reproducible (slabs summed in a fixed order)."""
+    from tomosar2height_amd import _lib, mlp
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(m + k + n)
+    wide_y = torch.randn(m, n + 64, generator=g)
+    wide_x = torch.randn(m, k + 32, generator=g)
+    if m >= 4096:                                        # row blocks of very different size: every unit has its own scale
+        wide_y[m // 4: m // 2] *= 2.0 ** 10
+        wide_x[m // 2: 3 * m // 4] *= 2.0 ** -10
+    dy, x = wide_y.to(dev)[:, 32:32 + n], wide_x.to(dev)[:, 16:16 + k]
+    want_w = dy.double().cpu().t() @ x.double().cpu()
+    want_b = dy.double().cpu().sum(0)
+    monkeypatch.setattr(mlp, "_GEMM_BX3_WGRAD", True)
+    monkeypatch.setattr(mlp, "_BX3_WGRAD_MIN_N", 0)
+    monkeypatch.setattr(mlp, "_BX3_WGRAD_MIN_M", 0)
+    dw, db = torch.full((n, k), 7.0, device=dev), torch.full((n,), 7.0, device=dev)
+    with _lib.KernelTimeline() as tl:
+        mlp.linear_wgrad_(dy, x, dw, db)
+    torch.cuda.synchronize()
+    assert any(r[5] == f"bx3_wgrad_kernel<2,2,false,{k // 32}>" for r in tl.records), [r[5] for r in tl.records]
+    sw, sb = want_w.abs().max().item(), want_b.abs().max().item()
+    assert (dw.double().cpu() - want_w).abs().max().item() <= 2e-5 * sw
+    assert (db.double().cpu() - want_b).abs().max().item() <= 2e-5 * sb
+    # accumulate on top of what is there; the same bits every time
+    dw2, db2 = dw.clone(), db.clone()
+    mlp.linear_wgrad_(dy, x, dw2, db2, accumulate=True)
+    assert (dw2.double().cpu() - 2 * want_w).abs().max().item() <= 4e-5 * sw
+    assert (db2.double().cpu() - 2 * want_b).abs().max().item() <= 4e-5 * sb
+    dw3, db3 = torch.empty_like(dw), torch.empty_like(db)
+    mlp.linear_wgrad_(dy, x, dw3, db3)
+    assert torch.equal(dw3, dw) and torch.equal(db3, db)
+    # against the fp32 MFMA kernel it replaces (same tolerance class)
+    monkeypatch.setattr(mlp, "_GEMM_BX3_WGRAD", False)
+    dw4, db4 = torch.empty_like(dw), torch.empty_like(db)
+    mlp.linear_wgrad_(dy, x, dw4, db4)
+    assert (dw4.double().cpu() - want_w).abs().max().item() <= 2e-5 * sw
+    assert (dw4 - dw).abs().max().item() <= 4e-5 * sw
+
+
 def test_batched_slab_reductions_are_bit_identical():
     """_lib.reduce_capture: weight-gradient calls that opt in record their slab reduction and the block's exit runs them in one
     launch -- the same summation tree per output, so dw / db equal the immediately reduced ones bit for bit; two calls into the

@@ -112,6 +112,7 @@ def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride
     nb = len(enc.blocks)
     blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(nb)]
     old = (mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS)
+    old_min, mlp._TRUNK_FUSED_MIN_ROWS = mlp._TRUNK_FUSED_MIN_ROWS, 0
     try:
         # stride -1: the default -- units packed greedily once per tile index (t2h_trunk_units_build); >= 0: fixed windows of
         # `stride` rows (0: 96) snapped to cell boundaries and looked up inside the launch
@@ -127,6 +128,7 @@ def test_one_launch_trunk_equals_the_per_block_launches_bit_for_bit(name, stride
         per = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
     finally:
         mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_STRIDE, mlp._TRUNK_UNIT_BOUNDS = old
+        mlp._TRUNK_FUSED_MIN_ROWS = old_min
     names = ("c", "nets", "pooled", "hrs", "winners")
     assert torch.equal(one[0], per[0]), "c"
     for what, a, b in zip(names[1:], one[1:], per[1:]):

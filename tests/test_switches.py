@@ -40,6 +40,7 @@ GROUPS = {
                        "T2H_CONV_WGRAD_WGS": "128", "T2H_UPCONV_FWD_TILES": "64"},
     "conv_mixed": {"T2H_BX3_WGRAD": "0", "T2H_UPCONV_BX3": "0", "T2H_GEMM_BX3": "0", "T2H_BX3_MIN_PIXELS": "16384"},
     "gemm_bx3_wide": {"T2H_GEMM_BX3_MIN_N": "32", "T2H_GEMM_BX3_MIN_K": "64", "T2H_BX3_PERSIST_WGS": "512"},
+    "gemm_bx3_wgrad_split": {"T2H_GEMM_BX3_WGRAD": "1", "T2H_GEMM_BX3_WGRAD_WGS": "1024"},        # r06: the wide weight gradients on the split TN form
     "gemm_bx3_narrow": {"T2H_GEMM_BX3_MIN_N": "128", "T2H_BX3_PERSIST_N": "0"},            # (the default until r05's last day: 64-wide outputs on the fp32 kernels)
     # per-point GEMM families, trunk forms, grid-first / deferred thresholds
     "gemm_plain": {"T2H_GEMM_DMA": "0", "T2H_SKINNY": "0", "T2H_SMALLM_BK": "16", "T2H_KWAVES_MIN_K": "100000"},
@@ -48,6 +49,7 @@ GROUPS = {
     # r06: the whole trunk forward in one launch (greedy work units per tile index; fixed-stride windows looked up in the launch),
     # coalescing off / eight tiles, micro-batches outside the tile pipeline
     "trunk_one_launch": {"T2H_TRUNK_FUSED": "1"},
+    "trunk_five_launches": {"T2H_TRUNK_FUSED": "0"},
     "trunk_one_launch_strided": {"T2H_TRUNK_FUSED": "1", "T2H_TRUNK_UNIT_BOUNDS": "0", "T2H_TRUNK_FUSED_STRIDE": "112"},
     "trainer_tile_by_tile": {"T2H_COALESCE_TILES": "1"},
     "trainer_coalesce_two_unpipelined": {"T2H_COALESCE_TILES": "2", "T2H_PIPELINE_MICRO_BATCHES": "0"},

@@ -622,6 +622,7 @@ struct WgradArgs {
     int H, W, Cin, Cout;
     int n_units, units_per_split;
     int ldx;                 // pixel stride of x in floats (UP: of the layer's output gradient, which may be a channel slice)
+    int lddy;                // GT (the GEMM form): row stride of dy in floats
 };
 
 // COT = 32-channel tiles of Cout per workgroup (4, 2 or 1): the workgroup's (COT x 9) output tiles are dealt to the four waves
@@ -631,14 +632,19 @@ struct WgradArgs {
 // rows x 64 pixels above a unit's 32 input pixels are staged de-interleaved as [tap][32 pixels] (so a tap reads exactly like a 3 x 3
 // tap does), 4 taps instead of 9; p.Cout / p.Cin are the channel counts of those roles (the layer's Cin / Cout), p.H / p.W the INPUT
 // plane.  The column sums (bias gradient) are then those of the tap side.
-template <int COT, int NPL, bool UP = false>
+// GT > 0 (r06): the same kernel as a transposed product on ROWS -- dW [N][K] = sum_m dY[m][N] X[m][K] with K = 32 GT (the weight
+// gradient of a Linear on pixel rows, t2h_gemm_bx3_wgrad): a unit is 32 consecutive rows, the K side is staged whole as
+// [chunk][32 rows] of 32 channels -- the UP layout with GT "taps", a tap being a channel chunk instead of a pixel shift -- so that dY,
+// the large operand, is read once; p.Cout = N, p.Cin = 32, p.lddy / p.ldx the row strides.
+template <int COT, int NPL, bool UP = false, int GT = 0>
 __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
-    constexpr int NTAPS = UP ? 4 : 9;
+    static_assert(!(UP && GT), "UP and GT are different forms");
+    constexpr int NTAPS = GT ? GT : (UP ? 4 : 9);
     constexpr int WPC = 4 / COT;                                         // waves per co tile
     constexpr int TMAX = (NTAPS + WPC - 1) / WPC;                        // taps per wave, at most
     constexpr int YS = COT == 1 ? 64 : 64 * COT + 64;                    // dY image: bytes per pixel row (4 rows tile the bank row)
     constexpr int XS = 64;                                               // X image: 32 bf16 per pixel, no padding
-    constexpr int YPLANE = 32 * YS, XHP = UP ? 4 * TW : 3 * (TW + 2), XPLANE = XHP * XS;
+    constexpr int YPLANE = 32 * YS, XHP = GT ? GT * TW : (UP ? 4 * TW : 3 * (TW + 2)), XPLANE = XHP * XS;
     constexpr int LDS_WORK = NPL * YPLANE + NPL * XPLANE;
     constexpr int LDS_BYTES = LDS_WORK >= 4 * 32 * 36 * 4 ? LDS_WORK : 4 * 32 * 36 * 4;      // (epilogue patches, column-sum scratch)
     constexpr bool H2 = NPL == 2;                                        // the fp16 two-way split: one power-of-two scale per staged unit
@@ -647,7 +653,8 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
     float *slots = reinterpret_cast<float *>(lds + LDS_BYTES);           // H2: [parity][wave][x, y] unit maxima
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x, ci0 = blockIdx.y * CC, co0 = blockIdx.z * (32 * COT);
+    // (GT: the column groups of dY fastest -- the workgroups that share a row range, i.e. the same rows of X, start together)
+    const int split = GT ? blockIdx.z : blockIdx.x, ci0 = GT ? 0 : blockIdx.y * CC, co0 = (GT ? blockIdx.x : blockIdx.z) * (32 * COT);
     const int u_beg = split * p.units_per_split, u_end = min(p.n_units, u_beg + p.units_per_split);
     const int segs = p.W / TW;
 
@@ -668,7 +675,9 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
             const int hy = px / (TW + 2), hx = px - hy * (TW + 2);
             const int gy = y + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (UP) {      // px = (output row parity, 64 output pixels): rows 2 row, 2 row + 1 of the [*, 2 W] plane, columns 2 x0 ..
+            if (GT) {      // px = (channel chunk, row of the unit): X[u TW + i][32 chunk + 4 c4 ..]
+                if (idx < XF4) v = *reinterpret_cast<const float4 *>(p.x + ((size_t)u * TW + (px % TW)) * p.ldx + (px / TW) * 32 + c4 * 4);
+            } else if (UP) {      // px = (output row parity, 64 output pixels): rows 2 row, 2 row + 1 of the [*, 2 W] plane, columns 2 x0 ..
                 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(2 * row + (px >> 6)) * (2 * p.W) + 2 * x0 + (px & 63)) * p.ldx + ci0 + c4 * 4);
             } else if (idx < XF4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
                 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(row + hy - 1) * p.W + gx) * p.ldx + ci0 + c4 * 4);
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
         for (int f = 0; f < YPER; ++f) {
             const int idx = tid + f * NT;
             const int px = idx / (8 * COT), c4 = idx % (8 * COT);
-            yr[f] = *reinterpret_cast<const float4 *>(p.dy + ((size_t)row * p.W + x0 + px) * p.Cout + co0 + c4 * 4);
+            yr[f] = *reinterpret_cast<const float4 *>(p.dy + ((size_t)row * p.W + x0 + px) * (GT ? p.lddy : p.Cout) + co0 + c4 * 4);
         }
     };
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_wgrad_kernel(WgradArgs p) {
                 const int tap = tap_lo + t;
                 if (tap < tap_hi) {                                       // wave-uniform
                     const int ky = tap / 3, kx = tap - 3 * ky;
-                    const unsigned char *xa = ximg + (UP ? tap * TW + 16 * s + kpix : ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
+                    const unsigned char *xa = ximg + ((UP || GT) ? tap * TW + 16 * s + kpix : ky * (TW + 2) + 16 * s + kpix + kx) * XS + choff;
                     bf16x8 bfr[NPL];
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl) bfr[pl] = tr8(xa + pl * XPLANE, XS);
@@ -999,7 +1008,12 @@ int launch_rows(RowsArgs a, int npl, void *ws, size_t ws_bytes, hipStream_t s, c
         const int pbn = r.bn == 128 ? 64 : r.bn;                          // (128-column tiles spill in this form)
         const int ntn = a.Nc / pbn;
         static const long long persist_wgs = getenv("T2H_BX3_PERSIST_WGS") ? atoll(getenv("T2H_BX3_PERSIST_WGS")) : 2048;
+        // r06: at least four column groups however many row tiles there are -- with four tiles per launch (2 048 row tiles) a
+        // single group made every workgroup walk all 43 column tiles: 289 us per tile against 181 with four groups and the 185 of
+        // one tile per launch (profiles/level256_probe.py; T2H_BX3_PERSIST_MIN_GROUPS)
+        static const long long min_groups = getenv("T2H_BX3_PERSIST_MIN_GROUPS") ? atoll(getenv("T2H_BX3_PERSIST_MIN_GROUPS")) : 4;
         long long groups = persist_wgs / (row_tiles > 0 ? row_tiles : 1);
+        if (groups < min_groups) groups = min_groups;
         if (groups < 1) groups = 1;
         if (groups > ntn) groups = ntn;
         a.ntn_per_wg = (int)((ntn + groups - 1) / groups);
@@ -1130,17 +1144,17 @@ T2H_API int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, fl
     dim3 grid(p.splits, Cin / CC, Cout / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "conv3x3_bx3_wgrad: too many channel chunks");
     if (flags & T2H_F16X2) {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,false>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,2,false>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,false,0>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false,0>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,2,false,0>"); }
     } else if (flags & T2H_BF16) {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,1,false>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,1,false>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,1,false>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,1,false,0>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,1,false,0>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 1>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,1,false,0>"); }
     } else {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,false>"); }
-        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,false>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,3,false>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,false,0>"); }
+        else if (p.cot == 2) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,false,0>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<1, 3>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<1,3,false,0>"); }
     }
     if (int rc = check_launch("conv3x3_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cout * Ncols, Cout, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
@@ -1188,6 +1202,55 @@ T2H_API int t2h_gemm_bx3(const float *x, int ldx, const void *wf, const float *b
     a.flags = ((flags & T2H_RELU_OUT) ? F_RELU_OUT : 0) | ((flags & T2H_ACCUM) ? F_ACCUM : 0);
     a.wscale = f16_trailer(wf, (size_t)K * N * 4);
     return launch_rows(a, npl_of(flags), workspace, workspace_bytes, as_stream(stream), "gemm_bx3", 1);
+}
+
+// ---- the weight gradient of the same GEMM: dW [N][K] = dY^T X, reduction over the M rows (bx3_wgrad_kernel<.., GT = K / 32>) ----------
+static int gemm_wgrad_splits(int64_t M, int N) {
+    static const long long target = getenv("T2H_GEMM_BX3_WGRAD_WGS") ? atoll(getenv("T2H_GEMM_BX3_WGRAD_WGS")) : 4096;
+    const long long groups = N / 64, units = M / TW;
+    long long splits = (target + groups - 1) / groups;
+    if (splits > units) splits = units;
+    if (splits < 1) splits = 1;
+    const long long per = (units + splits - 1) / splits;
+    return (int)((units + per - 1) / per);
+}
+
+T2H_API int t2h_gemm_bx3_wgrad_supported(int64_t M, int K, int N) {
+    return M >= TW && M % TW == 0 && M <= (1LL << 30) && (K == 64 || K == 128 || K == 256) && N >= 64 && N % 64 == 0;
+}
+
+T2H_API size_t t2h_gemm_bx3_wgrad_workspace_bytes(int64_t M, int K, int N) {
+    if (!t2h_gemm_bx3_wgrad_supported(M, K, N)) return 0;
+    return (size_t)gemm_wgrad_splits(M, N) * ((size_t)N * K + N) * sizeof(float);
+}
+
+T2H_API int t2h_gemm_bx3_wgrad(const float *dy, int lddy, const float *x, int ldx, int64_t M, int K, int N, float *dw, float *db, int flags,
+                               void *workspace, size_t workspace_bytes, t2h_stream_t stream) {
+    if (!dy || !x || !dw) return fail(T2H_ERR_ARG, "gemm_bx3_wgrad: null pointer");
+    if (!t2h_gemm_bx3_wgrad_supported(M, K, N))
+        return fail(T2H_ERR_ARG, "gemm_bx3_wgrad: needs M %% 32 == 0, K in {64, 128, 256}, N %% 64 == 0 (M=%lld K=%d N=%d)", (long long)M, K, N);
+    if (lddy < N || ldx < K || lddy % 4 || ldx % 4 || !al16(dy) || !al16(x))
+        return fail(T2H_ERR_ARG, "gemm_bx3_wgrad: rows must be 16-byte aligned and at least N / K floats long");
+    if (!(flags & T2H_F16X2)) return fail(T2H_ERR_ARG, "gemm_bx3_wgrad: only the fp16 two-way split (T2H_F16X2) is built");
+    const size_t need = t2h_gemm_bx3_wgrad_workspace_bytes(M, K, N);
+    if (!workspace || workspace_bytes < need || !al16(workspace))
+        return fail(T2H_ERR_WORKSPACE, "gemm_bx3_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = as_stream(stream);
+    const int splits = gemm_wgrad_splits(M, N);
+    float *slab = static_cast<float *>(workspace);
+    float *colslab = slab + (size_t)splits * N * K;
+    WgradArgs a{};
+    a.dy = dy; a.x = x; a.slab = slab; a.colslab = db ? colslab : nullptr;
+    a.H = (int)(M / TW); a.W = TW; a.Cin = 32; a.Cout = N; a.n_units = (int)(M / TW);
+    a.units_per_split = (a.n_units + splits - 1) / splits; a.ldx = ldx; a.lddy = lddy;
+    const dim3 grid(N / 64, 1, splits);
+    if (grid.z > 65535) return fail(T2H_ERR_ARG, "gemm_bx3_wgrad: too many splits");
+    if (K == 64) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, false, 2>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false,2>"); }
+    else if (K == 128) { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, false, 4>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false,4>"); }
+    else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, false, 8>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,false,8>"); }
+    if (int rc = check_launch("gemm_bx3_wgrad")) return rc;
+    return launch_reduce_slabs(slab, splits, (long long)N * K, N, K, K, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s, 0, 0,
+                               (flags & T2H_DEFER_REDUCE) != 0);
 }
 
 // ---- ConvTranspose2d(kernel_size = 2, stride = 2) on the 1-tap form -------------------------------------------------------------------
@@ -1286,10 +1349,10 @@ T2H_API int t2h_upconv2x2_bx3_wgrad(const float *dy, int lddy, const float *x, f
     dim3 grid(p.splits, Cout / CC, Cin / (32 * p.cot));
     if (grid.y > 65535 || grid.z > 65535) return fail(T2H_ERR_ARG, "upconv2x2_bx3_wgrad: too many channel chunks");
     if (flags & T2H_F16X2) {
-        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,true>"); }
-        else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,true>"); }
-    } else if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,true>"); }
-    else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,true>"); }
+        if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,2,true,0>"); }
+        else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 2, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,2,true,0>"); }
+    } else if (p.cot == 4) { hipLaunchKernelGGL((bx3_wgrad_kernel<4, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<4,3,true,0>"); }
+    else { hipLaunchKernelGGL((bx3_wgrad_kernel<2, 3, true>), grid, dim3(NT), 0, s, a); note_kernel("bx3_wgrad_kernel<2,3,true,0>"); }
     if (int rc = check_launch("upconv2x2_bx3_wgrad")) return rc;
     return launch_reduce_slabs(slab, p.splits, (long long)Cin * Ncols, Cin, Ncols, Ncols, (flags & T2H_ACCUM) ? 1 : 0, dw, colslab, db, s,
                                p.splits, Cout, (flags & T2H_DEFER_REDUCE) != 0);

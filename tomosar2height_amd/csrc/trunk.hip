@@ -628,7 +628,10 @@ __device__ inline void fused_fc_pos(const TrunkFusedArgs &a, float *Xs, const fl
 
 // segmented max of the unit's rows (left half of the X tile, whole cells only) -> right half, winner bits and pooled half to
 // global.  span[p]: first and one-past-last tile row of the cell of this thread's row p (cs | ce << 8), found once per unit from
-// the head masks (the four poolings of a unit share them)
+// the head masks (the four poolings of a unit share them).
+// Each row scans its own cell in ascending order (strict '>': the first maximum wins) -- the L^2 form of pool_into_tile_v2.  (Tried
+// in r06: a long cell's rows SHARING its scan -- eight residue classes, partials through LDS, merged by every row after a barrier
+// -- costs two barriers per row slot and measured slower, 711 against 633 us per four-tile launch; profiles/r06_trunk_fused.txt.)
 __device__ inline void fused_pool_local(float *Xs, const int (&span)[TR / NG], int s, int rows, uint8_t *winner, float *pooled,
                                         int tid, int abl = 0) {
     const int lane = tid & (G - 1), grp = tid >> 3;
@@ -649,12 +652,48 @@ __device__ inline void fused_pool_local(float *Xs, const int (&span)[TR / NG], i
             best_strict(b, v0, n); best_strict(b, v1, n + 1); best_strict(b, v2, n + 2); best_strict(b, v3, n + 3);
         }
         for (; n < ce; ++n) best_strict(b, *reinterpret_cast<const float4 *>(Xs + n * XS + lane * 4), n);
+        // untouched (all NaN) -> 0, as torch_scatter's fill of cells that no value entered.  Only the left halves of the tile are
+        // read above and only right halves written here, so no barrier separates the two
         const float4 pv = make_float4(b.a.x == -1 ? 0.f : b.v.x, b.a.y == -1 ? 0.f : b.v.y, b.a.z == -1 ? 0.f : b.v.z,
                                       b.a.w == -1 ? 0.f : b.v.w);
         *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = pv;
         if ((abl >> 1) & 1) continue;
         *reinterpret_cast<float4 *>(pooled + (size_t)(s + me) * 32 + lane * 4) = pv;
         winner[(size_t)(s + me) * G + lane] = (uint8_t)((b.a.x == me) | ((b.a.y == me) << 1) | ((b.a.z == me) << 2) | ((b.a.w == me) << 3));
+    }
+}
+
+// a unit longer than a tile: chunks of TR rows, block by block, through memory (the one-block loader's border runs are rows of this
+// unit, written by this workgroup and published by a device-scope fence + barrier between the blocks).  Expects block 0's weights staged; leaves the last block's.
+__device__ inline void fused_slow_unit(const TrunkFusedArgs &a, float *Xs, float *Hsm, float *W0s, float *Wss, float *W1s,
+                                             float *Wcs, float *bsm, const float *wps, int s, int e, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int b = 0; b < a.nb; ++b) {
+        const bool last = b == a.nb - 1;
+        if (b > 0) {
+            __threadfence();                                 // this workgroup's `out` rows of the previous block, device-wide
+            __syncthreads();
+            stage_block_weights(a, b, W0s, Wss, W1s, Wcs, bsm, tid);
+            __syncthreads();
+        }
+        TrunkFwdArgs t{};
+        t.net_prev = b > 0 ? a.out[b - 1] : nullptr; t.ld_prev = 32; t.cell = a.cell; t.off0 = a.off0;
+        t.M = a.M; t.pooled = a.pooled[b]; t.winner = a.winner[b]; t.loader = 1;
+        for (int c0 = s; c0 < e; c0 += TR) {
+            const int c1 = min(c0 + TR, e);
+            if (b == 0) { fused_fc_pos(a, Xs, wps, c0, c1, tid); __syncthreads(); }
+            else {
+                pool_into_tile(t, Xs, Hsm, c0, c1, tid);
+                for (int f = 0; f < 4; ++f) {                // the pooled half the backward reads: every wave its own rows
+                    const int idx = lane + f * 64, row = wave * 32 + (idx >> 3), c = (idx & 7) * 4;
+                    if (c0 + row < c1)
+                        *reinterpret_cast<float4 *>(a.pooled[b] + (size_t)(c0 + row) * 32 + c) =
+                            *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
+                }
+            }
+            fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, c0, c1, a.hr[b], a.out[b], a.c_out, last, false, lane, wave);
+            __syncthreads();
+        }
     }
 }
 
@@ -668,7 +707,6 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     __shared__ float bsm[96];
     __shared__ float wps[256];
     __shared__ int unit[2];
-    __shared__ int cells[TR];
     __shared__ unsigned long long heads[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 192) wps[tid] = a.wpos[tid];
@@ -683,8 +721,8 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     // blocks run, and block 0's weights for the next unit right after this unit's last GEMM.
     int k = blockIdx.x;
     int s = 0, e = 0;
-    if (a.bounds) a.n_units = *a.n_bounds;
-    if (k < a.n_units) {
+    const int n_units = a.bounds ? *a.n_bounds : a.n_units;     // (a local: writing the member would copy the whole argument block to scratch)
+    if (k < n_units) {
         if (a.bounds) { const int2 u = a.bounds[k]; s = u.x; e = u.y; }
         else {
             if (tid == 0) { unit[0] = (abl & 16) ? min(k * a.stride, a.M) : unit_start(a, k); unit[1] = (abl & 16) ? min((k + 1) * a.stride, a.M) : unit_start(a, k + 1); }
@@ -705,13 +743,14 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
         }
     };
     request(s, e);
-    for (; k < a.n_units; k += gridDim.x) {
+    for (; k < n_units; k += gridDim.x) {
         const int kn = k + gridDim.x;
         int sn = a.M, en = a.M;
-        if (kn < a.n_units && a.bounds) { const int2 u = a.bounds[kn]; sn = u.x; en = u.y; }  // (in flight during this unit)
+        if (kn < n_units && a.bounds) { const int2 u = a.bounds[kn]; sn = u.x; en = u.y; }  // (in flight during this unit)
         const int rows = e - s;
         if (rows > 0 && rows <= TR) {
             // ---------------------------------------------------------------- fast path: the unit lives in LDS for all blocks
+            int *cells = reinterpret_cast<int *>(Hsm);
             {
                 const int row = tid >> 1, c0 = (tid & 1) * 32;
 #pragma unroll
@@ -728,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                     }
                     *reinterpret_cast<float4 *>(Xs + row * XS + c0 + c) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                if (tid < TR) cells[tid] = cid;
+                if (tid < TR) cells[tid] = cid;                  // (Hsm is free until the unit's first GEMM)
             }
             __syncthreads();                                 // X, the cell ids, block 0's weights (and wps, the first time)
             if (tid < TR) {
@@ -746,7 +785,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                     span[p] = mask_prev_head(m0, m1, me) | (mask_next_head(m0, m1, me) << 8);
                 }
             }
-            if (!a.bounds && kn < a.n_units) {               // (no bounds array: the next unit's lookup, off the critical path)
+            if (!a.bounds && kn < n_units) {               // (no bounds array: the next unit's lookup, off the critical path)
                 if (tid == 0) { unit[0] = (abl & 16) ? min(kn * a.stride, a.M) : unit_start(a, kn); unit[1] = (abl & 16) ? min((kn + 1) * a.stride, a.M) : unit_start(a, kn + 1); }
             }
             for (int b = 0; b < a.nb; ++b) {
@@ -759,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                 }
                 __syncthreads();                             // every wave's `out` rows are in the tile; the block's weights are consumed
                 if (b == 0) {                                // the next unit's inputs, requested under this unit's remaining blocks
-                    if (!a.bounds && kn < a.n_units) { sn = unit[0]; en = unit[1]; }
+                    if (!a.bounds && kn < n_units) { sn = unit[0]; en = unit[1]; }
                     request(sn, en);
                 }
                 if (!(abl & 4) || last) stage_block_weights(a, last ? 0 : b + 1, W0s, Wss, W1s, Wcs, bsm, tid);
@@ -770,42 +809,16 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
         } else if (rows > TR) {
             // ---------------------------------------------------------------- slow path: chunks of TR rows, block by block, through HBM
             __syncthreads();                                 // block 0's weights (and wps)
-            if (!a.bounds && kn < a.n_units) {
+            if (!a.bounds && kn < n_units) {
                 if (tid == 0) { unit[0] = unit_start(a, kn); unit[1] = unit_start(a, kn + 1); }
             }
-            for (int b = 0; b < a.nb; ++b) {
-                const bool last = b == a.nb - 1;
-                if (b > 0) {
-                    __threadfence();                         // this workgroup's `out` rows of the previous block, device-wide
-                    __syncthreads();
-                    stage_block_weights(a, b, W0s, Wss, W1s, Wcs, bsm, tid);
-                    __syncthreads();
-                }
-                TrunkFwdArgs t{};
-                t.net_prev = b > 0 ? a.out[b - 1] : nullptr; t.ld_prev = 32; t.cell = a.cell; t.off0 = a.off0;
-                t.M = a.M; t.pooled = a.pooled[b]; t.winner = a.winner[b]; t.loader = 1;
-                for (int c0 = s; c0 < e; c0 += TR) {
-                    const int c1 = min(c0 + TR, e);
-                    if (b == 0) { fused_fc_pos(a, Xs, wps, c0, c1, tid); __syncthreads(); }
-                    else {
-                        pool_into_tile(t, Xs, Hsm, c0, c1, tid);
-                        for (int f = 0; f < 4; ++f) {        // the pooled half the backward reads: every wave its own rows
-                            const int idx = lane + f * 64, row = wave * 32 + (idx >> 3), c = (idx & 7) * 4;
-                            if (c0 + row < c1)
-                                *reinterpret_cast<float4 *>(a.pooled[b] + (size_t)(c0 + row) * 32 + c) =
-                                    *reinterpret_cast<const float4 *>(Xs + row * XS + 32 + c);
-                        }
-                    }
-                    fused_block_gemms(Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, c0, c1, a.hr[b], a.out[b], a.c_out, last, false, lane, wave, abl);
-                    __syncthreads();
-                }
-            }
-            if (!a.bounds && kn < a.n_units) { sn = unit[0]; en = unit[1]; }
+            fused_slow_unit(a, Xs, Hsm, W0s, Wss, W1s, Wcs, bsm, wps, s, e, tid);
+            if (!a.bounds && kn < n_units) { sn = unit[0]; en = unit[1]; }
             request(sn, en);
             stage_block_weights(a, 0, W0s, Wss, W1s, Wcs, bsm, tid);
         } else {
             // an empty unit (the cell that starts before k S covers the whole window): nothing to do but to move on
-            if (!a.bounds && kn < a.n_units) {
+            if (!a.bounds && kn < n_units) {
                 __syncthreads();
                 if (tid == 0) { unit[0] = unit_start(a, kn); unit[1] = unit_start(a, kn + 1); }
                 __syncthreads();

@@ -66,6 +66,12 @@ GEMM_BX3 = os.environ.get("T2H_GEMM_BX3", "1") != "0"
 
 _BX3_MIN_N = int(os.environ.get("T2H_GEMM_BX3_MIN_N", "64"))
 _BX3_MIN_K = int(os.environ.get("T2H_GEMM_BX3_MIN_K", "128"))
+# (r06: the transposed product dW = dY^T X of those matrices on the split kernels too, t2h_gemm_bx3_wgrad.  OFF by default: 215 against
+# 232 us per tile on the r = 256 level's [N = 2752, K = 64] at four tiles per launch, 248 against 280 at one -- its 32-row units of
+# 256-byte row segments keep it at 3.4 TB/s, not at the HBM floor the arithmetic would allow; profiles/r06_level256_probe.txt)
+_GEMM_BX3_WGRAD = os.environ.get("T2H_GEMM_BX3_WGRAD", "0") == "1"
+_BX3_WGRAD_MIN_N = int(os.environ.get("T2H_GEMM_BX3_WGRAD_MIN_N", "1024"))
+_BX3_WGRAD_MIN_M = int(os.environ.get("T2H_GEMM_BX3_WGRAD_MIN_M", "4096"))
 _PERSIST_N = os.environ.get("T2H_BX3_PERSIST_N", "1") != "0"
 
 
@@ -134,6 +140,11 @@ def linear_dgrad_(dy, w, dx, mask=None, accumulate=False, bx3=False):
     return dx
 
 
+def _grid_h2() -> bool:
+    from . import grid
+    return grid._h2()
+
+
 def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False, defer=False):
     """dw = [dw +] dy^T act_in(x); db = [db +] colsum(dy) (db may be None); deterministic split reduction.  ``defer``: dw / db are
     buffers nobody reads before the backward pass ends: the reduction may join the pass's batched one (``_lib.reduce_capture``)."""
@@ -147,6 +158,18 @@ def linear_wgrad_(dy, x, dw, db, relu_in=False, accumulate=False, defer=False):
             dw.zero_()
             if db is not None:
                 db.zero_()
+        return
+    if (_GEMM_BX3_WGRAD and GEMM_BX3 and _MODE == "fp32" and not relu_in and n >= _BX3_WGRAD_MIN_N and m >= _BX3_WGRAD_MIN_M
+            and _grid_h2() and bool(_lib.ws_bytes("t2h_gemm_bx3_wgrad_supported", m, k, n))):
+        # r06: the wide grid-side products' weight gradients (the per-resolution sum matrices of the deferred update: N = 2368 ..
+        # 2752 columns, K = 64 .. 256) on the split kernels -- fp32-grade products from three fp16 MFMAs like their forward and data
+        # gradient (bx3_wgrad_kernel<.., GT = K / 32>; T2H_GEMM_BX3_WGRAD=1)
+        ws_bytes = _lib.ws_bytes("t2h_gemm_bx3_wgrad_workspace_bytes", m, k, n)
+        ws = _lib.workspace(ws_bytes, dy.device)
+        flags = (_lib.ACCUM if accumulate else 0) | _lib.F16X2 | (_lib.defer_reduce(ws, dw) if defer else 0)
+        _lib.call("t2h_gemm_bx3_wgrad", gp, ldg, xp, ldx, m, k, n, dw.data_ptr(), db.data_ptr() if db is not None else None, flags,
+                  ws.data_ptr(), ws_bytes, _lib.stream(), nbytes=4 * (m * k + m * n + n * k), flops=2 * m * k * n,
+                  tag=_lib.timing() and f"t2h_linear_wgrad[N={n},K={k}]")
         return
     ws_bytes = _lib.ws_bytes("t2h_linear_wgrad_workspace_bytes", m, k, n)
     ws = _lib.workspace(ws_bytes, dy.device)
@@ -597,10 +620,13 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
-# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block).  OFF by default: 633 against
-# 730 us at four tiles per launch, 218 against 192 us at one (profiles/r06_trunk_fused.txt: 2 x 80 KB workgroups per CU leave its
-# phases -- GEMMs, pooling, weight staging -- to run one after the other) -- 24 us per tile of a 5.4 ms step; T2H_TRUNK_FUSED=1
-_TRUNK_FUSED = os.environ.get("T2H_TRUNK_FUSED", "0") == "1"
+# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block): 530 against 737 us at
+# four tiles per launch, 196-218 against 192 us at one (profiles/r06_trunk_fused.txt: its 1 037 work units of one tile are 2.03
+# rounds of the 512 resident workgroups, i.e. three).  T2H_TRUNK_FUSED: "auto" (default) = from _TRUNK_FUSED_MIN_ROWS rows on -- the
+# coalesced micro-batches --, "1" always, "0" never
+_TRUNK_FUSED_MODE = os.environ.get("T2H_TRUNK_FUSED", "auto")
+_TRUNK_FUSED = _TRUNK_FUSED_MODE != "0"
+_TRUNK_FUSED_MIN_ROWS = 0 if _TRUNK_FUSED_MODE == "1" else int(os.environ.get("T2H_TRUNK_FUSED_MIN_ROWS", "196608"))
 _TRUNK_FUSED_STRIDE = int(os.environ.get("T2H_TRUNK_FUSED_STRIDE", "0"))
 _TRUNK_UNIT_BOUNDS = os.environ.get("T2H_TRUNK_UNIT_BOUNDS", "1") != "0"     # greedy units built once per tile index (0: fixed-stride windows looked up in the kernel)
 
@@ -636,7 +662,7 @@ def _trunk_forward_fused(tile, pts, w_pos, b_pos, blocks, w_c, b_c, want_x_full=
     [M, 32] output, pooled[i] (i >= 1) = the pooled half of block i's input (= pool_local(nets[i-1])), winners[i-1] its
     arg-max bits, hrs[i] the hidden activations; ``want_x_full`` also materialises every block's [M, 64] input (tests)."""
     m, nb, dev = pts.shape[0], len(blocks), pts.device
-    if not want_x_full and _TRUNK_FUSED and 2 <= nb <= 8 and m > 0:
+    if not want_x_full and _TRUNK_FUSED and 2 <= nb <= 8 and m > 0 and m >= _TRUNK_FUSED_MIN_ROWS:
         return _trunk_forward_one_launch(tile, pts, w_pos, b_pos, blocks, w_c, b_c)
     nets, pooled, hrs, winners, x_fulls = [], [None], [], [], []
     net_prev, c_out = None, None
