@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 17
+#define T2H_ABI_VERSION 18
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -412,6 +412,16 @@ int t2h_conv3x3_bx3_fwd(const float *x, const void *wf, const float *bias, float
 size_t t2h_conv3x3_bx3_dgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_transposed, float *dx, const float *mask, int B, int H, int W, int Cin,
                           int Cout, int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);
+
+/* r06: the same data gradient with the 1 x 1 head's share of the gradient formed in its epilogue: dx = mask(dgrad) + mask(g[pixel] *
+ * w1[ci]) (mask: (mask > 0), or none), WRITTEN -- for the decoder activations that feed both the next 3 x 3 convolution and the head
+ * (pixel.py:28-31: out = conv4(cat[x, x1, x2, x3])): the head's backward then writes no gradient for them and this kernel reads no
+ * old values.  Bit-identical to t2h_head1x1_bwd's dx followed by t2h_conv3x3_bx3_dgrad(T2H_ACCUM).  g [B H W], w1 [Cin].
+ * Only for shapes whose reduction is not split (t2h_conv3x3_bx3_dgrad_rank1_supported). */
+int t2h_conv3x3_bx3_dgrad_rank1_supported(int B, int H, int W, int Cin, int Cout);
+int t2h_conv3x3_bx3_dgrad_rank1(const float *dy, const void *wf_t, float *dx, const float *mask, const float *g, const float *w1,
+                                int B, int H, int W, int Cin, int Cout, int flags, t2h_stream_t stream);
+
 size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int t2h_conv3x3_bx3_wgrad(const float *dy, const float *x, float *dw, float *db, int B, int H, int W, int Cin, int Cout,
                           int flags, void *workspace, size_t workspace_bytes, t2h_stream_t stream);

@@ -59,6 +59,23 @@ __global__ __launch_bounds__(256, 2) void aggr_lds(float *out, int iters) {
     for (int it = 0; it < iters * 4; ++it) { const float4 v = buf[(threadIdx.x * 7 + it * 13) & 2047]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     if (s.x == 12345.f) out[0] = s.x;
 }
+// r06 (coresidency_hunt.py): integer checksum of a device block, added into *out (64-bit integer adds: order-free, deterministic)
+__global__ __launch_bounds__(256) void aggr_checksum_kernel(const unsigned *p, long long nwords, unsigned long long *out) {
+    unsigned long long s = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long long)gridDim.x * 256)
+        s += (unsigned long long)p[i] * (unsigned long long)((i & 1023) + 1);
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+int aggr_checksum(const void *p, long long nbytes, void *out, void *stream) {
+    const long long nwords = nbytes / 4;
+    long long blocks = (nwords + 256 * 16 - 1) / (256 * 16);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(aggr_checksum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned *)p, nwords,
+                       (unsigned long long *)out);
+    return (int)hipGetLastError();
+}
 int aggr_launch(int which, float *out, int blocks, int iters, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (which == 0) hipLaunchKernelGGL(aggr_mfma_f16_32x32x16, dim3(blocks), dim3(256), 0, s, out, iters);

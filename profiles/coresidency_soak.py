@@ -1,5 +1,7 @@
-"""r05: how often does a pipelined four-tile window differ from the step-synchronised one?  (tests/test_coresidency.py, many times over)
-    python profiles/coresidency_soak.py <windows> [image] [prepared]"""
+"""r05: how often does a pipelined window differ from the step-synchronised one?  (tests/test_coresidency.py, many times over)
+    python profiles/coresidency_soak.py <windows> [image] [prepared] [coalesced]
+r06: `coalesced` = the Trainer's default (nine tiles: micro-batches of 1 + 4 + 4 whose forwards and backwards overlap); without it
+every tile is issued by its own call (four tiles), as in r05."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,10 +14,10 @@ from tomosar2height_amd.config import berlin_config
 from tomosar2height_amd.trainer import Trainer
 
 windows = int(sys.argv[1])
-image, ahead = "image" in sys.argv[2:], "prepared" in sys.argv[2:]
+image, ahead, coalesced = "image" in sys.argv[2:], "prepared" in sys.argv[2:], "coalesced" in sys.argv[2:]
 dev = torch.device("cuda:0")
 tiles = [{"inputs": synth_cloud(40000, seed=700 + i).to(dev),
-          "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(dev)} for i in range(4)]
+          "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(dev)} for i in range(9 if coalesced else 4)]
 if image:
     for i, t in enumerate(tiles):
         t["image"] = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(40 + i)).to(dev)
@@ -26,6 +28,7 @@ def run(ahead, stepsync):
     model = det_init_(TomoSAR2Height(cfg), seed=15).to(dev)
     model.set_channels_last(True)
     tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True, use_image=image)
+    tr.coalesce_tiles = 4 if coalesced else 1
     side = torch.cuda.Stream() if ahead else None
     prep = (lambda t: tr.prepare(t, side)) if ahead else (lambda t: t)
     losses, inner = [], tr._losses
@@ -48,7 +51,7 @@ def run(ahead, stepsync):
     return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, [float(x) for x in losses]
 
 
-gold, gl = run(False, True)
+gold, gl = run(ahead, True)
 bad = 0
 for it in range(windows):
     got, ls = run(ahead, False)
@@ -61,4 +64,4 @@ for it in range(windows):
         worst = max(d, key=lambda k: float((got[k] - gold[k]).abs().max() / (gold[k].abs().max() + 1e-30))) if d else None
         print(f"window {it}: losses equal {[a == b for a, b in zip(ls, gl)]}, {len(d)} of {len(gold)} gradients differ {tops}; worst {worst} "
               f"{float((got[worst] - gold[worst]).abs().max() / (gold[worst].abs().max() + 1e-30)) if worst else 0:.2e}", flush=True)
-print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}: {bad} of {windows} windows differ", flush=True)
+print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}{', coalesced' if coalesced else ''}: {bad} of {windows} windows differ", flush=True)

@@ -167,6 +167,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_conv3x3_f16x2_prepare": (n, 32, 32, 0, n, n),
         "t2h_gemm_f16x2_prepare": (n, 64, 64, 32, 0, n, n),
         "t2h_split_weights_batch": (n, 1, n),
+        "t2h_conv3x3_bx3_dgrad_rank1": (n, n, n, n, n, n, 1, 512, 512, 64, 128, 64, n),
         "t2h_gemm_bx3_wgrad": (n, 2752, n, 64, 128, 64, 2752, n, n, 64, n, 0, n),
         "t2h_gemm_bx3": (n, 64, n, n, n, 0, n, 32, 128, 64, 32, 0, n, 0, n),
         "t2h_upconv2x2_fwd": (n, n, n, n, 1, 32, 32, 32, 32, 0, n),
@@ -195,7 +196,7 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_nchw_to_nhwc": (n, 1, 32, 64, n, n),
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }
-    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems", "t2h_conv3x3_bx3_supported", "t2h_gemm_bx3_supported", "t2h_gemm_bx3_wgrad_supported", "t2h_upconv2x2_bx3_supported",
+    launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems", "t2h_conv3x3_bx3_supported", "t2h_gemm_bx3_supported", "t2h_gemm_bx3_wgrad_supported", "t2h_conv3x3_bx3_dgrad_rank1_supported", "t2h_upconv2x2_bx3_supported",
                                                                                     "t2h_reduce_capture_begin", "t2h_reduce_capture_pending", "t2h_reduce_capture_end")]
     assert sorted(cases) == sorted(launching), set(launching) ^ set(cases)
     for name, args in cases.items():

@@ -413,6 +413,44 @@ def test_fused_conv_decoder(need_x):
         assert torch.equal(a, b)
 
 
+def test_conv_decoder_rank1_epilogue_is_bit_identical():
+    """r06: at 256 x 256 (no split reduction) the decoder's backward forms the 1 x 1 head's share of d x, d x1, d x2 --
+    g[pixel] * w4[channel], ReLU-masked -- in the epilogue of the data gradient that produces the rest of that gradient
+    (t2h_conv3x3_bx3_dgrad_rank1) instead of having the head write it and the data gradient accumulate onto it: every gradient
+    bit for bit the same (T2H_HEAD_RANK1 = 0 / 1), the head's kernel no longer writes those three tensors."""
+    from tomosar2height_amd import _lib, grid
+    from tomosar2height_amd.decoder.pixel import ConvDecoder
+    torch.manual_seed(7)
+    dec = ConvDecoder(32, 1)
+    with torch.no_grad():
+        for c in (dec.conv1, dec.conv2, dec.conv3, dec.conv4):
+            c.bias.uniform_(-0.2, 0.2)
+    dec = dec.to(_dev()).to(memory_format=torch.channels_last)
+    dec.channels_last = True
+    convs = (dec.conv1, dec.conv2, dec.conv3, dec.conv4)
+    x = torch.randn(1, 32, 256, 256, generator=torch.Generator().manual_seed(8))
+    gout = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(9)).to(_dev())
+    res, names = {}, {}
+    old = grid.HEAD_RANK1
+    try:
+        for on in (False, True, False):                     # (the first pass also prepares the transposed split weights)
+            grid.HEAD_RANK1 = on
+            dec.zero_grad()
+            xg = _cl(x).requires_grad_(True)
+            y = dec(xg)
+            with _lib.KernelTimeline() as tl:
+                y.backward(gout)
+            torch.cuda.synchronize()
+            names[on] = [r[0] for r in tl.records]
+            res[on] = [xg.grad.clone()] + [c.weight.grad.clone() for c in convs] + [c.bias.grad.clone() for c in convs]
+    finally:
+        grid.HEAD_RANK1 = old
+    assert grid.dgrad_rank1_ok(torch.empty(1, 64, 256, 256, device=_dev()), dec.conv1.weight)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert len(names[True]) == len(names[False])          # same launches: the rank-1 form replaces the accumulating one
+
+
 def test_conv_module_path_uses_hip_and_accumulates_directly():
     """conv_bias_act on a 3x3 conv: same numbers as torch's module, weight.grad keeps the parameter's channels_last
     layout, and with direct accumulation the gradient lands in the existing .grad buffers (the trainer's bucket)."""

@@ -41,6 +41,7 @@ GROUPS = {
     "conv_mixed": {"T2H_BX3_WGRAD": "0", "T2H_UPCONV_BX3": "0", "T2H_GEMM_BX3": "0", "T2H_BX3_MIN_PIXELS": "16384"},
     "gemm_bx3_wide": {"T2H_GEMM_BX3_MIN_N": "32", "T2H_GEMM_BX3_MIN_K": "64", "T2H_BX3_PERSIST_WGS": "512"},
     "gemm_bx3_wgrad_split": {"T2H_GEMM_BX3_WGRAD": "1", "T2H_GEMM_BX3_WGRAD_WGS": "1024"},        # r06: the wide weight gradients on the split TN form
+    "head_rank1_off": {"T2H_HEAD_RANK1": "0"},                  # r06: the head writes its share of the decoder gradients, the data gradients accumulate
     "gemm_bx3_narrow": {"T2H_GEMM_BX3_MIN_N": "128", "T2H_BX3_PERSIST_N": "0"},            # (the default until r05's last day: 64-wide outputs on the fp32 kernels)
     # per-point GEMM families, trunk forms, grid-first / deferred thresholds
     "gemm_plain": {"T2H_GEMM_DMA": "0", "T2H_SKINNY": "0", "T2H_SMALLM_BK": "16", "T2H_KWAVES_MIN_K": "100000"},

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -112,6 +112,8 @@ SIGNATURES = {
     "t2h_gemm_f16x2_weights_bytes": (_sz, [_i, _i]),
     "t2h_gemm_f16x2_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "t2h_split_weights_batch": (_i, [_vp, _i, _vp]),
+    "t2h_conv3x3_bx3_dgrad_rank1_supported": (_i, [_i, _i, _i, _i, _i]),
+    "t2h_conv3x3_bx3_dgrad_rank1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2h_gemm_bx3_wgrad_supported": (_i, [_i64, _i, _i]),
     "t2h_gemm_bx3_wgrad_workspace_bytes": (_sz, [_i64, _i, _i]),
     "t2h_gemm_bx3_wgrad": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),

@@ -264,6 +264,10 @@ struct RowsArgs {
     // [*, 2^up_logH, 2^up_logW], the output plane has twice its size and up_cout channels
     const float *addend;     // UPM = 1: tensor of the output's shape added to the result, or null
     int up_logW, up_logH, up_cout;
+    // r06 (plain forms): a rank-1 term r1_g[pixel] * r1_w[channel] added to the result under the same mask -- the 1 x 1 head's share of
+    // a decoder activation's gradient (pixel.py:31: conv4(cat[x, x1, x2, x3])), formed in this epilogue instead of being written by
+    // the head's backward and read back here as "old values" (T2H_ACCUM): same products, same order of additions, same bits
+    const float *r1_g, *r1_w;
 };
 
 // output pixel (2y + dy, 2x + dx) of the transposed convolution for GEMM row m = ((b * H + y) * W + x), tap = 2 dy + dx
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
     // epilogue: one 32 x 32 tile at a time through the wave's LDS patch -> float4 rows along the output channels
     float *patch = reinterpret_cast<float *>(lds + (PERSIST ? LDS_WORK : 0)) + wave * (32 * 36);
     const int er = lane >> 3, ec = (lane & 7) * 4;
-    const bool relu = p.flags & F_RELU_OUT, accum = p.flags & F_ACCUM;
+    const bool relu = p.flags & F_RELU_OUT, rank1 = UPM == 0 && p.r1_g != nullptr, accum = (p.flags & F_ACCUM) || rank1;
     float *const ybase = p.y + (size_t)split * ((size_t)p.B * p.H * p.W * p.ldy);     // (split == 0 unless the reduction is split)
     // What the epilogue READS from global memory (ReLU mask, the old values under T2H_ACCUM, the residual addend of the transposed
     // convolution) is fetched one 32 x 32 tile ahead of the tile being written: issued inside the pass loop each load's latency was
@@ -566,7 +570,11 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
                 if (accum) o[pass] = *reinterpret_cast<const float4 *>(p.y + q);
             } else {
                 if (p.mask) m[pass] = *reinterpret_cast<const float4 *>(p.mask + q * p.ldm + col);
-                if (accum) o[pass] = *reinterpret_cast<const float4 *>(ybase + q * p.ldy + col);
+                if (rank1) {
+                    const float gq = p.r1_g[q];
+                    const float4 wv = *reinterpret_cast<const float4 *>(p.r1_w + col);
+                    o[pass] = make_float4(gq * wv.x, gq * wv.y, gq * wv.z, gq * wv.w);
+                } else if (accum) o[pass] = *reinterpret_cast<const float4 *>(ybase + q * p.ldy + col);
             }
         }
     };
@@ -591,7 +599,12 @@ __global__ __launch_bounds__(NT, 2) void bx3_rows_kernel(RowsArgs p) {
             float4 v = *reinterpret_cast<const float4 *>(patch + (pass * 8 + er) * 36 + ec);
             int col, co;
             const size_t q = tile_off(t, pass, col, co);
-            const float4 mk = pre_m[t & 1][pass], old = pre_o[t & 1][pass];
+            const float4 mk = pre_m[t & 1][pass];
+            float4 old = pre_o[t & 1][pass];
+            if (rank1 && p.mask) {                                        // (the head masks its share like this kernel masks its own)
+                old.x = mk.x > 0.f ? old.x : 0.f; old.y = mk.y > 0.f ? old.y : 0.f;
+                old.z = mk.z > 0.f ? old.z : 0.f; old.w = mk.w > 0.f ? old.w : 0.f;
+            }
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (UPM == 1) {
                 float4 *dst = reinterpret_cast<float4 *>(p.y + q);
@@ -1117,6 +1130,30 @@ T2H_API int t2h_conv3x3_bx3_dgrad(const float *dy, const void *wf_t, float *dx, 
     a.flags = (flags & T2H_ACCUM) ? F_ACCUM : 0;
     a.wscale = f16_trailer(wf_t, (size_t)Cout * 9 * Cin * 4);
     return launch_rows(a, npl_of(flags), workspace, workspace_bytes, as_stream(stream), "conv3x3_bx3_dgrad");
+}
+
+// the data gradient + the rank-1 term g[pixel] * w1[ci] under the same mask, written (not accumulated): dx = mask(dgrad) + mask(g w1).
+// Only where the reduction is not split (the epilogue runs in the kernel): t2h_conv3x3_bx3_dgrad_rank1_supported
+T2H_API int t2h_conv3x3_bx3_dgrad_rank1_supported(int B, int H, int W, int Cin, int Cout) {
+    if (!t2h_conv3x3_bx3_supported(B, H, W, Cin, Cout)) return 0;
+    return bx3_rows_plan(B, H, W, Cout, Cin).splits == 1;
+}
+
+T2H_API int t2h_conv3x3_bx3_dgrad_rank1(const float *dy, const void *wf_t, float *dx, const float *mask, const float *g, const float *w1,
+                                        int B, int H, int W, int Cin, int Cout, int flags, t2h_stream_t stream) {
+    if (!dy || !wf_t || !dx || !g || !w1) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad_rank1: null pointer");
+    if (int rc = check_bx3("conv3x3_bx3_dgrad_rank1", B, H, W, Cin, Cout)) return rc;
+    if (!t2h_conv3x3_bx3_dgrad_rank1_supported(B, H, W, Cin, Cout))
+        return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad_rank1: this shape splits its reduction (use t2h_conv3x3_bx3_dgrad with T2H_ACCUM)");
+    if (flags & T2H_ACCUM) return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad_rank1: the rank-1 term takes the place of the accumulated values");
+    if (!al16(dy) || !al16(wf_t) || !al16(dx) || (mask && !al16(mask)) || !al16(w1))
+        return fail(T2H_ERR_ARG, "conv3x3_bx3_dgrad_rank1: pointers must be 16-byte aligned");
+    RowsArgs a{};
+    a.x = dy; a.wf = static_cast<const unsigned *>(wf_t); a.bias = nullptr; a.mask = mask; a.y = dx;
+    a.B = B; a.H = H; a.W = W; a.Kc = Cout; a.Nc = Cin; a.ldx = Cout; a.ldy = Cin; a.ldm = Cin;
+    a.flags = 0; a.r1_g = g; a.r1_w = w1;
+    a.wscale = f16_trailer(wf_t, (size_t)Cout * 9 * Cin * 4);
+    return launch_rows(a, npl_of(flags), nullptr, 0, as_stream(stream), "conv3x3_bx3_dgrad_rank1");
 }
 
 T2H_API size_t t2h_conv3x3_bx3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

@@ -303,6 +303,29 @@ def conv3x3_fwd_(x, w, bias, y, relu=False, accumulate=False):
     return y
 
 
+# r06: the 1 x 1 head's rank-1 share of a decoder activation's gradient formed in the data gradient's epilogue (T2H_HEAD_RANK1=0: the
+# head writes it, the data gradient accumulates onto it -- bit-identical)
+HEAD_RANK1 = os.environ.get("T2H_HEAD_RANK1", "1") != "0"
+
+
+def dgrad_rank1_ok(gy, w) -> bool:
+    b, cout, h, wd = gy.shape
+    cin = w.shape[1]
+    return (HEAD_RANK1 and bx3_applicable(b, h, wd, cin, cout)
+            and bool(_lib.load().t2h_conv3x3_bx3_dgrad_rank1_supported(b, h, wd, cin, cout)))
+
+
+def conv3x3_dgrad_rank1_(gy, w, dx, mask, g, w1):
+    """dx = mask(conv3x3 data gradient of gy) + mask(g[pixel] * w1[channel]), written (``dgrad_rank1_ok`` shapes only)."""
+    b, cout, h, wd = gy.shape
+    cin = w.shape[1]
+    _lib.call("t2h_conv3x3_bx3_dgrad_rank1", _lib.ptr(gy), _lib.ptr(split_weights.get(w, True)), _lib.ptr(dx),
+              _lib.ptr(mask) if mask is not None else None, _lib.ptr(g), _lib.ptr(w1), b, h, wd, cin, cout, _bx3_flag(), _lib.stream(),
+              nbytes=4 * (gy.numel() + dx.numel() * (2 if mask is not None else 1) + w.numel() + g.numel()),
+              flops=2 * 9 * cin * cout * b * h * wd, tag=_lib.timing() and f"t2h_conv3x3_dgrad[{cout}->{cin},{h}x{wd}]")
+    return dx
+
+
 def conv3x3_dgrad_(gy, w, dx, mask=None, accumulate=False):
     b, cout, h, wd = gy.shape
     cin = w.shape[1]
@@ -773,12 +796,26 @@ class _ConvDecoder(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         dxs = [torch.empty_like(a, memory_format=torch.channels_last) if (i > 0 or need_x) else None
                for i, a in enumerate(acts)]
-        dw4, db4 = _head_bwd(acts, dxs, w4, b4, g, relu_inputs=(1, 2, 3))
+        g = g.contiguous()
+        # r06: where the data gradient can form the head's rank-1 share itself (g[pixel] * w4[channel], same mask) the head writes
+        # no gradient for that activation and the data gradient reads no old values: 0.65 GB less traffic per tile at 512 x 512
+        convs = ((w1, b1), (w2, b2), (w3, b3))
+        fold = [dxs[i] is not None and dgrad_rank1_ok(dxs[i + 1], _w_cl(convs[i][0])) for i in range(3)]      # input i of the head
+        w4flat = w4.reshape(-1).contiguous()
+        starts = [0]
+        for a in acts:
+            starts.append(starts[-1] + a.shape[1])
+        dw4, db4 = _head_bwd(acts, [None if (i < 3 and fold[i]) else d for i, d in enumerate(dxs)], w4, b4, g, relu_inputs=(1, 2, 3))
         grads = []
-        for level, (w, bias) in reversed(list(enumerate(((w1, b1), (w2, b2), (w3, b3)), start=1))):
+        for level, (w, bias) in reversed(list(enumerate(convs, start=1))):
             gm, xin = dxs[level], acts[level - 1]            # gm: complete and already ReLU-masked
             grads.append(_conv3x3_param_grads(gm, xin, w, bias))
-            if dxs[level - 1] is not None:
+            if dxs[level - 1] is None:
+                continue
+            if fold[level - 1]:
+                conv3x3_dgrad_rank1_(gm, _w_cl(w), dxs[level - 1], xin if level > 1 else None, g,
+                                     w4flat[starts[level - 1]:starts[level]])
+            else:
                 conv3x3_dgrad_(gm, _w_cl(w), dxs[level - 1], mask=xin if level > 1 else None, accumulate=True)
         (dw3, db3), (dw2, db2), (dw1, db1) = grads
         return dxs[0], dw1, db1, dw2, db2, dw3, db3, dw4, db4
