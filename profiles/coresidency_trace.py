@@ -71,10 +71,19 @@ def call(name, *a, **k):
     for j, (p, n) in enumerate(uniq):
         if n >= 4:
             ag.aggr_checksum(p, n, table_ptr + 8 * (i * ARGS + j), s)
+        if SAVE == (i, j):
+            saved_n[0] = min(n, saved.numel() * 4) // 4
+            hip.hipMemcpyAsync(raw_data_ptr(saved), p, saved_n[0] * 4, 3, s)
 
 
 torch.Tensor.data_ptr = data_ptr
 _lib.call = call
+# T2H_TRACE_SAVE=call:tensor -- a copy of that tensor's bytes right after that call, compared word by word where the losses differ
+SAVE = tuple(int(v) for v in os.environ["T2H_TRACE_SAVE"].split(":")) if os.environ.get("T2H_TRACE_SAVE") else None
+saved = torch.zeros(1 << 26, dtype=torch.int32, device=dev) if SAVE else None          # 256 MB
+saved_n = [0]
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
 
 
 def run(stepsync):
@@ -120,25 +129,49 @@ def run(stepsync):
 
 
 gold, gl = run(True)
+saved_gold = saved[:saved_n[0]].clone() if SAVE else None
 gold2, _ = run(True)
+if os.environ.get("T2H_TRACE_LIST"):
+    lo, hi = (int(v) for v in os.environ["T2H_TRACE_LIST"].split(","))
+    for k in range(lo, min(hi, len(names))):
+        print(f"    [{k}] {names[k][0]} ({names[k][1]}) {names[k][2]}")
 free = gold != gold2
 print(f"{gold.shape[0]} traced calls per window ({'forward + backward' if with_bwd else 'forward'}), {int((gold != 0).sum())} tensors; "
       f"{int(free.sum())} entries differ between two step-synchronised windows (masked):", flush=True)
 for k in sorted(set(torch.nonzero(free)[:, 0].tolist())):
     print(f"    call {k}: {names[k][0]} ({names[k][1]}) tensors {torch.nonzero(free[k]).flatten().tolist()}")
-bad, firsts = 0, {}
+bad, record = 0, []
 for it in range(windows):
     got, ls = run(False)
     d = torch.nonzero((got != gold) & ~free)
-    if len(d) or ls != gl:
-        bad += 1
-        rows = sorted(set(d[:, 0].tolist()))
-        print(f"window {it}: losses equal {[a == b for a, b in zip(ls, gl)]}; {len(rows)} calls differ", flush=True)
-        for k in rows[:6]:
-            js = d[d[:, 0] == k][:, 1].tolist()
-            print(f"    call {k}: {names[k][0]} ({names[k][1]}): tensors {js} of {len(names[k][2])} (bytes {[names[k][2][j] for j in js]})", flush=True)
-        if rows:
-            key = f"{rows[0]}:{names[rows[0]][0]}"
-            firsts[key] = firsts.get(key, 0) + 1
-print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}, coalesced, N = {points}: {bad} of {windows} windows differ; "
+    record.append((it, ls == gl, {(int(k), int(j)) for k, j in d.tolist()}, [a == b for a, b in zip(ls, gl)]))
+    if SAVE and ls != gl:
+        now = saved[:saved_n[0]]
+        w = torch.nonzero(now != saved_gold).flatten()
+        print(f"window {it}: saved tensor {SAVE}: {len(w)} of {saved_n[0]} words differ"
+              + (f", word offsets {w[:6].tolist()} .. {w[-3:].tolist()}; here {[hex(v & 0xffffffff) for v in now[w[:6]].tolist()]} "
+                 f"gold {[hex(v & 0xffffffff) for v in saved_gold[w[:6]].tolist()]}; last 64 words here "
+                 f"{[hex(v & 0xffffffff) for v in now[-64:].tolist() if v]} gold {[hex(v & 0xffffffff) for v in saved_gold[-64:].tolist() if v]}" if len(w) else ""),
+              flush=True)
+    bad += ls != gl
+# entries that also differ in windows whose losses are all equal are not the fault: a tensor handed over as a slice of a wider
+# buffer is summed over its whole extent (the r = 256 concatenation: 2.7 GB), columns another call has not written yet included
+noise = set()
+for _, same, d, _ in record:
+    if same:
+        noise |= d
+print(f"{len(noise)} (call, tensor) entries differ in windows whose losses are equal (unwritten parts of wider buffers): ignored")
+firsts = {}
+for it, same, d, eq in record:
+    if same:
+        continue
+    real = sorted(d - noise)
+    rows = sorted({k for k, _ in real})
+    print(f"window {it}: losses equal {eq}; {len(rows)} calls differ beyond the ignored entries", flush=True)
+    for k in rows[:8]:
+        js = [j for kk, j in real if kk == k]
+        print(f"    call {k}: {names[k][0]} ({names[k][1]}): tensors {js} of {len(names[k][2])} (bytes {[names[k][2][j] for j in js]}; all {names[k][2]})", flush=True)
+    key = f"{rows[0]}:{names[rows[0]][0]}" if rows else "none beyond the ignored entries"
+    firsts[key] = firsts.get(key, 0) + 1
+print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}, coalesced, N = {points}: the losses of {bad} of {windows} windows differ; "
       f"first differing call -> windows: {firsts or 'none'}", flush=True)

@@ -316,3 +316,41 @@ def test_batched_slab_reductions_are_bit_identical():
 
     for a, b in zip(run(False), run(True)):
         assert torch.equal(a, b)
+
+
+def test_split_weights_filled_on_one_stream_are_waited_for_on_another():
+    """r06: a SplitWeightCache entry is filled lazily by the stream that first needs it; another stream's first use waits for the
+    event behind that fill (_lib.Ready).  Here the fill is queued behind a 0.1 s spin on stream a and the product runs on stream b
+    at once: without the wait it multiplies by whatever the fresh buffer held."""
+    from tomosar2height_amd import grid, mlp
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4096, 1664, generator=g).to(dev)
+    w = torch.randn(512, 1664, generator=g).to(dev)
+    ref = (x.double() @ w.double().t())
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    assert mlp._bx3_gemm_ok(4096, 1664, 512, x)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(int(3e8))
+        grid.split_weights.get_gemm(w, False)
+    with torch.cuda.stream(b):
+        y = torch.empty(4096, 512, device=dev)
+        mlp.linear_fwd_(x, w, None, y, bx3=True)
+    torch.cuda.synchronize()
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    # the conv form and the transposed-convolution form go through the same guard
+    wc = torch.randn(64, 64, 3, 3, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    xi = torch.randn(1, 64, 64, 64, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(int(3e8))
+        grid.split_weights.get(wc, False)
+    with torch.cuda.stream(b):
+        yc = torch.empty(1, 64, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+        grid.conv3x3_fwd_(xi, wc, None, yc)
+    torch.cuda.synchronize()
+    refc = torch.nn.functional.conv2d(xi.double().cpu(), wc.double().cpu(), padding=1)
+    errc = float((yc.double().cpu() - refc).abs().max() / refc.abs().max())
+    assert errc < 1e-5, errc

@@ -439,6 +439,36 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_CACHE_READY = os.environ.get("T2H_CACHE_READY", "1") != "0"      # 0: the r04-r06 behaviour, to show that the tests catch it
+
+
+class Ready:
+    """Who may read a device buffer that some stream filled lazily (a cache entry: split weights, composed maps): the stream that
+    filled it, and any other stream AFTER it has waited for the event recorded behind the fill.  r06: the tile pipeline runs the
+    forwards of consecutive micro-batches on two streams that are ordered by nothing but the weights -- an entry created by the
+    first four-tile forward (shapes a single tile does not use) was read by the next forward, on the other stream, before its
+    fill had run: garbage weights in one product of one forward, 1 window in 150 (profiles/r06_coresidency.txt section 7)."""
+    __slots__ = ("event", "seen")
+
+    def __init__(self):
+        self.event, self.seen = None, None
+
+    def mark(self):
+        """The buffer's fill has just been issued on the current stream."""
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.seen = {stream()}
+
+    def wait(self):
+        """Called before every use: one dictionary look-up on the stream that already knows the buffer."""
+        cur = stream()
+        if self.seen is None or cur in self.seen or not _CACHE_READY:
+            return
+        if not torch.cuda.is_current_stream_capturing():       # (a capture is preceded by warm-up passes and a device-wide wait)
+            torch.cuda.current_stream().wait_event(self.event)
+        self.seen.add(cur)
+
+
 def require_device(*tensors, what="t2h op"):
     """Argument validation that the C side cannot do: device, dtype, contiguity."""
     for t in tensors:

@@ -245,6 +245,7 @@ class _DeferredLevel(torch.autograd.Function):
         if state.cache is not None and not ctx.needs_input_grad[1]:
             # maps from the trainer's ComposeCache: this tile's share goes onto the persistent sums (zeroed by flush())
             e = state.cache.levels[idx]
+            e["ready"].wait()
             mlp.linear_wgrad_(x, dacc, e["ga"], None, accumulate=True, defer=True)   # += x^T dacc (read at flush(): after the pass)
             e["gconst"].add_(dconst)
             dconst = None
@@ -317,7 +318,8 @@ class ComposeCache:
         if idx == len(self.levels):
             a_all, const = self._compute(idx, params)
             self.levels.append({"params": params, "versions": ver, "a_all": a_all, "const": const,
-                                "ga": torch.zeros_like(a_all), "gconst": torch.zeros_like(const)})
+                                "ga": torch.zeros_like(a_all), "gconst": torch.zeros_like(const), "ready": _lib.Ready()})
+            self.levels[idx]["ready"].mark()
         else:
             e = self.levels[idx]
             if any(p is not q for p, q in zip(e["params"], params)):
@@ -329,6 +331,9 @@ class ComposeCache:
                 e["a_all"].copy_(a_all)
                 e["const"].copy_(const)
                 e["versions"] = ver
+                e["ready"].mark()
+            else:
+                e["ready"].wait()                             # (computed on another stream, e.g. the other tile stream: that first)
         e = self.levels[idx]
         return e["a_all"], e["const"]
 

@@ -165,7 +165,7 @@ class SplitWeightCache:
     values after ``refresh()`` (called by ``Trainer.optimizer_boundary``; a replayed graph runs no Python per tile)."""
 
     def __init__(self):
-        self.entries = {}          # (id(weight), transposed) -> [weakref, version, data_ptr, buffer]
+        self.entries = {}          # (id(weight), transposed) -> [weakref, version, data_ptr, buffer, max slot, _lib.Ready]
 
     def get(self, w: torch.Tensor, transposed: bool) -> torch.Tensor:
         import weakref
@@ -176,10 +176,13 @@ class SplitWeightCache:
             lib = _lib.load()
             nbytes = int((lib.t2h_conv3x3_f16x2_weights_bytes if _h2() else lib.t2h_conv3x3_bx3_weights_bytes)(cin, cout))
             buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf, 3]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, k=key: self.entries.pop(k, None)), None, None, buf, 3, _lib.Ready()]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare(w, key[1], e[3])
             e[1], e[2], e[4] = w._version, w.data_ptr(), 3
+            e[5].mark()
+        else:
+            e[5].wait()                                       # (filled on another stream: that fill first)
         return e[3]
 
     @staticmethod
@@ -200,10 +203,13 @@ class SplitWeightCache:
             lib = _lib.load()
             buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
                               dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3, _lib.Ready()]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare_gemm(w, key[1], e[3])
             e[1], e[2], e[4] = w._version, w.data_ptr(), 3
+            e[5].mark()
+        else:
+            e[5].wait()
         return e[3]
 
     @staticmethod
@@ -225,10 +231,13 @@ class SplitWeightCache:
             lib = _lib.load()
             buf = torch.empty(int((lib.t2h_gemm_f16x2_weights_bytes if _h2() else lib.t2h_gemm_bx3_weights_bytes)(k, n)),
                               dtype=torch.uint8, device=w.device)
-            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3]
+            e = self.entries[key] = [weakref.ref(w, lambda _r, kk=key: self.entries.pop(kk, None)), None, None, buf, 3, _lib.Ready()]
         if e[1] != w._version or e[2] != w.data_ptr():
             self._prepare_up(w, key[1], e[3])
             e[1], e[2], e[4] = w._version, w.data_ptr(), 3
+            e[5].mark()
+        else:
+            e[5].wait()
         return e[3]
 
     @staticmethod
@@ -271,8 +280,11 @@ class SplitWeightCache:
             return
         arr = (_lib.PrepDesc * len(todo))(*[t[0] for t in todo])
         _lib.call("t2h_split_weights_batch", ctypes.addressof(arr), len(todo), _lib.stream())
+        done = _lib.Ready()
+        done.mark()                                           # one event behind the batch, shared by its entries
         for d, e, w in todo:
             e[1], e[2], e[4] = w._version, w.data_ptr(), (e[4] ^ 3) if d.h2 else e[4]
+            e[5] = done
 
 
 split_weights = SplitWeightCache()
