@@ -12,6 +12,10 @@ import ctypes
 import os
 import sys
 
+# (the replay reads the recorded micro-batch's index buffers after the allocator has recycled them: harmless for kernels that only
+#  index rows with them, not for the one-launch trunk, whose unit list and count live there -- the hunt runs the per-block trunk)
+os.environ.setdefault("T2H_TRUNK_FUSED", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)

@@ -16,4 +16,5 @@ pad = int(os.environ.get("T2H_LAB_PAD", "4"))
 b.build_variant(os.path.join(lab, "libt2h_select.so"), {"point_grid": {"defines": ["T2H_TAPS_BY_SELECT"]}})
 b.build_variant(os.path.join(lab, f"libt2h_select_pad{pad}.so"), {"point_grid": {"defines": ["T2H_TAPS_BY_SELECT"], "pad": pad}})
 b.build_variant(os.path.join(lab, f"libt2h_trunk_pad{pad}.so"), {"trunk": {"pad": pad}})
+b.build_variant(os.path.join(lab, "libt2h_trunk_ablate.so"), {"trunk": {"defines": ["T2H_TRUNK_ABLATE"]}})      # profiles/trunk_fused_probe.py
 print(sorted(os.listdir(lab)))

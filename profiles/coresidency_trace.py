@@ -8,6 +8,7 @@ no allocation, no host sync), and names the first (call, tensor) whose checksum 
 Entries that differ between two step-synchronised windows (scratch whose order is free, e.g. the cell-order lists) are masked.
 
     python profiles/coresidency_trace.py <windows> [image] [prepared] [backward]
+    (T2H_TRACE_POINTS=N, T2H_TRACE_COALESCE=1 for the tile-by-tile window, T2H_TRACE_STALL=1, T2H_TRACE_SAVE=call:tensor, T2H_TRACE_LIST=lo,hi)
 """
 import ctypes
 import os
@@ -25,17 +26,19 @@ from tomosar2height_amd.trainer import Trainer
 windows = int(sys.argv[1])
 image, ahead, with_bwd = "image" in sys.argv[2:], "prepared" in sys.argv[2:], "backward" in sys.argv[2:]
 points = int(os.environ.get("T2H_TRACE_POINTS", "40000"))
+coalesce = int(os.environ.get("T2H_TRACE_COALESCE", "4"))            # 1: tile by tile (four tiles)
+stall = os.environ.get("T2H_TRACE_STALL") == "1"                      # the second forward of a pipelined window starts 0.1 s late
 dev = torch.device("cuda:0")
 ag = ctypes.CDLL(os.path.join(ROOT, "profiles", "_lab", "libaggr.so"))
 ag.aggr_checksum.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
 tiles = [{"inputs": synth_cloud(points, seed=700 + i).to(dev),
-          "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(dev)} for i in range(9)]
+          "dsm": (torch.rand(1, 512, 512, generator=torch.Generator().manual_seed(i)) * 30).to(dev)} for i in range(9 if coalesce > 1 else 4)]
 if image:
     for i, t in enumerate(tiles):
         t["image"] = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(40 + i)).to(dev)
 cfg = berlin_config(use_image=image)
 
-CALLS, ARGS = 4096, 24
+CALLS, ARGS = 4096, 64
 table = torch.zeros(CALLS, ARGS, dtype=torch.int64, device=dev)
 table_ptr = table.data_ptr()
 seen, names, state = [], [], {"on": False, "k": 0}
@@ -66,7 +69,8 @@ def call(name, *a, **k):
     del seen[:]
     if len(names) <= i:
         names.append((k.get("tag") or name, name, [n for _, n in uniq]))
-    assert i < CALLS and len(uniq) <= ARGS, (i, len(uniq))
+    assert i < CALLS, i
+    uniq = uniq[:ARGS]
     s = _lib.stream()
     for j, (p, n) in enumerate(uniq):
         if n >= 4:
@@ -90,7 +94,7 @@ def run(stepsync):
     model = det_init_(TomoSAR2Height(cfg), seed=15).to(dev)
     model.set_channels_last(True)
     tr = Trainer(model, torch.optim.SGD(model.parameters(), lr=0.0), device=dev, optimize_every=100, use_cloud=True, use_image=image)
-    tr.coalesce_tiles = 4
+    tr.coalesce_tiles = coalesce
     side = torch.cuda.Stream() if ahead else None
     prep = (lambda t: tr.prepare(t, side)) if ahead else (lambda t: t)
     losses, inner, inner_bwd = [], tr._losses, tr._backward
@@ -100,6 +104,8 @@ def run(stepsync):
     del seen[:]
 
     def rec(data, thr):
+        if stall and not stepsync and len(losses) == 1:
+            torch.cuda._sleep(int(3e8))
         state["on"] = True
         try:
             l1, ce = inner(data, thr)
@@ -173,5 +179,5 @@ for it, same, d, eq in record:
         print(f"    call {k}: {names[k][0]} ({names[k][1]}): tensors {js} of {len(names[k][2])} (bytes {[names[k][2][j] for j in js]}; all {names[k][2]})", flush=True)
     key = f"{rows[0]}:{names[rows[0]][0]}" if rows else "none beyond the ignored entries"
     firsts[key] = firsts.get(key, 0) + 1
-print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}, coalesced, N = {points}: the losses of {bad} of {windows} windows differ; "
+print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}, {'coalesced' if coalesce > 1 else 'tile by tile'}{', stalled' if stall else ''}, N = {points}: the losses of {bad} of {windows} windows differ; "
       f"first differing call -> windows: {firsts or 'none'}", flush=True)

@@ -52,6 +52,15 @@ struct TrunkFwdArgs {
 
 __device__ inline float clean(float x) { return x != x ? -FLT_MAX : x; }
 
+// `a` where the integer n is positive, else +0 -- without a compare result (a kernel that can share a CU with the split convolutions
+// keeps none for a later vector select: DESIGN.md section 8).  The clamp is an opaque v_med3_i32: written as min(max(n, 0), 1) the
+// compiler recognises the idiom and emits the very v_cmp -> v_cndmask it was meant to avoid.
+__device__ inline float keep_if_positive(int n, float a) {
+    int m;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(m) : "v"(n));
+    return __int_as_float(__float_as_int(a) & -m);
+}
+
 struct Best { float4 v; int4 a; };
 __device__ inline void best_init(Best &b) {
     b.v = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
@@ -597,7 +606,7 @@ __device__ inline void fused_block_gemms(float *Xs, float *Hsm, const float *W0s
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int ro = (q & 3) + 8 * (q >> 2);
-            xt[(ro + 4 * h) * XS + r] = rb + ro < row_end ? acc_s[q] : 0.f;
+            xt[(ro + 4 * h) * XS + r] = keep_if_positive(row_end - (rb + ro), acc_s[q]);     // (r06: was a select on sixteen parked compares)
         }
     }
 }
@@ -620,7 +629,7 @@ __device__ inline void fused_fc_pos(const TrunkFusedArgs &a, float *Xs, const fl
             acc = fmaf(p0, wps[n * 3 + 0], acc);
             acc = fmaf(p1, wps[n * 3 + 1], acc);
             acc = fmaf(p2, wps[n * 3 + 2], acc);
-            v[j] = r0 + row < r1 ? acc : 0.f;
+            v[j] = keep_if_positive(r1 - (r0 + row), acc);
         }
         *reinterpret_cast<float4 *>(Xs + row * XS + c0 + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -660,6 +669,52 @@ __device__ inline void fused_pool_local(float *Xs, const int (&span)[TR / NG], i
         if ((abl >> 1) & 1) continue;
         *reinterpret_cast<float4 *>(pooled + (size_t)(s + me) * 32 + lane * 4) = pv;
         winner[(size_t)(s + me) * G + lane] = (uint8_t)((b.a.x == me) | ((b.a.y == me) << 1) | ((b.a.z == me) << 2) | ((b.a.w == me) << 3));
+    }
+}
+
+// The same pooling with ONE scan per cell (r06, last day): phase A -- a lane group per CELL scans its rows once (the row-parallel form
+// above reads a cell of L rows L times: fine for the 2-3-row cells of a sparse tile, 174 of 633 us when units pack 30-60-row
+// cells) and leaves the pooled row in the right half of the cell's FIRST row and the four winners as bytes in `args`; barrier;
+// phase B -- a lane group per ROW copies its cell's result into its own right half, writes the global pooled row and its winner
+// bits.  Same visiting order per cell (ascending rows, strict >), so values and winners are those of the form above bit for bit.
+// cstart[c] = first row of cell c inside the unit, cstart[ncell] = rows.  Phase B writes only non-first rows' right halves and
+// reads only first rows', so it needs no barrier inside.
+__device__ inline void fused_pool_cells(float *Xs, unsigned *args, const uint8_t *cstart, int ncell, const int (&span)[TR / NG], int s,
+                                        int rows, uint8_t *winner, float *pooled, int tid, int abl = 0) {
+    const int lane = tid & (G - 1), grp = tid >> 3;
+    for (int c = grp; c < ncell; c += NG) {
+        const int cs = cstart[c], ce = cstart[c + 1];
+        Best b; best_init(b);
+        int n = cs;
+        for (; n + 3 < ce; n += 4) {
+            const float *xp = Xs + n * XS + lane * 4;
+            const float4 v0 = *reinterpret_cast<const float4 *>(xp), v1 = *reinterpret_cast<const float4 *>(xp + XS);
+            const float4 v2 = *reinterpret_cast<const float4 *>(xp + 2 * XS), v3 = *reinterpret_cast<const float4 *>(xp + 3 * XS);
+            best_strict(b, v0, n); best_strict(b, v1, n + 1); best_strict(b, v2, n + 2); best_strict(b, v3, n + 3);
+        }
+        for (; n < ce; ++n) best_strict(b, *reinterpret_cast<const float4 *>(Xs + n * XS + lane * 4), n);
+        // untouched (all NaN) -> 0, as torch_scatter's fill of cells that no value entered
+        *reinterpret_cast<float4 *>(Xs + cs * XS + 32 + lane * 4) =
+            make_float4(b.a.x == -1 ? 0.f : b.v.x, b.a.y == -1 ? 0.f : b.v.y, b.a.z == -1 ? 0.f : b.v.z, b.a.w == -1 ? 0.f : b.v.w);
+        args[cs * G + lane] = (unsigned)(b.a.x & 255) | ((unsigned)(b.a.y & 255) << 8) | ((unsigned)(b.a.z & 255) << 16) |
+                              ((unsigned)(b.a.w & 255) << 24);              // (-1 -> 255: no row of a 128-row tile)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < TR / NG; ++p) {
+        const int me = p * NG + grp;
+        if (me >= rows) {
+            *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int cs = span[p] & 255;
+        const float4 pv = *reinterpret_cast<const float4 *>(Xs + cs * XS + 32 + lane * 4);
+        const unsigned pk = args[cs * G + lane];
+        if (me != cs) *reinterpret_cast<float4 *>(Xs + me * XS + 32 + lane * 4) = pv;
+        if ((abl >> 1) & 1) continue;
+        *reinterpret_cast<float4 *>(pooled + (size_t)(s + me) * 32 + lane * 4) = pv;
+        winner[(size_t)(s + me) * G + lane] = (uint8_t)(((pk & 255u) == (unsigned)me) | ((((pk >> 8) & 255u) == (unsigned)me) << 1) |
+                                                        ((((pk >> 16) & 255u) == (unsigned)me) << 2) | (((pk >> 24) == (unsigned)me) << 3));
     }
 }
 
@@ -708,9 +763,15 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     __shared__ float wps[256];
     __shared__ int unit[2];
     __shared__ unsigned long long heads[2];
+    __shared__ uint8_t cstart[TR + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 192) wps[tid] = a.wpos[tid];
     if (tid < 64) wps[192 + tid] = a.bpos[tid];
+    // fc_pos of the workgroup's FIRST unit reads wps before the unit's first barrier.  r06 (last day): without this barrier a wave
+    // that loads none of wps (wave 3) could get there first and compute its 32 rows with whatever the LDS held -- the same values
+    // when the previous workgroup on the CU was this kernel's (which is why the kernel alone never showed it), something else beside
+    // the split convolutions: 2 of 4 000 launches, one unit each (profiles/coresidency_trunk_fused.py, r06_coresidency.txt section 8)
+    __syncthreads();
 #ifdef T2H_TRUNK_ABLATE
     const int abl = a.ablate;
 #else
@@ -763,13 +824,13 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                         acc = fmaf(p0, wps[n * 3 + 0], acc);
                         acc = fmaf(p1, wps[n * 3 + 1], acc);
                         acc = fmaf(p2, wps[n * 3 + 2], acc);
-                        v[j] = row < rows ? acc : 0.f;
+                        v[j] = keep_if_positive(rows - row, acc);
                     }
                     *reinterpret_cast<float4 *>(Xs + row * XS + c0 + c) = make_float4(v[0], v[1], v[2], v[3]);
                 }
                 if (tid < TR) cells[tid] = cid;                  // (Hsm is free until the unit's first GEMM)
             }
-            __syncthreads();                                 // X, the cell ids, block 0's weights (and wps, the first time)
+            __syncthreads();                                 // X, the cell ids, block 0's weights
             if (tid < TR) {
                 const bool head = tid == 0 || cells[tid] != cells[tid - 1];
                 const unsigned long long m = __ballot(head);
@@ -777,6 +838,7 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
             }
             __syncthreads();
             int span[TR / NG];
+            int ncell;
             {
                 const unsigned long long m0 = heads[0], m1 = heads[1];
 #pragma unroll
@@ -784,6 +846,18 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                     const int me = p * NG + (tid >> 3);
                     span[p] = mask_prev_head(m0, m1, me) | (mask_next_head(m0, m1, me) << 8);
                 }
+                // the unit's cells as a list (rows past the unit carry unique ids: heads that do not count).  Read first behind the
+                // barrier that follows the block's GEMMs
+                const unsigned long long v0 = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+                const unsigned long long v1 = rows >= 128 ? ~0ull : (rows > 64 ? ((1ull << (rows - 64)) - 1) : 0ull);
+                const int n0 = __popcll(m0 & v0);
+                ncell = n0 + __popcll(m1 & v1);
+                if (tid < rows) {
+                    const unsigned long long mine = tid < 64 ? m0 : m1;
+                    if ((mine >> (tid & 63)) & 1)
+                        cstart[(tid < 64 ? 0 : n0) + __popcll(mine & ((1ull << (tid & 63)) - 1))] = (uint8_t)tid;
+                }
+                if (tid == 0) cstart[ncell] = (uint8_t)rows;         // (rows == 128 -> 128: fits a byte)
             }
             if (!a.bounds && kn < n_units) {               // (no bounds array: the next unit's lookup, off the critical path)
                 if (tid == 0) { unit[0] = (abl & 16) ? min(kn * a.stride, a.M) : unit_start(a, kn); unit[1] = (abl & 16) ? min((kn + 1) * a.stride, a.M) : unit_start(a, kn + 1); }
@@ -803,7 +877,11 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                 }
                 if (!(abl & 4) || last) stage_block_weights(a, last ? 0 : b + 1, W0s, Wss, W1s, Wcs, bsm, tid);
                 if (last) break;
-                if (!(abl & 1)) fused_pool_local(Xs, span, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
+                if (!(abl & 1)) {
+                    if (abl & 32) fused_pool_local(Xs, span, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
+                    else fused_pool_cells(Xs, reinterpret_cast<unsigned *>(Hsm), cstart, ncell, span, s, rows, a.winner[b + 1],
+                                          a.pooled[b + 1], tid, abl);
+                }
                 __syncthreads();
             }
         } else if (rows > TR) {

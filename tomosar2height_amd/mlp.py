@@ -620,13 +620,13 @@ def _fused_trunk_applicable(pts, params, n_blocks) -> bool:
     return tuple(params[-2].shape) == (32, 32)
 
 
-# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block): 530 against 737 us at
-# four tiles per launch, 196-218 against 192 us at one (profiles/r06_trunk_fused.txt: its 1 037 work units of one tile are 2.03
-# rounds of the 512 resident workgroups, i.e. three).  T2H_TRUNK_FUSED: "auto" (default) = from _TRUNK_FUSED_MIN_ROWS rows on -- the
-# coalesced micro-batches --, "1" always, "0" never
+# r06: the whole trunk forward in one launch (t2h_trunk_fused_fwd, bit-identical to one launch per block).  With one scan per cell in
+# its pooling (fused_pool_cells) it is ahead at every size measured: 453 against 726 us at four tiles per launch, 143 against 193 at
+# one, 40 against 58 at 7 k rows, the 9 us that build a tile's work units included once (profiles/r06_trunk_fused.txt).
+# T2H_TRUNK_FUSED: "auto" (default) = from T2H_TRUNK_FUSED_MIN_ROWS rows on (0: always), "1" always, "0" never (one launch per block)
 _TRUNK_FUSED_MODE = os.environ.get("T2H_TRUNK_FUSED", "auto")
 _TRUNK_FUSED = _TRUNK_FUSED_MODE != "0"
-_TRUNK_FUSED_MIN_ROWS = 0 if _TRUNK_FUSED_MODE == "1" else int(os.environ.get("T2H_TRUNK_FUSED_MIN_ROWS", "196608"))
+_TRUNK_FUSED_MIN_ROWS = 0 if _TRUNK_FUSED_MODE == "1" else int(os.environ.get("T2H_TRUNK_FUSED_MIN_ROWS", "0"))
 _TRUNK_FUSED_STRIDE = int(os.environ.get("T2H_TRUNK_FUSED_STRIDE", "0"))
 _TRUNK_UNIT_BOUNDS = os.environ.get("T2H_TRUNK_UNIT_BOUNDS", "1") != "0"     # greedy units built once per tile index (0: fixed-stride windows looked up in the kernel)
 
