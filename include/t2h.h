@@ -40,7 +40,7 @@ extern "C" {
 #define T2H_ERR_LAUNCH (-2)   /* HIP reported an error at launch */
 #define T2H_ERR_WORKSPACE (-3) /* workspace too small */
 
-#define T2H_ABI_VERSION 18
+#define T2H_ABI_VERSION 19
 #define T2H_MAX_NBITS 10      /* finest plane resolution up to 1024 */
 #define T2H_MAX_RAGGED_TILES 64 /* tiles per ragged batch (t2h_tile_build_ragged) */
 
@@ -53,6 +53,12 @@ const char *t2h_last_error_string(void);
  * exactly like `rocprofv3 --kernel-trace --stats` does.  t2h_clear_kernel_name() resets it. */
 const char *t2h_last_kernel_name(void);
 void t2h_clear_kernel_name(void);
+/* Test instrumentation (no reference counterpart): fills the LDS of every CU that is free on `stream`'s turn with NaN
+ * patterns -- one 160 KB workgroup per CU, two rounds.  A kernel that reads LDS before writing it (or before the barrier
+ * behind the write) normally finds the previous workgroup's values there, which are the right ones when that workgroup was
+ * the same kernel's; behind this call it finds NaNs.  T2H_POISON_LDS=1 makes the Python layer issue it before every entry
+ * point.  It catches LDS that is never written; a race that is usually won (the writer usually first) stays invisible. */
+int t2h_debug_poison_lds(t2h_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * coordinate2index(x, reso)                                     utils/coordinate.py:12-28

@@ -17,4 +17,5 @@ b.build_variant(os.path.join(lab, "libt2h_select.so"), {"point_grid": {"defines"
 b.build_variant(os.path.join(lab, f"libt2h_select_pad{pad}.so"), {"point_grid": {"defines": ["T2H_TAPS_BY_SELECT"], "pad": pad}})
 b.build_variant(os.path.join(lab, f"libt2h_trunk_pad{pad}.so"), {"trunk": {"pad": pad}})
 b.build_variant(os.path.join(lab, "libt2h_trunk_ablate.so"), {"trunk": {"defines": ["T2H_TRUNK_ABLATE"]}})      # profiles/trunk_fused_probe.py
+b.build_variant(os.path.join(lab, "libt2h_trunk_nobarrier.so"), {"trunk": {"defines": ["T2H_LAB_NO_PROLOGUE_BARRIER"]}})   # r06_coresidency.txt section 8
 print(sorted(os.listdir(lab)))

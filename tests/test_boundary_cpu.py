@@ -197,7 +197,8 @@ def test_every_entry_point_rejects_bad_arguments_without_a_gpu():
         "t2h_nhwc_to_nchw": (n, 1, 32, 64, n, n),
     }
     launching = [k for k, (res, _a) in _lib.SIGNATURES.items() if res is _lib._i and k not in ("t2h_abi_version", "t2h_pool_winner_stride", "t2h_adamw_chunk_elems", "t2h_conv3x3_bx3_supported", "t2h_gemm_bx3_supported", "t2h_gemm_bx3_wgrad_supported", "t2h_conv3x3_bx3_dgrad_rank1_supported", "t2h_upconv2x2_bx3_supported",
-                                                                                    "t2h_reduce_capture_begin", "t2h_reduce_capture_pending", "t2h_reduce_capture_end")]
+                                                                                    "t2h_reduce_capture_begin", "t2h_reduce_capture_pending", "t2h_reduce_capture_end",
+                                                                                    "t2h_debug_poison_lds")]          # (test instrumentation: no arguments to reject)
     assert sorted(cases) == sorted(launching), set(launching) ^ set(cases)
     for name, args in cases.items():
         rc = getattr(lib, name)(*args)

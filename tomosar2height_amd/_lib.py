@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # T2H_LIBRARY: load another build of the same ABI (A/B runs of a kernel change; a site-specific install path)
 LIB_PATH = os.environ.get("T2H_LIBRARY") or os.path.join(_HERE, "libt2h_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -23,6 +23,7 @@ SIGNATURES = {
     "t2h_last_error_string": (ctypes.c_char_p, []),
     "t2h_last_kernel_name": (ctypes.c_char_p, []),
     "t2h_clear_kernel_name": (None, []),
+    "t2h_debug_poison_lds": (_i, [_vp]),
     "t2h_coordinate2index": (_i, [_vp, _i, _i64, _i, _vp, _vp]),
     "t2h_tile_workspace_bytes": (_sz, [_i, _i, _i]),
     "t2h_tile_build": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -341,6 +342,10 @@ def timing() -> bool:
 _fn_cache = {}
 
 
+# test instrumentation: NaN patterns into every free CU's LDS before every entry point (t2h_debug_poison_lds, include/t2h.h)
+_POISON_LDS = os.environ.get("T2H_POISON_LDS", "0") == "1"
+
+
 def call(name: str, *args, nbytes: int = 0, flops: int = 0, tag: str = None):
     """Invoke ``name`` from the library, raising on a non-zero return code.  ``nbytes`` / ``flops`` = the
     ALGORITHMIC HBM bytes / floating-point operations of this launch, only used when a
@@ -348,6 +353,8 @@ def call(name: str, *args, nbytes: int = 0, flops: int = 0, tag: str = None):
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(load(), name)
+    if _POISON_LDS:
+        load().t2h_debug_poison_lds(stream())
     tl = _timeline
     if tl is None:
         rc = fn(*args)

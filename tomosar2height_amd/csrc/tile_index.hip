@@ -204,6 +204,16 @@ __global__ void tile_finalize_kernel(const float *__restrict__ cloud, int dim, i
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// t2h_debug_poison_lds: the whole LDS of a CU written with quiet-NaN patterns, the workgroup held for a few microseconds so that a
+// round of them lands on distinct CUs (each takes a CU's whole LDS)
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words, unsigned *sink) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < words; i += 256) lds_words[i] = 0x7fc00000u | (unsigned)(i & 0xffff);
+    __syncthreads();
+    for (int k = 0; k < 40; ++k) __builtin_amdgcn_s_sleep(127);
+    if (lds_words[(threadIdx.x * 97) % words] == 1u) sink[0] = 1u;       // (keeps the stores)
+}
+
 }  // namespace t2h
 
 using namespace t2h;
@@ -212,6 +222,21 @@ T2H_API int t2h_abi_version(void) { return T2H_ABI_VERSION; }
 T2H_API const char *t2h_last_error_string(void) { return err_buf(); }
 T2H_API const char *t2h_last_kernel_name(void) { return noted_kernel(); }
 T2H_API void t2h_clear_kernel_name(void) { note_kernel(""); }
+
+T2H_API int t2h_debug_poison_lds(t2h_stream_t stream) {
+    static unsigned *sink = nullptr;
+    static int bytes = 0;
+    if (!sink) {
+        if (hipMalloc(&sink, 256) != hipSuccess) return fail(T2H_ERR_LAUNCH, "debug_poison_lds: hipMalloc failed");
+        bytes = 160 * 1024;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            bytes = 64 * 1024;
+        }
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(512), dim3(256), (size_t)bytes, as_stream(stream), bytes / 4, sink);
+    return check_launch("debug_poison_lds");
+}
 
 T2H_API int t2h_coordinate2index(const float *pts, int stride, int64_t total, int reso, int64_t *index,
                                  t2h_stream_t stream) {

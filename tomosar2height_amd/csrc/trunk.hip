@@ -771,7 +771,9 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
     // that loads none of wps (wave 3) could get there first and compute its 32 rows with whatever the LDS held -- the same values
     // when the previous workgroup on the CU was this kernel's (which is why the kernel alone never showed it), something else beside
     // the split convolutions: 2 of 4 000 launches, one unit each (profiles/coresidency_trunk_fused.py, r06_coresidency.txt section 8)
+#ifndef T2H_LAB_NO_PROLOGUE_BARRIER                         // (lab build: shows T2H_POISON_LDS catching it in tests/test_hip_trunk.py)
     __syncthreads();
+#endif
 #ifdef T2H_TRUNK_ABLATE
     const int abl = a.ablate;
 #else
