@@ -44,6 +44,24 @@ def _library_fallback_policy():
     _lib.allow_library_fallback(False).set()
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _release_cached_device_memory():
+    """After every test MODULE on a GPU box: hand the caching allocator's free blocks back to the driver.  Every Trainer of the
+    window tests makes its own tile streams, every stream keeps its own pool of freed blocks, and this process never needs them
+    again -- but the data-parallel tests start up to eight other processes on the same GPU (r06: with two more windows per case
+    in test_coresidency.py those ranks ran out of the 288 GB)."""
+    yield
+    try:
+        import gc
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
