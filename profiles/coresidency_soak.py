@@ -1,5 +1,5 @@
 """r05: how often does a pipelined window differ from the step-synchronised one?  (tests/test_coresidency.py, many times over)
-    python profiles/coresidency_soak.py <windows> [image] [prepared] [coalesced] [fresh] [stall] [points=N]
+    python profiles/coresidency_soak.py <windows> [image] [prepared] [coalesced] [fresh] [stall[=k]] [stallb=k] [points=N]
 r06: `coalesced` = the Trainer's default (nine tiles: micro-batches of 1 + 4 + 4 whose forwards and backwards overlap); without it
 every tile is issued by its own call (four tiles), as in r05.  `fresh` = every window on a model with its own weights, its
 step-synchronised twin run AFTER it: a buffer that is read before it is filled then cannot happen to hold the previous window's copy
@@ -17,7 +17,10 @@ from tomosar2height_amd.trainer import Trainer
 
 windows = int(sys.argv[1])
 image, ahead, coalesced = "image" in sys.argv[2:], "prepared" in sys.argv[2:], "coalesced" in sys.argv[2:]
-fresh, stall = "fresh" in sys.argv[2:], "stall" in sys.argv[2:]       # stall: the second forward of every window starts 0.1 s late
+fresh = "fresh" in sys.argv[2:]
+# stall / stall=k: forward number k (default 1: the second) of every window starts 0.1 s late on its stream; stallb=k: backward k does
+stall = next((int(a.split("=")[1]) if "=" in a else 1 for a in sys.argv[2:] if a == "stall" or a.startswith("stall=")), None)
+stallb = next((int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("stallb=")), None)
 points = next((int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("points=")), 40000)
 dev = torch.device("cuda:0")
 tiles = [{"inputs": synth_cloud(points, seed=700 + i).to(dev),
@@ -38,12 +41,20 @@ def run(ahead, stepsync, seed=15):
     losses, inner = [], tr._losses
 
     def rec(data, thr):
-        if stall and not stepsync and len(losses) == 1:
+        if stall is not None and not stepsync and len(losses) == stall:
             torch.cuda._sleep(int(3e8))
         l1, ce = inner(data, thr)
         losses.append(l1.detach())
         return l1, ce
     tr._losses = rec
+    inner_bwd, nb = tr._backward, [0]
+
+    def bwd(loss):
+        if stallb is not None and not stepsync and nb[0] == stallb:
+            torch.cuda._sleep(int(3e8))
+        nb[0] += 1
+        return inner_bwd(loss)
+    tr._backward = bwd
     nxt = prep(tiles[0])
     for i in range(len(tiles)):
         cur = nxt
@@ -72,5 +83,5 @@ for it in range(windows):
         worst = max(d, key=lambda k: float((got[k] - gold[k]).abs().max() / (gold[k].abs().max() + 1e-30))) if d else None
         print(f"window {it}: losses equal {[a == b for a, b in zip(ls, gl)]}, {len(d)} of {len(gold)} gradients differ {tops}; worst {worst} "
               f"{float((got[worst] - gold[worst]).abs().max() / (gold[worst].abs().max() + 1e-30)) if worst else 0:.2e}", flush=True)
-print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}{', coalesced' if coalesced else ''}{', fresh weights per window' if fresh else ''}{', second forward stalled' if stall else ''}, N = {points}: "
+print(f"{'cloud+image' if image else 'cloud-only'}{', prepared' if ahead else ''}{', coalesced' if coalesced else ''}{', fresh weights per window' if fresh else ''}{f', forward {stall} stalled' if stall is not None else ''}{f', backward {stallb} stalled' if stallb is not None else ''}, N = {points}: "
       f"{bad} of {windows} windows differ", flush=True)
