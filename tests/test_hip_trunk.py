@@ -250,3 +250,32 @@ def test_fused_backward_vs_float64_with_the_same_masks(name):
     for k, (a, b) in enumerate(zip(got, want)):
         scale = b.abs().max().item() + 1e-30
         assert (a.to(d) - b).abs().max().item() <= 1e-5 * scale, f"param {k}: {(a.to(d) - b).abs().max().item() / scale:.2e}"
+
+
+def test_trunk_forwards_behind_poisoned_lds():
+    """r06: t2h_debug_poison_lds (NaN patterns into the whole LDS of every free CU) in front of both trunk forwards: the results are
+    those of the clean run bit for bit -- neither form reads LDS it has not written.  (What the poison cannot show is a read that
+    usually comes after the write anyway: the missing barrier of r06_coresidency.txt section 8 passes this test too; that one is
+    pinned by the stalled windows of test_coresidency.py.)"""
+    from tomosar2height_amd import _lib, mlp
+    from tomosar2height_amd.tile import TileIndex
+    enc = _trunk_modules(seed=13)
+    tile = TileIndex(synth_cloud(30000, seed=4).to(_dev()), 256)
+    params = [p.detach() for p in _params(enc)]
+    blocks = [params[2 + 5 * i: 7 + 5 * i] for i in range(len(enc.blocks))]
+    lib = _lib.load()
+    old = mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_MIN_ROWS
+    try:
+        for fused in (True, False):
+            mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_MIN_ROWS = fused, 0
+            clean = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+            torch.cuda.synchronize()
+            for _ in range(3):
+                assert lib.t2h_debug_poison_lds(_lib.stream()) == 0
+                got = mlp._trunk_forward_fused(tile, tile.pts, params[0], params[1], blocks, params[-2], params[-1])
+                torch.cuda.synchronize()
+                for a, b in zip(clean, got):
+                    for x, y in zip(a if isinstance(a, (list, tuple)) else [a], b if isinstance(b, (list, tuple)) else [b]):
+                        assert (x is None and y is None) or torch.equal(x, y)
+    finally:
+        mlp._TRUNK_FUSED, mlp._TRUNK_FUSED_MIN_ROWS = old
