@@ -30,6 +30,9 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+#ifndef T2H_LAB_TRUNK_PRIO
+#define T2H_LAB_TRUNK_PRIO 0     // lab builds: 1 = s_setprio 1 around the one-launch forward's MFMA clusters, 2 = around its pooling
+#endif
 constexpr int TR = 128;          // rows per workgroup
 constexpr int XS = 68;           // row stride of 64-wide LDS tiles (floats)
 constexpr int HS = 36;           // row stride of 32-wide LDS tiles
@@ -558,7 +561,13 @@ __device__ inline void fused_block_gemms(float *Xs, float *Hsm, const float *W0s
     f32x16 acc_h, acc_s, acc_d;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc_h[q] = 0.f; acc_s[q] = 0.f; acc_d[q] = 0.f; }
+#if T2H_LAB_TRUNK_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
     if (!no_mfma) mfma_rows_pair<64>(xa, W0s + r * XS + 4 * h, Wss + r * XS + 4 * h, acc_h, acc_s);
+#if T2H_LAB_TRUNK_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     float *ht = Hsm + wave * 32 * HS;
     {
         const float b0 = bsm[r];
@@ -572,7 +581,13 @@ __device__ inline void fused_block_gemms(float *Xs, float *Hsm, const float *W0s
         }
     }
     wave_sync();
+#if T2H_LAB_TRUNK_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
     if (!no_mfma) mfma_rows<32, false>(ht + r * HS + 4 * h, W1s + r * HS + 4 * h, acc_d);
+#if T2H_LAB_TRUNK_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     {
         const float b1 = bsm[32 + r];
         float *op = out + (size_t)rb * 32 + r;
@@ -881,8 +896,16 @@ __global__ __launch_bounds__(256, 2) void trunk_fused_fwd_kernel(TrunkFusedArgs 
                 if (last) break;
                 if (!(abl & 1)) {
                     if (abl & 32) fused_pool_local(Xs, span, s, rows, a.winner[b + 1], a.pooled[b + 1], tid, abl);
-                    else fused_pool_cells(Xs, reinterpret_cast<unsigned *>(Hsm), cstart, ncell, span, s, rows, a.winner[b + 1],
-                                          a.pooled[b + 1], tid, abl);
+                    else {
+#if T2H_LAB_TRUNK_PRIO == 2
+                        __builtin_amdgcn_s_setprio(1);
+#endif
+                        fused_pool_cells(Xs, reinterpret_cast<unsigned *>(Hsm), cstart, ncell, span, s, rows, a.winner[b + 1],
+                                         a.pooled[b + 1], tid, abl);
+#if T2H_LAB_TRUNK_PRIO == 2
+                        __builtin_amdgcn_s_setprio(0);
+#endif
+                    }
                 }
                 __syncthreads();
             }
