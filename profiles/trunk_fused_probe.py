@@ -66,8 +66,9 @@ def build_units():
 
 
 if True:
-    print(f"  building the unit list (once per tile index)   {timed(build_units):8.1f} us")
-for stride in (112, 96, 128):
+    if os.environ.get("T2H_PROBE_DEFAULT_ONLY") != "1":
+        print(f"  building the unit list (once per tile index)   {timed(build_units):8.1f} us")
+for stride in (() if os.environ.get("T2H_PROBE_DEFAULT_ONLY") == "1" else (112, 96, 128)):      # (1: the PMC passes of pmc_trunk.sh)
     print(f"  one launch, stride {stride:3d}                        {timed(run(True, stride)):8.1f} us")
 if "ablate" in os.environ.get("T2H_LIBRARY", ""):
     names = {1: "no pooling", 2: "no global stores", 4: "weights staged once", 8: "no MFMAs", 16: "unit bounds without the cell lookups",
