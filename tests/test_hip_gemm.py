@@ -354,3 +354,30 @@ def test_split_weights_filled_on_one_stream_are_waited_for_on_another():
     refc = torch.nn.functional.conv2d(xi.double().cpu(), wc.double().cpu(), padding=1)
     errc = float((yc.double().cpu() - refc).abs().max() / refc.abs().max())
     assert errc < 1e-5, errc
+
+
+def test_ready_orders_a_fill_before_another_streams_first_use():
+    """_lib.Ready by itself: a buffer filled behind a 0.1 s spin on stream a, marked, read on stream b after wait() -- the reader sees
+    the fill; a second wait() on b and any wait() on a are look-ups only (no event is waited for twice)."""
+    from tomosar2height_amd import _lib
+    dev = torch.device("cuda:0")
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    buf = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+    r = _lib.Ready()
+    r.wait()                                                   # nothing marked yet: a no-op
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(int(3e8))
+        buf.fill_(3.0)
+        r.mark()
+        r.wait()
+        assert r.seen == {_lib.stream()}
+    with torch.cuda.stream(b):
+        r.wait()
+        got = buf.sum()
+        assert _lib.stream() in r.seen and len(r.seen) == 2
+        ev = r.event
+        r.wait()
+        assert r.event is ev
+    torch.cuda.synchronize()
+    assert float(got) == 3.0 * (1 << 20)
