@@ -202,9 +202,9 @@ def point_update_note():
     from tomosar2height_amd import deferred, mlp
     parts = []
     if mlp.GRID_FIRST_MIN_RATIO > 0:
-        parts.append(f"fc_comm.0 on the pixels at levels with >= {mlp.GRID_FIRST_MIN_RATIO:g} points/pixel")
+        parts.append(f"fc_comm.0 on pixels where >= {mlp.GRID_FIRST_MIN_RATIO:g} points/pixel")
     if deferred.DEFER_MIN_CHANNELS > 0:
-        parts.append(f"fc_comm.2 / fc_c on per-cell sums from the first level with >= {deferred.DEFER_MIN_CHANNELS} channels")
+        parts.append(f"fc_comm.2 / fc_c on per-cell sums from >= {deferred.DEFER_MIN_CHANNELS} channels on")
     return "; ".join(parts) if parts else "point-wise as the reference (alto.py:121-130)"
 
 
@@ -242,9 +242,8 @@ def cpu_baseline(args):
     torch_ref.train_loss(model, small["inputs"], None, small["dsm"]).backward()
     main = leg(min(args.cpu_threads, host_cores), args.cpu_warmup, args.cpu_steps)
     out = {"value": main["value"], "unit": "tiles/s", "cores": main["cores"], "kind": "port",
-           "sample": f"median of {main['timed_steps']} tile-steps (fwd+bwd, N={args.points}, fp32) after {main['warmup_steps']} "
-                     f"warm-up, oracle torch restatement, {main['median_s']} s/step, {main['cores']} threads "
-                     f"(reference default) on a {host_cores}-core host"}
+           "sample": f"median of {main['timed_steps']} tile-steps (fwd+bwd, N={args.points}) after {main['warmup_steps']} warm-up, "
+                     f"oracle torch restatement, {main['median_s']} s/step, {main['cores']} threads (reference default)"}
     if host_cores > main["cores"]:
         # "all cores", bounded: median of 3 timed steps after one warm-up at that thread count (the thread pool is
         # re-created), at most 64 threads -- with every hardware thread of a 256-thread host torch's CPU path needed 164 s
@@ -902,7 +901,7 @@ def main():
                        "grid_convs": ({"bf16x3": "t2h csrc/conv_bx3.hip: every fp32 product from six bf16 MFMAs (exact 3-way operand "
                                                  "split, fp32 accumulate; error vs float64 = the fp32 MFMA kernels'), planes >= 32 wide; "
                                                  "csrc/conv.hip (fp32 MFMA) for the rest",
-                                       "f16x2": "conv_bx3.hip: fp32 products from 3 fp16 MFMAs (2-way split, block scales; DESIGN 4.1b)",
+                                       "f16x2": "conv_bx3.hip: fp32 products from 3 fp16 MFMAs (2-way split, block scales)",
                                        "bf16": "t2h csrc/conv_bx3.hip, operands rounded to bf16 (one MFMA per product, fp32 accumulate)",
                                        "fp32": "t2h implicit-GEMM on fp32 MFMA (csrc/conv.hip)"}[grid.CONV_PRECISION]
                                       if (grid.USE_HIP_CONV and args.channels_last) else "MIOpen"),
@@ -940,14 +939,14 @@ def main():
                     out["roofline"]["rocprof_source"] = prof_src
                 out["roofline"]["entry_points"] = syms[0]["entry_points"]
                 out["roofline"]["traffic_source"] = traffic_src if out["roofline"]["traffic"] is not None else None
-                out["roofline"]["how"] = f"HIP events per launch, {args.profile_steps} untimed steps, overlaps off"
+                out["roofline"]["how"] = f"HIP events per launch, {args.profile_steps} untimed steps"
                 # the scatter-reduce kernels north_star names (pool_local and the largest mean)
                 # (compact: peak and unit are those of `bound` -- 8000 GB/s for hbm, 157.3 TFLOP/s fp32 MFMA for mfma)
                 out["roofline_scatter_reduce"] = [{k: v for k, v in roof(named[n], traffic.get(n, traffic.get(named[n]["symbol"]))).items()
                                                    if k not in ("peak", "unit", "launches_per_step")}
                                                   for n in SCATTER_REDUCE_TAGS if n in named]
                 out["roofline_top_symbols"] = [{"kernel": s["kernel"][:60], "ms_per_step": s["ms_per_step"], "frac": s["frac"],
-                                                "bound": s["bound"]} for s in syms[:4]]          # (the stdout line stays < 4 KB: the full table is in the file)
+                                                "bound": s["bound"]} for s in syms[:3]]          # (the stdout line stays < 4 KB: the full table is in the file)
                 out["t2h_kernels_ms_per_step"] = round(sum(k["ms_per_step"] for k in tags), 3)
                 # sum of the kernels' durations ALONE over the time of a timed step: > 1 is what the step's overlaps (side stream,
                 # tile pipeline) hide, plus whatever the per-launch event pairs of the profile leg over-read (2-3 %)
