@@ -37,7 +37,7 @@ python3 bench.py --steps 20 --warmup 5 --kernel-table $OUT/bench_kernels.json > 
 # tests/test_hip_ragged.py): micro-batched accumulation window; tiles from the device tile producer; BASELINE configs[2]
 # (cloud+image, bf16 mode) and its fp32 sibling; the other tile sizes of SURVEY 8d; the no-skew control
 python3 bench.py --steps 20 --warmup 5 --coalesce 1 --skip-cpu-baseline --kernel-table $OUT/bench_b1_kernels.json > $OUT/bench_b1.json 2> $OUT/bench_b1.err
-python3 bench.py --steps 64 --warmup 8 --coalesce 8 --skip-cpu-baseline --profile-steps 0 --sustain-s 2 > $OUT/bench_b8.json 2> /dev/null
+python3 bench.py --steps 64 --warmup 24 --coalesce 8 --skip-cpu-baseline --profile-steps 0 --sustain-s 2 > $OUT/bench_b8.json 2> /dev/null      # (warm-up: both tile streams' pools)
 python3 bench.py --steps 20 --warmup 5 --from-producer --skip-cpu-baseline --kernel-table $OUT/bench_producer_kernels.json > $OUT/bench_producer.json 2> $OUT/bench_producer.err
 python3 bench.py --steps 20 --warmup 5 --use-image --mlp-precision bf16 --skip-cpu-baseline --profile-steps 0 > $OUT/bench_image_bf16.json 2> $OUT/bench_image_bf16.err
 python3 bench.py --steps 20 --warmup 5 --use-image --skip-cpu-baseline --profile-steps 0 > $OUT/bench_image_fp32.json 2> $OUT/bench_image_fp32.err
